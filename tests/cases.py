@@ -1,0 +1,47 @@
+"""Shared enumeration of the golden loss cases (tests/golden/losses_golden.npz, made by make_golden.py)."""
+LAMBDA_SCHEMES = [None, "ndcgLoss1_scheme", "ndcgLoss2_scheme", "lambdaRank_scheme", "ndcgLoss2PP_scheme",
+                  "rankNet_scheme", "rankNetWeightedByGTDiff_scheme", "rankNetWeightedByGTDiffPowed_scheme"]
+
+
+def close(a, b, rtol=1e-5, atol=1e-5):
+    """|a-b| <= atol + rtol*|b| -- the 1e-5 fp32 bar of BASELINE.json's north_star, relative for large values."""
+    import numpy as np
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return bool(np.all(np.abs(a - b) <= atol + rtol * np.abs(b)))
+
+
+def grad_close(g, gref, rtol=2e-4):
+    """gradient check: max abs error relative to the largest reference gradient entry of the tensor."""
+    import numpy as np
+    g = np.asarray(g, dtype=np.float64)
+    gref = np.asarray(gref, dtype=np.float64)
+    scale = max(float(np.abs(gref).max()), 1e-6)
+    return float(np.abs(g - gref).max()) <= rtol * scale + 1e-7
+
+
+def iter_loss_cases(gold):
+    """yields (name, kind, kwargs, s, y, ref_loss, ref_grad)"""
+    n = int(gold["n_cases"])
+    for ci in range(n):
+        pre = "c%d." % ci
+        s, y = gold[pre + "s"], gold[pre + "y"]
+        yield (pre + "listnet", "listnet", {}, s, y, gold[pre + "listnet.loss"], gold[pre + "listnet.grad"])
+        for a in (1.0, 2.5):
+            k = pre + "approxndcg.a%g" % a
+            yield (k, "approxndcg", dict(alpha=a), s, y, gold[k + ".loss"], gold[k + ".grad"])
+        yield (pre + "listmle", "listmle", dict(perm=gold[pre + "listmle.perm"]), s, y,
+               gold[pre + "listmle.loss"], gold[pre + "listmle.grad"])
+        for si, sch in enumerate(LAMBDA_SCHEMES):
+            for kk in (None, 5):
+                for red, lg in (("sum", "binary"), ("mean", "natural")):
+                    k = pre + "lambda.s%d.k%s.%s.%s" % (si, kk, red, lg)
+                    yield (k, "lambdaloss", dict(weighing_scheme=sch, k=kk, reduction=red, reduction_log=lg, sigma=1.3, mu=7.0),
+                           s, y, gold[k + ".loss"], gold[k + ".grad"])
+        for tr in (False, True):
+            for tau in (1.0, 0.1):
+                for kk in (None, 5):
+                    for pw in (True, False):
+                        k = pre + "neural.t%d.tau%g.k%s.p%d" % (int(tr), tau, kk, int(pw))
+                        yield (k, "neuralndcg", dict(transposed=tr, temperature=tau, k=kk, powered_relevancies=pw),
+                               s, y, gold[k + ".loss"], gold[k + ".grad"])

@@ -1,0 +1,149 @@
+"""Pins oracle/ (the CPU restatement) against (1) the literal known-answer constants of the reference's own
+tests and (2) golden vectors generated from the reference itself (tests/golden/make_golden.py).  CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import ltr_oracle as O
+from oracle import model_oracle as M
+from tests.cases import close, grad_close, iter_loss_cases
+
+PAD = -1.0
+
+
+def _a(x):
+    return np.asarray([x], dtype=np.float32)
+
+
+# ---- (1) KATs copied as numbers from /root/reference/tests/losses/*.py ----------------------------------
+def test_kat_approxndcg():          # tests/losses/test_approxndcg.py:10-20
+    l0 = O.approxndcg(_a([0.5, 0.3, 0.5]), _a([0.5, 0.3, 0.5]))[0]
+    l1 = O.approxndcg(_a([0.5, 0.3, 0.5, 1.0]), _a([0.5, 0.3, 0.5, PAD]))[0]
+    assert l0 == pytest.approx(-0.8499219417) and l1 == pytest.approx(l0)
+
+
+@pytest.mark.parametrize("scheme,log,expected", [
+    ("ndcgLoss1_scheme", "binary", 2.9272110462),       # tests/losses/test_lambdaloss.py:10-21
+    ("ndcgLoss2PP_scheme", "binary", 1.1244146823),     # :24-34
+    ("rankNet_scheme", "natural", 1.1962778568),        # :37-46
+])
+def test_kat_lambdaloss(scheme, log, expected):
+    l0 = O.lambdaloss(_a([0.5, 0.3, 0.5]), _a([0.5, 0.3, 0.5]), weighing_scheme=scheme, reduction_log=log)[0]
+    l1 = O.lambdaloss(_a([0.5, 0.3, 0.5, 1.0]), _a([0.5, 0.3, 0.5, PAD]), weighing_scheme=scheme, reduction_log=log)[0]
+    assert l0 == pytest.approx(expected) and l1 == pytest.approx(l0)
+
+
+def test_kat_listmle():             # tests/losses/test_listmle.py:14-22 (result independent of the shuffle here)
+    for perm in ([0, 1, 2], [2, 0, 1], [1, 2, 0]):
+        l0 = O.listmle(_a([0.5, 0.3, 0.5]), _a([1.0, 0.0, PAD]), perm)[0]
+        assert l0 == pytest.approx(0.5981389284133911)
+
+
+def _softmax(v):
+    v = np.asarray(v, np.float64)
+    e = np.exp(v - v.max())
+    return e / e.sum()
+
+
+def test_kat_listnet():             # tests/losses/test_listnet.py:16-46
+    r = O.listnet(_a([0.5, 0.2]), _a([1.0, 0.0]), eps=0.0)[0]
+    assert r == pytest.approx(-np.sum(_softmax([1.0, 0.0]) * np.log(_softmax([0.5, 0.2]))))
+    r = O.listnet(_a([0.5, -1e30]), _a([1.0, 0.0]))[0]
+    assert math.isfinite(r) and r == pytest.approx(-np.sum(_softmax([1.0, 0.0]) * np.log(_softmax([0.5, -1e30]) + 1e-10)))
+    r = O.listnet(_a([0.5, 0.2, 0.5]), _a([1.0, 0.0, PAD]))[0]
+    assert r == pytest.approx(-np.sum(_softmax([1.0, 0.0]) * np.log(_softmax([0.5, 0.2]) + 1e-10)))
+
+
+def test_kat_ndcg():                # tests/losses/test_ndcg.py:14-69 (idcg==0 -> 1.0 per metrics.py:8,24)
+    assert O.ndcg(_a([0.5, 0.2]), _a([1.0, 0.0]))[0][0, 0] == 1.0
+    assert O.ndcg(_a([0.5, 0.2]), _a([0.0, 1.0]))[0][0, 0] == pytest.approx(1 / math.log2(3))
+    assert O.ndcg(_a([0.5, 0.2]), _a([0.0, 0.0]))[0][0, 0] == 1.0
+    r = O.ndcg(_a([0.5, 0.2, 0.1]), _a([1.0, 0.0, 1.0]), ats=[1, 2])[0][0]
+    assert r == pytest.approx([1.0, 1.0 / (1.0 + 1 / math.log2(3))])
+    assert O.ndcg(_a([0.5, 0.2, 1.0]), _a([1.0, 0.0, PAD]))[0][0, 0] == 1.0
+    assert O.ndcg(_a([0.5, 0.2, 1.0]), _a([0.0, 1.0, PAD]))[0][0, 0] == pytest.approx(1 / math.log2(3))
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+def test_kat_neuralndcg_equals_ndcg_at_low_temperature(transposed):   # tests/losses/test_neuralndcg.py:16-94
+    cases = [
+        ([0.5, 0.2], [1.0, 0.0], 1e-4, None),
+        ([0.5, 0.2, 0.1, 0.4, 1.0, -1.0, 0.63], [1.0, 2.0, 2.0, 4.0, 1.0, 4.0, 3.0], 1e-4, None),
+        ([0.5, -1e30], [1.0, 0.0], 1e-4, None),
+        ([0.5, 0.2, 0.1, 0.4, 1.0, -1.0, 0.63, 1., 0.5, 0.3], [1.0, 2.0, 2.0, 4.0, 1.0, 4.0, 3.0, PAD, PAD, PAD], 1e-3, None),
+        ([0.5, 0.2, 0.1, 0.4, 1.0, -1.0, 0.63], [1.0, 2.0, 2.0, 4.0, 1.0, 4.0, 3.0], 1e-4, 3),
+    ]
+    for yp, yt, tau, k in cases:
+        r = O.neuralndcg(_a(yp), _a(yt), temperature=tau, k=k, transposed=transposed)[0]
+        e = O.ndcg(_a(yp), _a(yt), ats=None if k is None else [k])[0].mean()
+        assert math.isfinite(r) and -r == pytest.approx(e)
+
+
+# ---- (2) golden vectors from the reference itself ---------------------------------------------------------
+def _run_oracle(kind, kw, s, y):
+    if kind == "listnet":
+        return O.listnet(s, y)[:2]
+    if kind == "approxndcg":
+        return O.approxndcg(s, y, **kw)[:2]
+    if kind == "listmle":
+        return O.listmle(s, y, kw["perm"])[:2]
+    if kind == "lambdaloss":
+        return O.lambdaloss(s, y, **kw)[:2]
+    if kind == "neuralndcg":
+        return O.neuralndcg(s, y, **kw)[:2]
+    raise KeyError(kind)
+
+
+def test_losses_match_reference_golden(losses_golden):
+    bad = []
+    n = 0
+    for name, kind, kw, s, y, rl, rg in iter_loss_cases(losses_golden):
+        lo, go = _run_oracle(kind, kw, s, y)
+        n += 1
+        if not (close(lo, rl) and grad_close(go, rg)):
+            bad.append((name, float(lo), float(rl), float(np.abs(go - rg).max())))
+    assert n == 208 and not bad, bad[:10]
+
+
+def test_ndcg_and_sort_indices_match_reference_golden(losses_golden):
+    g = losses_golden
+    for ci in range(int(g["n_cases"])):
+        pre = "c%d." % ci
+        ats = [int(a) for a in g[pre + "ndcg.ats"]]
+        nd, order = O.ndcg(g[pre + "s"], g[pre + "y"], ats=ats)
+        dc, _ = O.dcg(g[pre + "s"], g[pre + "y"], ats=ats)
+        assert close(nd, g[pre + "ndcg.val"]) and close(dc, g[pre + "dcg.val"])
+        nvalid = (g[pre + "y"] != -1).sum(1)
+        for b in range(order.shape[0]):     # bit-exact on the valid prefix (tie policy: stable descending)
+            assert np.array_equal(order[b, :nvalid[b]], g[pre + "order"][b, :nvalid[b]])
+
+
+def _cfg_from_golden(g, pre):
+    def val(k):
+        v = g[pre + "cfg." + k]
+        return v
+    acts = {"ReLU": "ReLU", "Tanh": "Tanh", "Sigmoid": "Sigmoid", "-1": None}
+    return dict(n_features=int(val("n_features")), fc_sizes=[int(v) for v in np.atleast_1d(val("fc_sizes"))],
+                fc_activation=acts[str(val("fc_activation"))], fc_input_norm=bool(val("fc_input_norm")),
+                N=int(val("N")), d_ff=int(val("d_ff")), h=int(val("h")),
+                output_activation=acts[str(val("output_activation"))])
+
+
+def test_model_forward_backward_match_reference_golden(model_golden):
+    g = model_golden
+    for mi in range(int(g["n_models"])):
+        pre = "m%d." % mi
+        cfg = _cfg_from_golden(g, pre)
+        params = {k[len(pre + "param."):]: v for k, v in g.items() if k.startswith(pre + "param.")}
+        x, y = g[pre + "x"], g[pre + "y"]
+        mask = y == -1
+        sc, cache = M.forward(params, cfg, x, mask)
+        assert close(sc[~mask], g[pre + "scores"][~mask], rtol=1e-5, atol=2e-5)
+        lo, gs, _ = O.approxndcg(sc, y)
+        assert close(lo, g[pre + "loss"])
+        grads = M.backward(params, cfg, cache, gs)
+        allg = np.concatenate([g[pre + "grad." + k].ravel() for k in params])
+        scale = np.abs(allg).max()
+        for k in params:
+            assert np.abs(grads[k] - g[pre + "grad." + k]).max() <= 2e-4 * scale + 1e-8, k
