@@ -1,0 +1,94 @@
+"""ctypes binding of libltrx.so (include/ltrx.h).  No fallback: if the library is missing, importing the
+kernels fails loudly (the product path never routes through a CPU implementation)."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libltrx.so")
+
+_c_float_p = ctypes.c_void_p   # device pointers are passed as raw addresses
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+SIGNATURES = {
+    "ltrx_version": (_i, []),
+    "ltrx_listnet_workspace_bytes": (_sz, [_i, _i]),
+    "ltrx_listnet_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_listmle_workspace_bytes": (_sz, [_i, _i]),
+    "ltrx_listmle_fwd_bwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_approxndcg_workspace_bytes": (_sz, [_i, _i]),
+    "ltrx_approxndcg_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_lambdaloss_workspace_bytes": (_sz, [_i, _i]),
+    "ltrx_lambdaloss_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_neuralndcg_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ltrx_neuralndcg_prepare": (_i, [_vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp]),
+    "ltrx_neuralndcg_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_ndcg_workspace_bytes": (_sz, [_i, _i]),
+    "ltrx_ndcg_at": (_i, [_vp, _vp, _i, _i, ctypes.POINTER(ctypes.c_int), _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "ltrx_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_mha_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "ltrx_mha_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ltrx_selftest_mfma32x32x2": (_i, [_vp, _vp, _vp, _vp]),
+    "ltrx_mha_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use).  Raises if libltrx.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "allrank_amd: %s is missing -- build it with `python -m allrank_amd.build` "
+                "(there is no CPU fallback for the HIP kernels)" % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)     # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kinds = {-1: "invalid argument", -2: "unsupported shape"}
+        msg = kinds.get(rc, "HIP error %d" % (-rc - 1000) if rc <= -1000 else "error")
+        raise RuntimeError("libltrx %s failed: %s (code %d)" % (what, msg, rc))
+
+
+def ptr(t):
+    """raw device address of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("allrank_amd kernels run on the MI355X only: got a %s tensor (no CPU fallback; "
+                               "use the reference implementation on CPU)" % t.device)
+
+
+def workspace(nbytes, like):
+    return torch.empty(max(int(nbytes), 64), dtype=torch.uint8, device=like.device)
+
+
+def f32c(t):
+    """contiguous float32 view/copy"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

@@ -1,0 +1,111 @@
+// Device-side helpers shared by the libltrx kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/ltrx.h"
+
+#define LTRX_WAVE 64
+#define LTRX_MAX_WAVES 16  // 1024-thread workgroup
+
+#define LTRX_LAUNCH_CHECK()                                   \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) return LTRX_EHIP - (int)e__;       \
+  } while (0)
+
+namespace ltrx {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// ---- wave (64-lane) reductions by butterfly shuffles: every lane ends with the full result ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- workgroup reductions: wave partials through LDS, summed in a fixed order (deterministic). ----
+// `red` must hold LTRX_MAX_WAVES floats.  All threads of the block must call; all get the result.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();  // protect `red` from a previous use
+  if (lane_id() == 0) red[wave_id()] = v;
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  float t = 0.f;
+  for (int w = 0; w < nw; ++w) t += red[w];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if (lane_id() == 0) red[wave_id()] = v;
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  float t = red[0];
+  for (int w = 1; w < nw; ++w) t = fmaxf(t, red[w]);
+  return t;
+}
+__device__ __forceinline__ int block_sum_i(int v, int* red) {
+  v = wave_sum_i(v);
+  __syncthreads();
+  if (lane_id() == 0) red[wave_id()] = v;
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  int t = 0;
+  for (int w = 0; w < nw; ++w) t += red[w];
+  return t;
+}
+
+// ---- in-place inclusive prefix sum of an LDS array a[0..n) by the whole workgroup. ----
+// Each thread scans a contiguous chunk serially, the per-thread totals are scanned with wave shuffles and
+// a fixed-order combine across waves.  `red` holds LTRX_MAX_WAVES floats.  Contains the needed barriers;
+// a[] must be fully written (and barrier'd) by the caller before the call; it is valid for all threads after.
+__device__ __forceinline__ void block_inclusive_scan(float* a, int n, float* red) {
+  const int T = blockDim.x;
+  const int chunk = (n + T - 1) / T;
+  const int lo = threadIdx.x * chunk;
+  const int hi = min(lo + chunk, n);
+  float tot = 0.f;
+  for (int i = lo; i < hi; ++i) {
+    tot += a[i];
+    a[i] = tot;
+  }
+  // inclusive scan of `tot` across the wave
+  float inc = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float up = __shfl_up(inc, o, 64);
+    if (lane_id() >= o) inc += up;
+  }
+  __syncthreads();
+  if (lane_id() == 63) red[wave_id()] = inc;
+  __syncthreads();
+  float base = inc - tot;  // exclusive prefix inside the wave
+  for (int w = 0; w < wave_id(); ++w) base += red[w];
+  for (int i = lo; i < hi; ++i) a[i] += base;
+  __syncthreads();
+}
+
+__device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace ltrx
+
+// Final cross-slate reduction: out[0] = scale * sum_b per[b]  (fixed order -> deterministic).  One block.
+// (host launcher lives in ltrx_common.hip; kernels are never launched across translation units)
+int ltrx_launch_finalize_sum(const float* per, int B, float scale, float* out, hipStream_t s);
+// x[0] = (denom[0] != 0) ? x[0] / denom[0] : 0   (one thread; used for batch-global normalisers kept on the device)
+int ltrx_launch_div_by_device_scalar(float* x, const float* denom, hipStream_t s);

@@ -1,0 +1,424 @@
+// Fused masked self-attention over a slate, forward and backward, on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
+// Reference: allrank/models/transformer.py:137-156 (attention) as called from MultiHeadedAttention.forward
+// (:178-203): scores = q k^T / sqrt(d_k); masked_fill(key padded, -inf); softmax over keys; p_attn @ v.
+// The [B,h,L,L] score / probability tensors of the reference are never materialised (flash-style online
+// softmax); only the row log-sum-exp [B,h,L] is kept for the backward, which recomputes P tile by tile.
+//
+// ---- MFMA tiling (wave64, one 32x32 output tile per wave-instruction chain) -------------------------------------
+// v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32]; lane l supplies A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31]; D register r of lane l is D[row(r, l>>5)][l&31], row(r,h) = (r&3) + 8*(r>>2) + 4*h.
+// Exact fp32 products and accumulation (bit-equal to an fmaf chain) -> strict-parity arithmetic.
+//
+// Both contractions are arranged so that the wave's FIXED operand index (its 32 queries, or its 32 keys in the
+// dK/dV kernel) is the lane index l&31, and the STREAMED operand (a 32-row tile staged in LDS) supplies rows:
+//   "rows x fixed" product  (QK^T, dO V^T):   acc[r] = sum_c TILE[row(r,h)][c] * FIXED[l&31][c]
+//        A = TILE[l&31][c], B = FIXED[l&31][c] with c = h*DKP/2 + t at step t (the k index of the MFMA is free to
+//        be permuted: each half-wave walks its own half of the head dimension -> every lane reads 128 contiguous
+//        bytes of its LDS row with ds_read_b128 and keeps its FIXED fragment in DKP/2 registers).
+//   "cols x fixed" product  (P V, dS K, P^T dO, dS^T Q):  out[ct][r'] (+)= sum_row TILE[row][32 ct + (l&31)] * P[row][l&31]
+//        the probabilities produced by the first product are ALREADY in B-operand position (register r of half h is
+//        row(r,h)), so P never moves between lanes: A = TILE[row(r,h)][32 ct + (l&31)], B = p[r].
+// With this "swapped" orientation softmax statistics of a query are lane-local: a max/sum over 16 registers plus
+// one exchange with lane^32.
+//
+// ---- kernels ----------------------------------------------------------------------------------------------------
+//   fwd   : workgroup = 4 waves = 128 queries of one (slate, head); loops over 32-key tiles (K and V staged in LDS).
+//   bwd dq: same decomposition; per key tile: S, dP = dO V^T, dS = P (dP - delta) / sqrt(dk), dQ += dS K.
+//   bwd dkdv: workgroup = 4 waves = 128 keys; loops over 32-query tiles (Q and dO staged in LDS):
+//             dV += P^T dO, dK += dS^T Q.  No atomics anywhere: every output element has one owner (deterministic).
+// Arithmetic intensity: 4 L d_k flop per (query, head) against 4 d_k-float rows read once per workgroup -> compute
+// (fp32 MFMA) bound; K/V re-reads by the 2 workgroups of a (slate, head) are served by L2.
+#include "ltrx_device.h"
+
+using namespace ltrx;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+__device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <int DKP>
+struct Tile {
+  static constexpr int LDT = DKP + 4;          // row stride in floats (16-B aligned rows, conflict-free b128 reads)
+  static constexpr int FLOATS = 32 * LDT;
+};
+
+// Stage a [32][dk] slab (rows row0.., global row stride `rs` floats) into an LDS tile, zero-filling rows >= nrows
+// and columns >= dk.  All 256 threads participate; 16-B loads (dk % 4 == 0 is required by the host wrapper).
+template <int DKP>
+__device__ __forceinline__ void stage_tile(float* tile, const float* __restrict__ base, int row0, int nrows, int dk,
+                                           size_t rs) {
+  constexpr int C4 = DKP / 4;
+  for (int idx = threadIdx.x; idx < 32 * C4; idx += blockDim.x) {
+    const int r = idx / C4, c = (idx % C4) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 + r < nrows && c < dk) v = *reinterpret_cast<const float4*>(base + (size_t)(row0 + r) * rs + c);
+    *reinterpret_cast<float4*>(tile + r * Tile<DKP>::LDT + c) = v;
+  }
+}
+
+// FIXED fragment of the wave: lane keeps FIXED[row0 + (l&31)][half*DKP/2 + t], t = 0..DKP/2-1 (zero beyond nrows/dk).
+template <int DKP>
+__device__ __forceinline__ void load_fixed(float (&frag)[DKP / 2], const float* __restrict__ base, int row0, int nrows,
+                                           int dk, size_t rs) {
+  const int row = row0 + (threadIdx.x & 31);
+  const int c0 = ((threadIdx.x & 63) >> 5) * (DKP / 2);
+#pragma unroll
+  for (int t4 = 0; t4 < DKP / 8; ++t4) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = c0 + 4 * t4;
+    if (row < nrows && c < dk) v = *reinterpret_cast<const float4*>(base + (size_t)row * rs + c);
+    frag[4 * t4 + 0] = v.x;
+    frag[4 * t4 + 1] = v.y;
+    frag[4 * t4 + 2] = v.z;
+    frag[4 * t4 + 3] = v.w;
+  }
+}
+
+// acc[r] = sum_c TILE[row(r,half)][c] * FIXED[l&31][c]
+template <int DKP>
+__device__ __forceinline__ f32x16 rows_x_fixed(const float* tile, const float (&frag)[DKP / 2]) {
+  const int lane = threadIdx.x & 63;
+  const float* rowp = tile + (lane & 31) * Tile<DKP>::LDT + (lane >> 5) * (DKP / 2);
+  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t4 = 0; t4 < DKP / 8; ++t4) {
+    const float4 a = *reinterpret_cast<const float4*>(rowp + 4 * t4);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, frag[4 * t4 + 0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, frag[4 * t4 + 1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, frag[4 * t4 + 2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, frag[4 * t4 + 3], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// out[ct][r'] += sum_row TILE[row][32 ct + (l&31)] * p[row]   (p[r] belongs to row(r,half))
+template <int DKP>
+__device__ __forceinline__ void cols_x_p(const float* tile, const f32x16& p, f32x16 (&out)[DKP / 32]) {
+  const int lane = threadIdx.x & 63;
+  const int half = lane >> 5;
+  const float* colp = tile + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float* rp = colp + rowmap(r, half) * Tile<DKP>::LDT;
+#pragma unroll
+    for (int ct = 0; ct < DKP / 32; ++ct) out[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(rp[32 * ct], p[r], out[ct], 0, 0, 0);
+  }
+}
+
+// Store OUT^T accumulators: lane owns output row (row0 + l&31); register r of out[ct] is column 32 ct + row(r,half).
+// Registers 4g..4g+3 are 4 consecutive columns -> one 16-B store each.
+template <int DKP>
+__device__ __forceinline__ void store_rows(float* __restrict__ base, int row0, int nrows, int dk, size_t rs,
+                                           const f32x16 (&out)[DKP / 32], float scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = row0 + (lane & 31);
+  if (row >= nrows) return;
+  float* rp = base + (size_t)row * rs;
+#pragma unroll
+  for (int ct = 0; ct < DKP / 32; ++ct) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 32 * ct + 8 * g + 4 * (lane >> 5);
+      if (c < dk)
+        *reinterpret_cast<float4*>(rp + c) = make_float4(out[ct][4 * g + 0] * scale, out[ct][4 * g + 1] * scale,
+                                                         out[ct][4 * g + 2] * scale, out[ct][4 * g + 3] * scale);
+    }
+  }
+}
+
+template <int DKP>
+__device__ __forceinline__ void zero_acc(f32x16 (&o)[DKP / 32]) {
+#pragma unroll
+  for (int ct = 0; ct < DKP / 32; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------------
+template <int DKP>
+__global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v,
+                                                              const uint8_t* __restrict__ kpm, int L, int h, int dk,
+                                                              int rs, float* __restrict__ o, int ors,
+                                                              float* __restrict__ lse, float scale) {
+  __shared__ __attribute__((aligned(16))) float ktile[Tile<DKP>::FLOATS];
+  __shared__ __attribute__((aligned(16))) float vtile[Tile<DKP>::FLOATS];
+  __shared__ float kmask[32];
+  const int b = blockIdx.y / h, head = blockIdx.y % h;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const size_t slate = (size_t)b * L;
+  const float* qb = q + slate * rs + (size_t)head * dk;
+  const float* kb = k + slate * rs + (size_t)head * dk;
+  const float* vb = v + slate * rs + (size_t)head * dk;
+
+  float qfrag[DKP / 2];
+  load_fixed<DKP>(qfrag, qb, q0, L, dk, rs);
+  f32x16 oacc[DKP / 32];
+  zero_acc<DKP>(oacc);
+  float m = -INFINITY, l = 0.f;
+
+  const int nkt = (L + 31) / 32;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();   // previous tile fully consumed
+    stage_tile<DKP>(ktile, kb, kt * 32, L, dk, rs);
+    stage_tile<DKP>(vtile, vb, kt * 32, L, dk, rs);
+    if (threadIdx.x < 32) {
+      const int key = kt * 32 + threadIdx.x;
+      kmask[threadIdx.x] = (key >= L || kpm[slate + key]) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    f32x16 s = rows_x_fixed<DKP>(ktile, qfrag);
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = (kmask[rowmap(r, half)] != 0.f) ? -INFINITY : s[r] * scale;
+      mt = fmaxf(mt, s[r]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);   // mn == -inf implies m == -inf
+    float ps = 0.f;
+    f32x16 p;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = (s[r] == -INFINITY) ? 0.f : expf(s[r] - mn);
+      ps += p[r];
+    }
+    l = l * alpha + ps;
+#pragma unroll
+    for (int ct = 0; ct < DKP / 32; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[ct][r] *= alpha;
+    cols_x_p<DKP>(vtile, p, oacc);
+    m = mn;
+  }
+  const float lt = l + __shfl_xor(l, 32, 64);
+  const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;   // a row whose keys are all padded: 0 (the reference yields NaN)
+  store_rows<DKP>(o + slate * ors + (size_t)head * dk, q0, L, dk, ors, oacc, inv);
+  const int qrow = q0 + (lane & 31);
+  if (half == 0 && qrow < L) lse[((size_t)b * h + head) * L + qrow] = (lt > 0.f) ? m + logf(lt) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward: delta[b,h,l] = sum_c dO[b,l,h,c] * O[b,l,h,c]
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ltrx_mha_delta_kernel(const float* __restrict__ o, const float* __restrict__ dout,
+                                                             int B, int L, int h, int dk, int ors,
+                                                             float* __restrict__ delta) {
+  const size_t n = (size_t)B * L * h;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const int head = (int)(idx % h);
+    const size_t bl = idx / h;            // b*L + l
+    const int b = (int)(bl / L), lq = (int)(bl % L);
+    const float* op = o + bl * ors + (size_t)head * dk;
+    const float* dp = dout + bl * ors + (size_t)head * dk;
+    float acc = 0.f;
+    for (int c = 0; c < dk; c += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(op + c);
+      const float4 g = *reinterpret_cast<const float4*>(dp + c);
+      acc += a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
+    }
+    delta[((size_t)b * h + head) * L + lq] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward: dQ   (wave owns 32 queries, streams key tiles)
+// ------------------------------------------------------------------------------------------------------------------
+template <int DKP>
+__global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const uint8_t* __restrict__ kpm, const float* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta, int L, int h, int dk, int rs, int ors, float* __restrict__ dq, int drs,
+    float scale) {
+  __shared__ __attribute__((aligned(16))) float ktile[Tile<DKP>::FLOATS];
+  __shared__ __attribute__((aligned(16))) float vtile[Tile<DKP>::FLOATS];
+  __shared__ float kmask[32];
+  const int b = blockIdx.y / h, head = blockIdx.y % h;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const size_t slate = (size_t)b * L;
+  const float* kb = k + slate * rs + (size_t)head * dk;
+  const float* vb = v + slate * rs + (size_t)head * dk;
+  float qfrag[DKP / 2], dofrag[DKP / 2];
+  load_fixed<DKP>(qfrag, q + slate * rs + (size_t)head * dk, q0, L, dk, rs);
+  load_fixed<DKP>(dofrag, dout + slate * ors + (size_t)head * dk, q0, L, dk, ors);
+  const int qrow = q0 + (lane & 31);
+  const size_t stat = ((size_t)b * h + head) * L + qrow;
+  const float lse_q = (qrow < L) ? lse[stat] : 0.f;
+  const float del_q = (qrow < L) ? delta[stat] : 0.f;
+  f32x16 dqacc[DKP / 32];
+  zero_acc<DKP>(dqacc);
+  const int nkt = (L + 31) / 32;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    stage_tile<DKP>(ktile, kb, kt * 32, L, dk, rs);
+    stage_tile<DKP>(vtile, vb, kt * 32, L, dk, rs);
+    if (threadIdx.x < 32) {
+      const int key = kt * 32 + threadIdx.x;
+      kmask[threadIdx.x] = (key >= L || kpm[slate + key]) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    const f32x16 s = rows_x_fixed<DKP>(ktile, qfrag);
+    const f32x16 dp = rows_x_fixed<DKP>(vtile, dofrag);
+    f32x16 ds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = (kmask[rowmap(r, half)] != 0.f) ? 0.f : expf(s[r] * scale - lse_q);
+      ds[r] = p * (dp[r] - del_q) * scale;
+    }
+    cols_x_p<DKP>(ktile, ds, dqacc);
+  }
+  store_rows<DKP>(dq + slate * drs + (size_t)head * dk, q0, L, dk, drs, dqacc, 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward: dK, dV   (wave owns 32 keys, streams query tiles)
+// ------------------------------------------------------------------------------------------------------------------
+template <int DKP>
+__global__ void __launch_bounds__(256) ltrx_mha_bwd_dkdv_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const uint8_t* __restrict__ kpm, const float* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta, int L, int h, int dk, int rs, int ors, float* __restrict__ dkout,
+    float* __restrict__ dvout, int drs, float scale) {
+  __shared__ __attribute__((aligned(16))) float qtile[Tile<DKP>::FLOATS];
+  __shared__ __attribute__((aligned(16))) float dotile[Tile<DKP>::FLOATS];
+  __shared__ float lse_t[32];
+  __shared__ float del_t[32];
+  const int b = blockIdx.y / h, head = blockIdx.y % h;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const size_t slate = (size_t)b * L;
+  const float* qb = q + slate * rs + (size_t)head * dk;
+  const float* dob = dout + slate * ors + (size_t)head * dk;
+  float kfrag[DKP / 2], vfrag[DKP / 2];
+  load_fixed<DKP>(kfrag, k + slate * rs + (size_t)head * dk, k0, L, dk, rs);
+  load_fixed<DKP>(vfrag, v + slate * rs + (size_t)head * dk, k0, L, dk, rs);
+  const int key = k0 + (lane & 31);
+  const bool key_masked = (key >= L) || (kpm[slate + (key < L ? key : 0)] != 0);
+  f32x16 dkacc[DKP / 32], dvacc[DKP / 32];
+  zero_acc<DKP>(dkacc);
+  zero_acc<DKP>(dvacc);
+  const size_t statb = ((size_t)b * h + head) * L;
+  const int nqt = (L + 31) / 32;
+  for (int qt = 0; qt < nqt; ++qt) {
+    __syncthreads();
+    stage_tile<DKP>(qtile, qb, qt * 32, L, dk, rs);
+    stage_tile<DKP>(dotile, dob, qt * 32, L, dk, ors);
+    if (threadIdx.x < 32) {
+      const int qrow = qt * 32 + threadIdx.x;
+      lse_t[threadIdx.x] = (qrow < L) ? lse[statb + qrow] : INFINITY;   // +inf -> P = exp(-inf) = 0 for rows >= L
+      del_t[threadIdx.x] = (qrow < L) ? delta[statb + qrow] : 0.f;
+    }
+    __syncthreads();
+    const f32x16 s = rows_x_fixed<DKP>(qtile, kfrag);     // S[q = row(r,half)][key = l&31]
+    f32x16 p;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] = key_masked ? 0.f : expf(s[r] * scale - lse_t[rowmap(r, half)]);
+    cols_x_p<DKP>(dotile, p, dvacc);                       // dV^T[c][key] += sum_q dO[q][c] P[q][key]
+    const f32x16 dp = rows_x_fixed<DKP>(dotile, vfrag);    // dP[q][key]
+    f32x16 ds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ds[r] = p[r] * (dp[r] - del_t[rowmap(r, half)]) * scale;
+    cols_x_p<DKP>(qtile, ds, dkacc);                       // dK^T[c][key] += sum_q Q[q][c] dS[q][key]
+  }
+  store_rows<DKP>(dkout + slate * drs + (size_t)head * dk, k0, L, dk, drs, dkacc, 1.0f);
+  store_rows<DKP>(dvout + slate * drs + (size_t)head * dk, k0, L, dk, drs, dvacc, 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// MFMA layout self-test (one wave): D[32x32] = A[32x2] * B[2x32] through the layout assumptions used above.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void ltrx_selftest_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ D) {
+  const int lane = threadIdx.x & 63, half = lane >> 5;
+  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(lane & 31) * 2 + half], Bm[half * 32 + (lane & 31)], acc, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) D[rowmap(r, half) * 32 + (lane & 31)] = acc[r];
+}
+
+extern "C" int ltrx_selftest_mfma32x32x2(const float* A, const float* Bm, float* D, ltrx_stream_t stream) {
+  if (!A || !Bm || !D) return LTRX_EINVAL;
+  hipLaunchKernelGGL(ltrx_selftest_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, D);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host wrappers
+// ------------------------------------------------------------------------------------------------------------------
+static int mha_check(int B, int L, int h, int dk, int rs, int ors) {
+  if (B <= 0 || L <= 0 || h <= 0 || dk <= 0) return LTRX_EINVAL;
+  if (dk % 4 != 0 || dk > 128 || rs % 4 != 0 || ors % 4 != 0 || rs < h * dk || ors < h * dk) return LTRX_EUNSUPPORTED;
+  if ((long long)B * h > 65535) return LTRX_EUNSUPPORTED;
+  return LTRX_OK;
+}
+
+#define LTRX_DKP_DISPATCH(dk, CALL) \
+  do {                              \
+    if ((dk) <= 32) { CALL(32); }   \
+    else if ((dk) <= 64) { CALL(64); } \
+    else if ((dk) <= 96) { CALL(96); } \
+    else { CALL(128); }             \
+  } while (0)
+
+extern "C" int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L,
+                            int h, int d_k, int row_stride, float* o, int o_row_stride, float* lse_out,
+                            ltrx_stream_t stream) {
+  if (!q || !k || !v || !key_pad_mask || !o || !lse_out) return LTRX_EINVAL;
+  int rc = mha_check(B, L, h, d_k, row_stride, o_row_stride);
+  if (rc != LTRX_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((L + 127) / 128, B * h);
+  const float scale = 1.0f / sqrtf((float)d_k);
+#define CALL(DKP)                                                                                                 \
+  hipLaunchKernelGGL(ltrx_mha_fwd_kernel<DKP>, grid, dim3(256), 0, s, q, k, v, key_pad_mask, L, h, d_k, row_stride, o, \
+                     o_row_stride, lse_out, scale)
+  LTRX_DKP_DISPATCH(d_k, CALL);
+#undef CALL
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+extern "C" size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h) {
+  if (B <= 0 || L <= 0 || h <= 0) return 0;
+  return (size_t)B * L * h * sizeof(float);
+}
+
+extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, const float* o,
+                            const float* dout, const float* lse, int B, int L, int h, int d_k, int row_stride,
+                            int o_row_stride, float* dq, float* dk, float* dv, int d_row_stride, void* ws,
+                            ltrx_stream_t stream) {
+  if (!q || !k || !v || !key_pad_mask || !o || !dout || !lse || !dq || !dk || !dv || !ws) return LTRX_EINVAL;
+  int rc = mha_check(B, L, h, d_k, row_stride, o_row_stride);
+  if (rc != LTRX_OK) return rc;
+  if (d_row_stride % 4 != 0 || d_row_stride < h * d_k) return LTRX_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  float* delta = (float*)ws;
+  const size_t n = (size_t)B * L * h;
+  int dblocks = (int)((n + 255) / 256);
+  if (dblocks > 4096) dblocks = 4096;
+  hipLaunchKernelGGL(ltrx_mha_delta_kernel, dim3(dblocks), dim3(256), 0, s, o, dout, B, L, h, d_k, o_row_stride, delta);
+  LTRX_LAUNCH_CHECK();
+  const dim3 grid((L + 127) / 128, B * h);
+  const float scale = 1.0f / sqrtf((float)d_k);
+#define CALLQ(DKP)                                                                                                   \
+  hipLaunchKernelGGL(ltrx_mha_bwd_dq_kernel<DKP>, grid, dim3(256), 0, s, q, k, v, key_pad_mask, dout, lse, delta, L, h, \
+                     d_k, row_stride, o_row_stride, dq, d_row_stride, scale)
+  LTRX_DKP_DISPATCH(d_k, CALLQ);
+#undef CALLQ
+  LTRX_LAUNCH_CHECK();
+#define CALLK(DKP)                                                                                                     \
+  hipLaunchKernelGGL(ltrx_mha_bwd_dkdv_kernel<DKP>, grid, dim3(256), 0, s, q, k, v, key_pad_mask, dout, lse, delta, L, h, \
+                     d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale)
+  LTRX_DKP_DISPATCH(d_k, CALLK);
+#undef CALLK
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}

@@ -1,0 +1,46 @@
+"""MI355X-native ranking metrics with the signatures of ``allrank.models.metrics`` (metrics.py:7-77; looked up by
+name at allrank/training/train_utils.py:50).  ``ndcg``/``dcg`` run as one HIP kernel per call (libltrx.so)."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+PADDED_Y_VALUE = -1
+
+
+def _run(y_pred, y_true, ats, padding_indicator, filler_value, want_order):
+    if y_pred.dim() != 2 or y_pred.shape != y_true.shape:
+        raise ValueError("y_pred and y_true must both be [batch_size, slate_length]")
+    L.require_device(y_pred, y_true)
+    yp = L.f32c(y_pred.detach())
+    yt = L.f32c(y_true.detach())
+    B, SL = yp.shape
+    if ats is None:
+        ats = [SL]                                    # metrics.py:58-59
+    ats = [min(int(a), SL) for a in ats]              # metrics.py:60
+    n = len(ats)
+    nd = torch.empty((B, n), dtype=torch.float32, device=yp.device)
+    dc = torch.empty((B, n), dtype=torch.float32, device=yp.device)
+    order = torch.empty((B, SL), dtype=torch.int64, device=yp.device) if want_order else None
+    arr = (ctypes.c_int * n)(*ats)
+    L.check(L.lib().ltrx_ndcg_at(L.ptr(yp), L.ptr(yt), B, SL, arr, n, float(padding_indicator), float(filler_value),
+                                 L.ptr(nd), L.ptr(dc), L.ptr(order), None, L.stream_of(yp)), "ndcg_at")
+    return nd, dc, order
+
+
+def ndcg(y_pred, y_true, ats=None, gain_function=None, padding_indicator=PADDED_Y_VALUE, filler_value=1.0,
+         return_order=False):
+    """NDCG@ats (metrics.py:7-28): [batch, len(ats)]; slates without a relevant item get ``filler_value`` (1.0).
+    Only the default gain 2^x - 1 is implemented in the kernel."""
+    if gain_function is not None:
+        raise NotImplementedError("custom gain_function: only the default 2**x - 1 is implemented on the device")
+    nd, _, order = _run(y_pred, y_true, ats, padding_indicator, filler_value, return_order)
+    return (nd, order) if return_order else nd
+
+
+def dcg(y_pred, y_true, ats=None, gain_function=None, padding_indicator=PADDED_Y_VALUE):
+    """DCG@ats (metrics.py:41-77)."""
+    if gain_function is not None:
+        raise NotImplementedError("custom gain_function: only the default 2**x - 1 is implemented on the device")
+    return _run(y_pred, y_true, ats, padding_indicator, 1.0, False)[1]

@@ -1,0 +1,158 @@
+/*
+ * ltrx.h -- C ABI of libltrx.so: MI355X (gfx950) kernels for the listwise-LTR training hot path.
+ *
+ * This is the drop-in boundary of the engine.  allegro/allRank has no
+ * FFI of its own: its plugin surface is Python name lookup (allrank/main.py:75,82-83).  Each entry
+ * point below therefore cites the reference *Python* function it replaces; the Python side
+ * (allrank_amd/) binds them with ctypes and mirrors the reference signatures one-to-one.
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, scalars; no torch / HIP types in the signatures.
+ *     `ltrx_stream_t` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - every tensor is caller-owned, dense row-major fp32 unless stated; kernels never allocate, never
+ *     retain pointers, never synchronise the device, and enqueue on the given stream only.
+ *   - y_true uses `pad_value` (-1 in allRank, allrank/data/dataset_loading.py:15) to mark padded slots.
+ *   - return value: 0 = ok; LTRX_EINVAL bad argument; LTRX_EUNSUPPORTED shape outside the supported
+ *     range; LTRX_EHIP a HIP launch error (hipGetLastError code is returned as -(1000+code)).
+ *   - `batch_divisor`: the number of slates the reference would have averaged over.  On one GPU it is B;
+ *     under slate sharding it is the GLOBAL batch so that summing per-rank results reproduces the
+ *     reference's loss on the gathered batch.
+ *   - sort tie policy: stable descending (lower original index first), SURVEY.md §9.2.
+ */
+#ifndef LTRX_H
+#define LTRX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LTRX_VERSION 100 /* 0.1.0 */
+
+#define LTRX_OK 0
+#define LTRX_EINVAL (-1)
+#define LTRX_EUNSUPPORTED (-2)
+#define LTRX_EHIP (-1000)
+
+#define LTRX_MAX_SLATE_LEN 2048 /* loss / metric kernels stage a slate in LDS */
+
+typedef void* ltrx_stream_t;
+
+int ltrx_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Listwise losses.  All of them: inputs y_pred[B,L], y_true[B,L]; outputs loss_out[1] (scalar, as the
+ * reference returns), optional per_slate_out[B] (the per-slate term before the batch reduction),
+ * optional grad_out[B,L] = d loss / d y_pred (exactly 0 at padded slots).  `ws` is a scratch buffer
+ * of at least the matching *_workspace_bytes(); it is write-only scratch, contents undefined after.
+ * ------------------------------------------------------------------------------------------- */
+
+/* allrank/models/losses/listNet.py:8-30   listNet(y_pred, y_true, eps, padded_value_indicator) */
+size_t ltrx_listnet_workspace_bytes(int B, int L);
+int ltrx_listnet_fwd_bwd(const float* y_pred, const float* y_true, int B, int L, float eps, float pad_value,
+                         float batch_divisor, float* loss_out, float* per_slate_out, float* grad_out, void* ws,
+                         ltrx_stream_t stream);
+
+/* allrank/models/losses/listMLE.py:7-38   listMLE(y_pred, y_true, eps, padded_value_indicator)
+ * `perm[L]` (int64, device) is the column shuffle the reference draws with torch.randperm (listMLE.py:17);
+ * order_out[B,L] (int64, optional) receives the original item index at each sorted position. */
+size_t ltrx_listmle_workspace_bytes(int B, int L);
+int ltrx_listmle_fwd_bwd(const float* y_pred, const float* y_true, const int64_t* perm, int B, int L, float eps,
+                         float pad_value, float batch_divisor, float* loss_out, float* per_slate_out,
+                         float* grad_out, int64_t* order_out, void* ws, ltrx_stream_t stream);
+
+/* allrank/models/losses/approxNDCG.py:7-53   approxNDCGLoss(y_pred, y_true, eps, padded_value_indicator, alpha) */
+size_t ltrx_approxndcg_workspace_bytes(int B, int L);
+int ltrx_approxndcg_fwd_bwd(const float* y_pred, const float* y_true, int B, int L, float eps, float pad_value,
+                            float alpha, float batch_divisor, float* loss_out, float* per_slate_out,
+                            float* grad_out, void* ws, ltrx_stream_t stream);
+
+/* allrank/models/losses/lambdaLoss.py:7-114   lambdaLoss(y_pred, y_true, eps, padded_value_indicator,
+ *                                              weighing_scheme, k, sigma, mu, reduction, reduction_log) */
+enum ltrx_lambda_scheme {
+  LTRX_SCHEME_NONE = 0,                 /* weighing_scheme=None            (lambdaLoss.py:58-59)  */
+  LTRX_SCHEME_NDCGLOSS1 = 1,            /* ndcgLoss1_scheme                (:84-85)               */
+  LTRX_SCHEME_NDCGLOSS2 = 2,            /* ndcgLoss2_scheme                (:88-94)               */
+  LTRX_SCHEME_LAMBDARANK = 3,           /* lambdaRank_scheme               (:97-98)               */
+  LTRX_SCHEME_NDCGLOSS2PP = 4,          /* ndcgLoss2PP_scheme              (:101-102)             */
+  LTRX_SCHEME_RANKNET = 5,              /* rankNet_scheme                  (:105-106)             */
+  LTRX_SCHEME_RANKNET_GTDIFF = 6,       /* rankNetWeightedByGTDiff_scheme  (:109-110)             */
+  LTRX_SCHEME_RANKNET_GTDIFF_POWED = 7  /* rankNetWeightedByGTDiffPowed_scheme (:113-114)         */
+};
+enum ltrx_reduction { LTRX_REDUCE_SUM = 0, LTRX_REDUCE_MEAN = 1 };
+enum ltrx_logbase { LTRX_LOG_BINARY = 0, LTRX_LOG_NATURAL = 1 };
+/* k <= 0 means k=None (no truncation).  For LTRX_REDUCE_MEAN the divisor is the number of selected pairs
+ * in THIS call's batch; pair_count_out[1] (optional) receives it.  When `ext_pair_count` (device, optional)
+ * is given it is used as the divisor instead (global count under slate sharding). */
+size_t ltrx_lambdaloss_workspace_bytes(int B, int L);
+int ltrx_lambdaloss_fwd_bwd(const float* y_pred, const float* y_true, int B, int L, float eps, float pad_value,
+                            int scheme, int k, float sigma, float mu, int reduction, int logbase,
+                            const float* ext_pair_count, float* loss_out, float* pair_count_out, float* grad_out,
+                            int64_t* order_out, void* ws, ltrx_stream_t stream);
+
+/* allrank/models/losses/neuralNDCG.py:10-70 (neuralNDCG) and :73-136 (neuralNDCG_transposed), deterministic
+ * NeuralSort (loss_utils.py:34-67) + Sinkhorn scaling (loss_utils.py:8-31).
+ *   step 1  ltrx_neuralndcg_prepare: per-slate ideal DCG@k (metrics.py:41-77 on (y_true,y_true)) and
+ *           nonzero_count_out[1] = number of slates with idcg != 0 (the loss normaliser, neuralNDCG.py:69).
+ *           Under slate sharding the caller all-reduces nonzero_count between the two steps.
+ *   step 2  ltrx_neuralndcg_fwd_bwd: loss and gradient; `nonzero_count` is read from DEVICE memory.
+ * transposed != 0 selects the neuralNDCG_transposed conventions (same value; idcg stays "powered" when
+ * powered_relevancies == 0, neuralNDCG.py:126).  k <= 0 means k=None.  The Sinkhorn early exit
+ * (loss_utils.py:25) is batch-global as in the reference; iters_out[1] (int32, optional) = iterations used. */
+size_t ltrx_neuralndcg_workspace_bytes(int B, int L, int max_iter);
+int ltrx_neuralndcg_prepare(const float* y_true, int B, int L, float pad_value, int k, int idcg_powered,
+                            float* idcg_out, float* nonzero_count_out, void* ws, ltrx_stream_t stream);
+int ltrx_neuralndcg_fwd_bwd(const float* y_pred, const float* y_true, const float* idcg, const float* nonzero_count,
+                            int B, int L, float pad_value, float temperature, int powered_relevancies, int k,
+                            int transposed, int max_iter, float tol, float* loss_out, float* per_slate_out,
+                            float* grad_out, int32_t* iters_out, void* ws, ltrx_stream_t stream);
+
+/* allrank/models/metrics.py:7-77   ndcg(y_pred, y_true, ats, gain=2^x-1, padding_indicator, filler_value)
+ * ats[n_ats] is a HOST array.  ndcg_out[B,n_ats]; dcg_out[B,n_ats] optional; order_out[B,L] (int64, optional)
+ * = stable descending argsort of the masked predictions (padded slots last, in original order). */
+size_t ltrx_ndcg_workspace_bytes(int B, int L);
+int ltrx_ndcg_at(const float* y_pred, const float* y_true, int B, int L, const int* ats, int n_ats,
+                 float pad_value, float filler_value, float* ndcg_out, float* dcg_out, int64_t* order_out,
+                 void* ws, ltrx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scoring model kernels (allrank/models/transformer.py).
+ * ------------------------------------------------------------------------------------------- */
+
+/* transformer.py:59-81  custom LayerNorm: y = a*(x-mean)/(std_unbiased+eps)+b over the last dim D, with an
+ * optional fused residual input (transformer.py:105: the sum x + sublayer(...) that feeds the next norm):
+ *   xsum = x (+ res);  y = LN(xsum).   xsum_out may be NULL when res is NULL.
+ * Saves mean[rows], rstd[rows] (= 1/(std+eps)) for the backward. */
+int ltrx_layernorm_fwd(const float* x, const float* res, const float* a, const float* b, int rows, int D, float eps,
+                       float* xsum_out, float* y_out, float* mean_out, float* rstd_out, ltrx_stream_t stream);
+/* dx = LN backward of dy (+ dres_in if given: the gradient arriving through the residual branch);
+ * da_out/db_out (fp32, length D) are written via a deterministic two-stage reduction through ws. */
+size_t ltrx_layernorm_bwd_workspace_bytes(int rows, int D);
+int ltrx_layernorm_bwd(const float* dy, const float* xsum, const float* a, const float* mean, const float* rstd,
+                       const float* dres_in, int rows, int D, float eps, float* dx_out, float* da_out, float* db_out,
+                       void* ws, ltrx_stream_t stream);
+
+/* transformer.py:137-156 attention() as used by MultiHeadedAttention.forward (:178-203), fused flash-style:
+ * q,k,v,o are [B, L, h, d_k] views of the projection outputs (element (b,l,head,c) at ((b*L+l)*h+head)*d_k + c
+ * scaled by the given row stride), key_pad_mask u8[B,L] (1 = padded key, filled with -inf, transformer.py:150-151);
+ * softmax over keys; dropout is not applied (p=0 / eval).  lse_out[B,h,L] = log-sum-exp of the
+ * scaled, masked scores (the only tensor saved for backward).  fp32 in/out; contractions on the fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32), exact fp32 products.  d_k % 4 == 0, d_k <= 128 (zero-padded to a multiple of 32). */
+int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L, int h,
+                 int d_k, int row_stride, float* o, int o_row_stride, float* lse_out, ltrx_stream_t stream);
+/* backward: dq,dk,dv from do; delta_ws[B,h,L] scratch (rowsum(do*o)). */
+size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h);
+int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, const float* o,
+                 const float* dout, const float* lse, int B, int L, int h, int d_k, int row_stride, int o_row_stride,
+                 float* dq, float* dk, float* dv, int d_row_stride, void* ws, ltrx_stream_t stream);
+
+/* Test hook: D[32x32] = A[32x2] * B[2x32] with ONE v_mfma_f32_32x32x2_f32, written through the operand / result
+ * lane layout the attention kernels assume.  Lets the parity suite tell a layout bug from a logic bug. */
+int ltrx_selftest_mfma32x32x2(const float* A, const float* B, float* D, ltrx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTRX_H */

@@ -17,25 +17,10 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle.ref_loader import load_reference  # noqa: E402
+from tests.golden.make_inputs import make_inputs  # noqa: E402
 
 LAMBDA_SCHEMES = [None, "ndcgLoss1_scheme", "ndcgLoss2_scheme", "lambdaRank_scheme", "ndcgLoss2PP_scheme",
                   "rankNet_scheme", "rankNetWeightedByGTDiff_scheme", "rankNetWeightedByGTDiffPowed_scheme"]
-
-
-def make_inputs(B, L, seed, tie_scores=False):
-    """SURVEY.md §8(d) recipe: N(0,1) scores, WEB30K-like label skew, ragged lengths, one all-zero slate."""
-    rng = np.random.default_rng(seed)
-    s = rng.standard_normal((B, L)).astype(np.float32)
-    if tie_scores:
-        s = (np.round(s * 2) / 2).astype(np.float32)
-    y = rng.choice(5, size=(B, L), p=[0.52, 0.32, 0.13, 0.02, 0.01]).astype(np.float32)
-    nv = np.clip(np.round(rng.lognormal(np.log(max(L * 0.45, 1.0)), 0.6, B)), 1, L).astype(int)
-    nv[0] = L
-    for b in range(B):
-        y[b, nv[b]:] = -1
-    if B > 2:
-        y[1][y[1] >= 0] = 0
-    return s, y
 
 
 def ref_loss(fn, s, y, **kw):

@@ -1,0 +1,92 @@
+"""CPU-side checks of the drop-in boundary: libltrx.so builds for gfx950, loads, and exports every symbol that
+include/ltrx.h declares; the Python surface mirrors the reference plugin signatures.  No kernel is launched."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from allrank_amd import build
+    return build.build(verbose=False)
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "ltrx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ltrx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported(libpath):
+    names = _declared_symbols()
+    assert len(names) >= 20
+    h = ctypes.CDLL(libpath)
+    for n in names:
+        assert hasattr(h, n), "libltrx.so does not export %s declared in include/ltrx.h" % n
+    h.ltrx_version.restype = ctypes.c_int
+    assert h.ltrx_version() == 100
+
+
+def test_binding_table_matches_header(libpath):
+    from allrank_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared_symbols()
+    assert _lib.lib().ltrx_version() == 100
+
+
+def test_workspace_queries_and_argument_validation_run_without_a_gpu(libpath):
+    from allrank_amd import _lib
+    lib = _lib.lib()
+    assert lib.ltrx_listnet_workspace_bytes(64, 240) >= 64 * 4
+    assert lib.ltrx_neuralndcg_workspace_bytes(64, 240, 50) >= 2 * 64 * 240 * 240 * 4
+    assert lib.ltrx_mha_bwd_workspace_bytes(64, 240, 8) == 64 * 240 * 8 * 4
+    # NULL pointers / bad shapes are rejected before any HIP call
+    assert lib.ltrx_listnet_fwd_bwd(None, None, 1, 1, 1e-10, -1.0, 1.0, None, None, None, None, None) == -1
+    assert lib.ltrx_mha_fwd(None, None, None, None, 1, 1, 1, 64, 64, None, 64, None, None) == -1
+
+
+def test_loss_signatures_mirror_reference():
+    """same parameter names and defaults as allrank/models/losses/*.py"""
+    from allrank_amd import losses, metrics
+    exp = {
+        "listNet": ["y_pred", "y_true", "eps", "padded_value_indicator"],
+        "listMLE": ["y_pred", "y_true", "eps", "padded_value_indicator"],
+        "approxNDCGLoss": ["y_pred", "y_true", "eps", "padded_value_indicator", "alpha"],
+        "lambdaLoss": ["y_pred", "y_true", "eps", "padded_value_indicator", "weighing_scheme", "k", "sigma", "mu",
+                       "reduction", "reduction_log"],
+        "neuralNDCG": ["y_pred", "y_true", "padded_value_indicator", "temperature", "powered_relevancies", "k",
+                       "stochastic", "n_samples", "beta", "log_scores"],
+        "neuralNDCG_transposed": ["y_pred", "y_true", "padded_value_indicator", "temperature", "powered_relevancies", "k",
+                                  "stochastic", "n_samples", "beta", "log_scores", "max_iter", "tol"],
+    }
+    for name, params in exp.items():
+        got = list(inspect.signature(getattr(losses, name)).parameters)
+        assert got[:len(params)] == params, (name, got)
+    assert list(inspect.signature(metrics.ndcg).parameters)[:6] == ["y_pred", "y_true", "ats", "gain_function",
+                                                                    "padding_indicator", "filler_value"]
+    d = inspect.signature(losses.lambdaLoss).parameters
+    assert d["sigma"].default == 1. and d["mu"].default == 10. and d["reduction"].default == "sum" \
+        and d["reduction_log"].default == "binary" and d["eps"].default == 1e-10 and d["padded_value_indicator"].default == -1
+
+
+def test_product_path_refuses_cpu_tensors(libpath):
+    import torch
+    from allrank_amd import losses
+    with pytest.raises(RuntimeError):
+        losses.listNet(torch.zeros(2, 3), torch.zeros(2, 3))
+
+
+def test_reference_error_behaviour():
+    import torch
+    from allrank_amd import losses
+    x = torch.zeros(2, 3)
+    with pytest.raises(ValueError):
+        losses.lambdaLoss(x, x, reduction="median")             # lambdaLoss.py:79
+    with pytest.raises(ValueError):
+        losses.lambdaLoss(x, x, reduction_log="decimal")        # lambdaLoss.py:72
+    with pytest.raises(KeyError):
+        losses.lambdaLoss(x, x, weighing_scheme="nope")         # globals()[...] at lambdaLoss.py:61

@@ -1,0 +1,260 @@
+"""GPU parity tests proper (-m gpu): the HIP kernels, called through the C ABI / Python boundary, against
+(1) the golden vectors generated from the reference itself and (2) the numpy oracle on seeded random inputs, plus
+size-independent properties at full size.  Tolerance: |a-b| <= 1e-5 (1 + |b|) for loss / NDCG values (BASELINE.json
+north_star: fp32 within 1e-5), bit-exact sort indices on the valid prefix, gradients within 2e-4 of the largest
+reference gradient entry.  /root/reference is NOT needed here."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ltr_oracle as O
+from oracle import model_oracle as M
+from tests.cases import close, grad_close, iter_loss_cases
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+
+
+def _log(name, obj):
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "parity_%s.json" % name), "w") as fh:
+        json.dump(obj, fh, indent=1, default=float)
+
+
+def _t(a, rg=False):
+    return torch.tensor(np.asarray(a), device=DEV, requires_grad=rg)
+
+
+def _engine_loss(kind, kw, s, y):
+    from allrank_amd import losses as E
+    sp = _t(s, True)
+    yt = _t(y)
+    if kind == "listnet":
+        l = E.listNet(sp, yt)
+    elif kind == "approxndcg":
+        l = E.approxNDCGLoss(sp, yt, **kw)
+    elif kind == "listmle":
+        l = E.listMLE(sp, yt, perm=torch.tensor(kw["perm"]))
+    elif kind == "lambdaloss":
+        l = E.lambdaLoss(sp, yt, **kw)
+    elif kind == "neuralndcg":
+        kw = dict(kw)
+        tr = kw.pop("transposed")
+        l = (E.neuralNDCG_transposed if tr else E.neuralNDCG)(sp, yt, **kw)
+    else:
+        raise KeyError(kind)
+    l.backward()
+    return float(l.item()), sp.grad.cpu().numpy()
+
+
+def _oracle_loss(kind, kw, s, y):
+    if kind == "listnet":
+        return O.listnet(s, y)[:2]
+    if kind == "approxndcg":
+        return O.approxndcg(s, y, **kw)[:2]
+    if kind == "listmle":
+        return O.listmle(s, y, kw["perm"])[:2]
+    if kind == "lambdaloss":
+        return O.lambdaloss(s, y, **kw)[:2]
+    if kind == "neuralndcg":
+        return O.neuralndcg(s, y, **kw)[:2]
+    raise KeyError(kind)
+
+
+def test_mfma_layout_selftest():
+    from allrank_amd import ops
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((32, 2)).astype(np.float32)          # asymmetric operands: catches row/col swaps
+    Bm = rng.standard_normal((2, 32)).astype(np.float32)
+    D = ops.mfma_selftest(_t(A), _t(Bm)).cpu().numpy()
+    ref = (A.astype(np.float64) @ Bm.astype(np.float64))
+    assert np.abs(D - ref).max() < 1e-5, np.abs(D - ref).max()
+
+
+def test_losses_match_reference_golden(losses_golden):
+    bad, rows = [], []
+    n = 0
+    for name, kind, kw, s, y, rl, rg in iter_loss_cases(losses_golden):
+        lo, go = _engine_loss(kind, kw, s, y)
+        n += 1
+        ok = close(lo, rl) and grad_close(go, rg) and np.all(go[y == -1] == 0)
+        rows.append(dict(name=name, loss=lo, ref=float(rl), gerr=float(np.abs(go - rg).max()), gmax=float(np.abs(rg).max()), ok=bool(ok)))
+        if not ok:
+            bad.append(rows[-1])
+    _log("golden_losses", rows)
+    assert n == 208 and not bad, bad[:8]
+
+
+@pytest.mark.parametrize("B,L,seed", [(64, 240, 1), (7, 33, 2), (3, 1, 3), (5, 257, 4), (2, 1024, 5)])
+def test_losses_match_oracle_random(B, L, seed):
+    from tests.golden.make_inputs import make_inputs
+    s, y = make_inputs(B, L, seed)
+    perm = np.random.default_rng(seed).permutation(L).astype(np.int64)
+    cases = [("listnet", {}), ("approxndcg", dict(alpha=1.0)), ("listmle", dict(perm=perm)),
+             ("lambdaloss", dict(weighing_scheme="lambdaRank_scheme")),
+             ("lambdaloss", dict(weighing_scheme="ndcgLoss2PP_scheme", k=10, reduction="mean", reduction_log="natural")),
+             ("lambdaloss", dict(weighing_scheme="ndcgLoss1_scheme", k=5))]
+    if L <= 257:
+        cases += [("neuralndcg", dict(transposed=False, temperature=1.0)),
+                  ("neuralndcg", dict(transposed=True, temperature=0.5, k=5, powered_relevancies=False))]
+    bad, rows = [], []
+    for kind, kw in cases:
+        lo, go = _engine_loss(kind, kw, s, y)
+        ro, rg = _oracle_loss(kind, kw, s, y)
+        ok = close(lo, ro, rtol=2e-5) and grad_close(go, rg, rtol=5e-4) and np.all(go[y == -1] == 0)
+        rows.append(dict(kind=kind, kw={k: (v if not isinstance(v, np.ndarray) else "perm") for k, v in kw.items()},
+                         loss=lo, ref=float(ro), gerr=float(np.abs(go - rg).max()), gmax=float(np.abs(rg).max()), ok=bool(ok)))
+        if not ok:
+            bad.append(rows[-1])
+    _log("random_losses_%dx%d" % (B, L), rows)
+    assert not bad, bad
+
+
+def test_padding_invariance_and_no_input_mutation():
+    """the reference's own test idiom (tests/losses/*: *_ignores_padded): an extra padded slot changes nothing."""
+    from allrank_amd import losses as E
+    yp = torch.tensor([[0.5, 0.3, 0.5]], device=DEV)
+    yt = torch.tensor([[0.5, 0.3, 0.5]], device=DEV)
+    ypp = torch.tensor([[0.5, 0.3, 0.5, 1.0]], device=DEV)
+    ytp = torch.tensor([[0.5, 0.3, 0.5, -1.0]], device=DEV)
+    kat = [(lambda a, b: E.approxNDCGLoss(a, b, alpha=1.), -0.8499219417),
+           (lambda a, b: E.lambdaLoss(a, b, weighing_scheme="ndcgLoss1_scheme", reduction_log="binary"), 2.9272110462),
+           (lambda a, b: E.lambdaLoss(a, b, weighing_scheme="ndcgLoss2PP_scheme", reduction_log="binary"), 1.1244146823),
+           (lambda a, b: E.lambdaLoss(a, b, weighing_scheme="rankNet_scheme", reduction_log="natural"), 1.1962778568)]
+    for fn, expected in kat:
+        c0, c1 = ypp.clone(), ytp.clone()
+        r, rp = fn(yp, yt).item(), fn(ypp, ytp).item()
+        assert r == pytest.approx(expected, abs=1e-5) and rp == pytest.approx(r, abs=1e-6)
+        assert torch.equal(ypp, c0) and torch.equal(ytp, c1)
+    r = E.listMLE(torch.tensor([[0.5, 0.3, 0.5]], device=DEV), torch.tensor([[1.0, 0.0, -1.0]], device=DEV)).item()
+    assert r == pytest.approx(0.5981389284133911, abs=1e-6)            # tests/losses/test_listmle.py:14-22
+    r = E.listNet(torch.tensor([[0.5, -1e30]], device=DEV), torch.tensor([[1.0, 0.0]], device=DEV)).item()
+    assert np.isfinite(r)                                              # tests/losses/test_listnet.py:29-35
+
+
+def test_neuralndcg_equals_ndcg_at_low_temperature():
+    """tests/losses/test_neuralndcg.py:16-94 (deterministic variants)."""
+    from allrank_amd import losses as E, metrics as EM
+    PAD = -1.0
+    cases = [([0.5, 0.2], [1.0, 0.0], 1e-4, None),
+             ([0.5, 0.2, 0.1, 0.4, 1.0, -1.0, 0.63], [1.0, 2.0, 2.0, 4.0, 1.0, 4.0, 3.0], 1e-4, None),
+             ([0.5, -1e30], [1.0, 0.0], 1e-4, None),
+             ([0.5, 0.2, 0.1, 0.4, 1.0, -1.0, 0.63, 1., 0.5, 0.3], [1.0, 2.0, 2.0, 4.0, 1.0, 4.0, 3.0, PAD, PAD, PAD], 1e-3, None),
+             ([0.5, 0.2, 0.1, 0.4, 1.0, -1.0, 0.63], [1.0, 2.0, 2.0, 4.0, 1.0, 4.0, 3.0], 1e-4, 3)]
+    for yp, yt, tau, k in cases:
+        a, b = torch.tensor([yp], device=DEV), torch.tensor([yt], device=DEV)
+        e = EM.ndcg(a, b, ats=None if k is None else [k]).mean().item()
+        for fn in (E.neuralNDCG, E.neuralNDCG_transposed):
+            r = fn(a, b, temperature=tau, k=k).item()
+            assert np.isfinite(r) and -r == pytest.approx(e, abs=1e-5), (yp, tau, k, r, e)
+
+
+def test_ndcg_and_sort_indices(losses_golden):
+    from allrank_amd import metrics as EM
+    g = losses_golden
+    for ci in range(int(g["n_cases"])):
+        pre = "c%d." % ci
+        s, y = g[pre + "s"], g[pre + "y"]
+        ats = [int(a) for a in g[pre + "ndcg.ats"]]
+        nd, order = EM.ndcg(_t(s), _t(y), ats=ats, return_order=True)
+        dc = EM.dcg(_t(s), _t(y), ats=ats)
+        assert close(nd.cpu().numpy(), g[pre + "ndcg.val"]) and close(dc.cpu().numpy(), g[pre + "dcg.val"])
+        order = order.cpu().numpy()
+        nv = (y != -1).sum(1)
+        for b in range(s.shape[0]):
+            assert np.array_equal(order[b, :nv[b]], g[pre + "order"][b, :nv[b]])      # bit-exact (tie policy)
+            assert sorted(order[b].tolist()) == list(range(s.shape[1]))              # a permutation
+
+
+def test_ndcg_full_size_properties():
+    """size-independent properties at the bench size: indices are a permutation that sorts the scores (stable), the
+    oracle agrees, NDCG of the ideal ranking is 1, all-zero-label slates give the filler."""
+    from allrank_amd import metrics as EM
+    from tests.golden.make_inputs import make_inputs
+    s, y = make_inputs(512, 240, 77, tie_scores=True)
+    st, yt = _t(s), _t(y)
+    nd, order = EM.ndcg(st, yt, ats=[5, 10, 240], return_order=True)
+    ndo, oo = O.ndcg(s, y, ats=[5, 10, 240])
+    assert close(nd.cpu().numpy(), ndo)
+    order = order.cpu().numpy()
+    nv = (y != -1).sum(1)
+    for b in range(0, 512, 17):
+        assert np.array_equal(order[b, :nv[b]], oo[b, :nv[b]])
+        v = s[b, order[b, :nv[b]]]
+        assert np.all(v[:-1] >= v[1:])
+    ideal = EM.ndcg(yt.clone(), yt, ats=[5, 240]).cpu().numpy()
+    assert np.allclose(ideal, 1.0, atol=1e-6)
+    assert np.all(nd.cpu().numpy()[1] == 1.0)        # slate 1 of make_inputs has no relevant item -> filler 1.0
+
+
+def test_layernorm_forward_backward():
+    from allrank_amd import ops
+    rng = np.random.default_rng(3)
+    for rows, D, with_res in [(37, 512, True), (64 * 240, 512, True), (9, 96, False), (5, 20, True)]:
+        x = rng.standard_normal((rows, D)).astype(np.float32) * 2 + 0.3
+        r = rng.standard_normal((rows, D)).astype(np.float32) if with_res else None
+        a = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+        b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+        gy = rng.standard_normal((rows, D)).astype(np.float32)
+        gx2 = rng.standard_normal((rows, D)).astype(np.float32)
+        xt, at, bt = _t(x, True), _t(a, True), _t(b, True)
+        rt = _t(r, True) if with_res else None
+        y, xs = ops.layer_norm_residual(xt, rt, at, bt, 1e-6)
+        xsum = x + r if with_res else x
+        yo, cache = M.custom_ln_fwd(xsum.astype(np.float64), a.astype(np.float64), b.astype(np.float64))
+        assert np.abs(y.detach().cpu().numpy() - yo).max() < 2e-5
+        if with_res:
+            (y * _t(gy)).sum().add((xs * _t(gx2)).sum()).backward()
+        else:
+            (y * _t(gy)).sum().backward()
+        grads = {}
+        gxo = M.custom_ln_bwd(cache, a.astype(np.float64), gy.astype(np.float64), grads, "n") + (gx2 if with_res else 0)
+        sc = np.abs(gxo).max()
+        assert np.abs(xt.grad.cpu().numpy() - gxo).max() < 1e-4 * sc
+        if with_res:
+            assert np.abs(rt.grad.cpu().numpy() - gxo).max() < 1e-4 * sc
+        assert np.abs(at.grad.cpu().numpy() - grads["n.a_2"]).max() < 1e-4 * max(1.0, np.abs(grads["n.a_2"]).max())
+        assert np.abs(bt.grad.cpu().numpy() - grads["n.b_2"]).max() < 1e-4 * max(1.0, np.abs(grads["n.b_2"]).max())
+
+
+@pytest.mark.parametrize("B,L,h,dk", [(2, 240, 8, 64), (3, 70, 4, 8), (2, 33, 1, 96), (1, 300, 2, 32), (2, 129, 1, 128),
+                                      (2, 64, 2, 72)])
+def test_attention_forward_backward(B, L, h, dk):
+    from allrank_amd import ops
+    rng = np.random.default_rng(L * 7 + dk)
+    d = h * dk
+    qkv = rng.standard_normal((B, L, 3 * d)).astype(np.float32)
+    mask = np.zeros((B, L), dtype=bool)
+    for b in range(B):
+        mask[b, L - 1 - 5 * b:] = b > 0
+    if B > 1:
+        mask[1, 3] = True                      # a padded key in the middle (the reference allows arbitrary masks)
+    go = rng.standard_normal((B, L, d)).astype(np.float32)
+    t = _t(qkv, True)
+    q, k, v = t[:, :, :d], t[:, :, d:2 * d], t[:, :, 2 * d:]
+    o = ops.attention(q, k, v, _t(mask), h)
+    (o * _t(go)).sum().backward()
+
+    def heads(x):
+        return x.reshape(B, L, h, dk).transpose(0, 2, 1, 3).astype(np.float64)
+
+    qo, ko, vo = heads(qkv[:, :, :d]), heads(qkv[:, :, d:2 * d]), heads(qkv[:, :, 2 * d:])
+    oo, p = M.attention_fwd(qo, ko, vo, mask)
+    gq, gk, gv = M.attention_bwd(qo, ko, vo, p, heads(go))
+
+    def unheads(x):
+        return x.transpose(0, 2, 1, 3).reshape(B, L, d)
+
+    err = dict(o=float(np.abs(o.detach().cpu().numpy() - unheads(oo)).max()))
+    g = t.grad.cpu().numpy()
+    for name, ref, sl in (("dq", gq, slice(0, d)), ("dk", gk, slice(d, 2 * d)), ("dv", gv, slice(2 * d, 3 * d))):
+        err[name] = float(np.abs(g[:, :, sl] - unheads(ref)).max() / max(np.abs(ref).max(), 1e-6))
+    _log("attention_%d_%d_%d_%d" % (B, L, h, dk), err)
+    assert err["o"] < 2e-5 and err["dq"] < 1e-4 and err["dk"] < 1e-4 and err["dv"] < 1e-4, err
+    assert np.all(g[:, :, d:][np.broadcast_to(mask[:, :, None], (B, L, 2 * d))] == 0)   # padded keys get exactly 0
