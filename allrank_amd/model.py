@@ -1,0 +1,231 @@
+"""MI355X-native scoring model with the plugin surface of ``allrank.models.model`` / ``allrank.models.transformer``.
+
+``make_model(fc_model, transformer, post_model, n_features)`` (allrank/models/model.py:131-151, called at
+allrank/main.py:75) returns an ``LTRModel`` with ``forward(x, mask, indices)`` / ``score(x, mask, indices)``
+(model.py:72-92), the same ``state_dict`` keys and shapes as the reference, and -- given the same
+torch RNG state -- bit-identical initial weights: the construction below draws from the generator in the same
+order as the reference (one prototype nn.Linear deep-copied 4x per attention block, the encoder layer cloned N
+times, Xavier-uniform over parameters() with dim > 1 in registration order).
+
+Arithmetic: the per-slate self-attention (flash-style, fp32 MFMA) and the custom LayerNorm (+ fused residual add)
+run in hand-written HIP kernels (allrank_amd/ops.py -> libltrx.so).  The dense projections are plain library GEMMs
+(torch.nn.functional.linear -> hipBLASLt), with Q, K and V computed by ONE [3d, d] GEMM so that the attention
+kernel reads q/k/v as strided views of a single buffer.  Dropout follows torch semantics (nn.Dropout on the
+residual branches / activations); the attention-probability dropout of transformer.py:154-155 is only honoured for
+p == 0 or eval() -- with p > 0 in train() it raises, rather than silently training a different model.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _instantiate_activation(name):
+    """reference: instantiate_class("torch.nn.modules.activation", name) (model.py:28-29,106-107)"""
+    if name is None:
+        return nn.Identity()
+    import torch.nn.modules.activation as A
+    return getattr(A, name)()
+
+
+def first_arg_id(x, *y):       # model.py:8-9
+    return x
+
+
+class FCModel(nn.Module):
+    """model.py:12-44: input_norm -> [Linear -> activation -> dropout] per layer (also after the last one)."""
+
+    def __init__(self, sizes, input_norm, activation, dropout, n_features):
+        super(FCModel, self).__init__()
+        sizes.insert(0, n_features)                      # the reference mutates the config list too (model.py:25)
+        layers = [nn.Linear(a, b) for a, b in zip(sizes[:-1], sizes[1:])]
+        self.input_norm = nn.LayerNorm(n_features) if input_norm else nn.Identity()
+        self.activation = _instantiate_activation(activation)
+        self.dropout = nn.Dropout(dropout or 0.0)
+        self.output_size = sizes[-1]
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, x):
+        x = self.input_norm(x)
+        for layer in self.layers:
+            x = self.dropout(self.activation(layer(x)))
+        return x
+
+
+class LayerNorm(nn.Module):
+    """transformer.py:59-81 -- unbiased std, eps added to std.  Parameters a_2 / b_2 like the reference."""
+
+    def __init__(self, features, eps=1e-6):
+        super(LayerNorm, self).__init__()
+        self.a_2 = nn.Parameter(torch.ones(features))
+        self.b_2 = nn.Parameter(torch.zeros(features))
+        self.eps = eps
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.a_2, self.b_2, self.eps)
+
+
+class SublayerConnection(nn.Module):
+    """transformer.py:84-106; only a parameter/dropout holder here -- EncoderLayer fuses add+norm."""
+
+    def __init__(self, size, dropout):
+        super(SublayerConnection, self).__init__()
+        self.norm = LayerNorm(size)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x, sublayer):
+        return x + self.dropout(sublayer(self.norm(x)))
+
+
+class MultiHeadedAttention(nn.Module):
+    """transformer.py:159-203.  linears[0..2] = q/k/v projections, linears[3] = output projection."""
+
+    def __init__(self, h, d_model, dropout=0.1):
+        super(MultiHeadedAttention, self).__init__()
+        assert d_model % h == 0
+        self.d_k = d_model // h
+        self.h = h
+        proto = nn.Linear(d_model, d_model)
+        self.linears = nn.ModuleList([copy.deepcopy(proto) for _ in range(4)])
+        self.attn = None                                  # the reference keeps p_attn here; never materialised now
+        self.dropout = nn.Dropout(p=dropout)
+
+    def forward(self, query, key, value, mask=None):
+        if query is not key or key is not value:
+            raise NotImplementedError("only self-attention (query is key is value) is on the MI355X hot path")
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("attention-probability dropout > 0 in train() is not implemented in the fused "
+                                      "kernel; configure the transformer with dropout 0 for the attention block")
+        B, SL, d = query.shape
+        if mask is None:
+            mask = torch.zeros((B, SL), dtype=torch.bool, device=query.device)
+        mask = mask.reshape(B, -1)[:, -SL:] if mask.dim() > 2 else mask
+        w = torch.cat([self.linears[i].weight for i in range(3)], dim=0)
+        b = torch.cat([self.linears[i].bias for i in range(3)], dim=0)
+        qkv = F.linear(query, w, b)                                        # [B, L, 3d]
+        o = ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], mask, self.h)
+        return self.linears[3](o)
+
+
+class PositionwiseFeedForward(nn.Module):
+    """transformer.py:206-227"""
+
+    def __init__(self, d_model, d_ff, dropout=0.1):
+        super(PositionwiseFeedForward, self).__init__()
+        self.w_1 = nn.Linear(d_model, d_ff)
+        self.w_2 = nn.Linear(d_ff, d_model)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        return self.w_2(self.dropout(F.relu(self.w_1(x))))
+
+
+class EncoderLayer(nn.Module):
+    """transformer.py:109-134: x = x + drop(attn(norm0(x)));  x = x + drop(ffn(norm1(x)))."""
+
+    def __init__(self, size, self_attn, feed_forward, dropout):
+        super(EncoderLayer, self).__init__()
+        self.self_attn = self_attn
+        self.feed_forward = feed_forward
+        self.sublayer = nn.ModuleList([copy.deepcopy(SublayerConnection(size, dropout)) for _ in range(2)])
+        self.size = size
+
+    def forward(self, x, mask):
+        s0, s1 = self.sublayer[0], self.sublayer[1]
+        xn = s0.norm(x)
+        a = s0.dropout(self.self_attn(xn, xn, xn, mask))
+        # fused: x1 = x + a ; xn1 = LN(x1)
+        xn1, x1 = ops.layer_norm_residual(x, a, s1.norm.a_2, s1.norm.b_2, s1.norm.eps)
+        return x1 + s1.dropout(self.feed_forward(xn1))
+
+
+class Encoder(nn.Module):
+    """transformer.py:28-56"""
+
+    def __init__(self, layer, N, position):
+        super(Encoder, self).__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(N)])
+        self.norm = LayerNorm(layer.size)
+        self.position = position
+
+    def forward(self, x, mask, indices):
+        if self.position:
+            x = self.position(x, mask, indices)
+        for layer in self.layers:
+            x = layer(x, mask)
+        return self.norm(x)
+
+
+def make_transformer(N=6, d_ff=2048, h=8, dropout=0.1, n_features=136, positional_encoding=None):
+    """transformer.py:230-247"""
+    if positional_encoding is not None:
+        raise NotImplementedError("positional encodings (allrank/models/positional.py) are the next scope row "
+                                  "(SURVEY.md §8f #3); every shipped config uses positional_encoding: null")
+    attn = MultiHeadedAttention(h, n_features, dropout)
+    ff = PositionwiseFeedForward(n_features, d_ff, dropout)
+    return Encoder(EncoderLayer(n_features, copy.deepcopy(attn), copy.deepcopy(ff), dropout), N, None)
+
+
+class OutputLayer(nn.Module):
+    """model.py:95-128"""
+
+    def __init__(self, d_model, d_output, output_activation=None):
+        super(OutputLayer, self).__init__()
+        self.activation = _instantiate_activation(output_activation)
+        self.d_output = d_output
+        self.w_1 = nn.Linear(d_model, d_output)
+
+    def forward(self, x):
+        return self.activation(self.w_1(x).squeeze(dim=2))
+
+    def score(self, x):
+        if self.d_output > 1:
+            return self.forward(x).sum(-1)
+        return self.forward(x)
+
+
+class LTRModel(nn.Module):
+    """model.py:47-92"""
+
+    def __init__(self, input_layer, encoder, output_layer):
+        super(LTRModel, self).__init__()
+        self.input_layer = input_layer if input_layer else nn.Identity()
+        self.encoder = encoder if encoder else first_arg_id
+        self.output_layer = output_layer
+
+    def prepare_for_output(self, x, mask, indices):
+        return self.encoder(self.input_layer(x), mask, indices)
+
+    def forward(self, x, mask, indices):
+        return self.output_layer(self.prepare_for_output(x, mask, indices))
+
+    def score(self, x, mask, indices):
+        return self.output_layer.score(self.prepare_for_output(x, mask, indices))
+
+
+def _as_dict(cfg):
+    """accepts the reference's attrs TransformerConfig (config.py:8-15), a plain dict, or any object with fields."""
+    if cfg is None or isinstance(cfg, dict):
+        return cfg
+    try:
+        from attr import asdict
+        return asdict(cfg, recurse=False)
+    except Exception:
+        return {k: getattr(cfg, k) for k in ("N", "d_ff", "h", "positional_encoding", "dropout")}
+
+
+def make_model(fc_model, transformer, post_model, n_features):
+    """model.py:131-151"""
+    if fc_model:
+        fc_model = FCModel(**fc_model, n_features=n_features)
+    d_model = n_features if not fc_model else fc_model.output_size
+    if transformer:
+        transformer = make_transformer(n_features=d_model, **_as_dict(transformer))
+    model = LTRModel(fc_model, transformer, OutputLayer(d_model, **post_model))
+    for p in model.parameters():            # Glorot / fan_avg (model.py:148-150)
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+    return model

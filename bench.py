@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""bench.py -- slate-items/s of the listwise-LTR training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (allrank/training/train_utils.py:18-29: mask -> model forward -> listwise loss
+-> backward -> Adam step -> zero_grad) over one batch of synthetic WEB30K-shaped slates that is already resident in
+HBM.  Default workload = BASELINE.json configs[2], the one the north_star target is quoted on:
+F=136, slate_len 240, FCModel[512] -> 2-layer self-attention (d_model 512, h 8, d_ff 2048) -> ApproxNDCG, Adam 1e-3,
+dense slates, 64 slates per GPU (reproducibility/configs/*: batch_size 64, slate_length 240).
+`--workload fc_listnet` runs configs[1] (FCModel[96] + ListNet).  Weak scaling: every rank gets its own
+`--slates-per-gpu` slates, losses are normalised by the global batch and gradients summed over RCCL.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant hand-written kernel of the step (timed live with
+HIP events on the launch stream, in a side pass after the timed region); `cpu_baseline` is the numpy oracle's
+training step (oracle/model_oracle.py, kind "port") on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0
+
+WORKLOADS = {
+    "attn_approxndcg": dict(desc="WEB30K-synth F=136 L=240, fc[512] + 2x self-attention(d512,h8,d_ff2048) + ApproxNDCG (BASELINE configs[2])",
+                            n_features=136, fc_sizes=[512], N=2, h=8, d_ff=2048, loss="approxNDCGLoss"),
+    "fc_listnet": dict(desc="WEB30K-synth F=136 L=240, FCModel[96] + ListNet (BASELINE configs[1])",
+                       n_features=136, fc_sizes=[96], N=0, h=1, d_ff=0, loss="listNet"),
+}
+
+
+def train_flops_per_item(w, L):
+    """3*[2Fd + N(8d^2 + 4Ld + 4 d d_ff) + 2d] - 2Fd"""
+    F, d, N, dff = w["n_features"], w["fc_sizes"][-1], w["N"], w["d_ff"]
+    fwd = 2 * F * d + N * (8 * d * d + 4 * L * d + 4 * d * dff) + 2 * d
+    return 3 * fwd - 2 * F * d
+
+
+def synth_batch(n_slates, L, F, seed, device):
+    """SURVEY.md §8d recipe, dense slates: x ~ N(0,1), labels ~ Cat(.52,.32,.13,.02,.01), 3% of slates all-zero."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((n_slates, L, F), generator=g, dtype=torch.float32)
+    probs = torch.tensor([0.52, 0.32, 0.13, 0.02, 0.01])
+    y = torch.multinomial(probs, n_slates * L, replacement=True, generator=g).view(n_slates, L).float()
+    zero = torch.rand(n_slates, generator=g) < 0.03
+    y[zero] = 0.0
+    idx = torch.arange(L).expand(n_slates, L).contiguous()
+    return x.to(device), y.to(device), idx.to(device)
+
+
+def build_model(w, device):
+    from allrank_amd.model import make_model
+    tr = dict(N=w["N"], d_ff=w["d_ff"], h=w["h"], positional_encoding=None, dropout=0.0) if w["N"] else None
+    fc = dict(sizes=list(w["fc_sizes"]), input_norm=False, activation=None, dropout=0.0)
+    torch.manual_seed(42)                      # allrank/main.py:36
+    return make_model(fc, tr, dict(d_output=1, output_activation=None), w["n_features"]).to(device)
+
+
+def time_kernels(w, B, L, device):
+    """side pass: time the hand-written kernels of one step with HIP events on the launch stream."""
+    from allrank_amd import ops, losses as E
+    res = {}
+
+    def ev(fn, iters=10):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e-3 / iters
+
+    d, h = w["fc_sizes"][-1], w["h"]
+    y = torch.zeros(B, L, device=device)
+    s = torch.randn(B, L, device=device, requires_grad=True)
+    lossfn = getattr(E, w["loss"])
+    res["loss_fwd_bwd"] = dict(sec=ev(lambda: lossfn(s, y)), launches_per_step=1)
+    if w["N"]:
+        dk = d // h
+        qkv = torch.randn(B, L, 3 * d, device=device)
+        mask = torch.zeros(B, L, dtype=torch.bool, device=device)
+        q, k, v = qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:]
+        with torch.no_grad():
+            t_f = ev(lambda: ops.attention(q, k, v, mask, h))
+        fl = 4.0 * B * h * L * L * dk
+        res["ltrx_mha_fwd_kernel"] = dict(sec=t_f, flops=fl, launches_per_step=w["N"])
+        qkv.requires_grad_(True)
+        go = torch.randn(B, L, d, device=device)
+
+        def fb():
+            qkv.grad = None
+            ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], mask, h).backward(go)
+        t_fb = ev(fb)
+        res["ltrx_mha_bwd(dq+dkdv+delta)"] = dict(sec=max(t_fb - t_f, 1e-9), flops=2.5 * fl, launches_per_step=w["N"])
+        x = torch.randn(B * L, d, device=device)
+        r = torch.randn(B * L, d, device=device)
+        a = torch.ones(d, device=device)
+        bb = torch.zeros(d, device=device)
+        with torch.no_grad():
+            t_ln = ev(lambda: ops.layer_norm_residual(x, r, a, bb))
+        res["ltrx_layernorm_fwd_kernel"] = dict(sec=t_ln, bytes=4.0 * B * L * d * 4, launches_per_step=2 * w["N"] + 1)
+    return res
+
+
+def cpu_baseline(w, L, seconds_budget=20.0):
+    """numpy oracle training step (fp32, BLAS threads = all cores) on a bounded sample of the same workload."""
+    from oracle import ltr_oracle as O, model_oracle as M
+    cfg = dict(n_features=w["n_features"], fc_sizes=list(w["fc_sizes"]), fc_activation=None, fc_input_norm=False, N=w["N"],
+               d_ff=w["d_ff"], h=w["h"], output_activation=None)
+    Bs = 16 if w["N"] else 64
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((Bs, L, w["n_features"])).astype(np.float32)
+    y = rng.choice(5, size=(Bs, L), p=[0.52, 0.32, 0.13, 0.02, 0.01]).astype(np.float32)
+    params = M.init_params(cfg, seed=0)
+    opt = M.Adam(params, lr=1e-3)
+    lossfn = (lambda s, t: O.approxndcg(s, t)) if w["loss"] == "approxNDCGLoss" else (lambda s, t: O.listnet(s, t))
+    M.train_step(params, cfg, opt, x, y, lossfn)        # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        M.train_step(params, cfg, opt, x, y, lossfn)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 50:
+            break
+    return dict(value=round(n * Bs * L / el, 1), unit="slate-items/s", cores=os.cpu_count(), kind="port",
+                sample="%d training steps of %d slates x %d items, numpy oracle (oracle/model_oracle.py), fp32, BLAS on all cores"
+                       % (n, Bs, L))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="attn_approxndcg", choices=sorted(WORKLOADS))
+    ap.add_argument("--slates-per-gpu", type=int, default=64)
+    ap.add_argument("--slate-len", type=int, default=240)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from allrank_amd import losses as E
+    from allrank_amd.engine import Trainer
+    w = WORKLOADS[args.workload]
+    B, L = args.slates_per_gpu, args.slate_len
+    model = build_model(w, device)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)            # approxndcg.json:28-33
+    trainer = Trainer(model, getattr(E, w["loss"]), opt, None, world, None)
+    n_batches = 8
+    x, y, idx = synth_batch(n_batches * B, L, w["n_features"], 42 + rank, device)
+
+    def one_step(i):
+        j = (i % n_batches) * B
+        return trainer.step(x[j:j + B], y[j:j + B], idx[j:j + B], global_batch=B * world)
+
+    for i in range(args.warmup):
+        loss = one_step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = one_step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    last_loss = float(loss.item())
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        items = args.steps * B * L * world
+        value = items / dt
+        fl_item = train_flops_per_item(w, L)
+        kern = time_kernels(w, B, L, device)
+        # dominant hand-written kernel by time per step
+        name, k = max(kern.items(), key=lambda kv: kv[1]["sec"] * kv[1]["launches_per_step"])
+        if "flops" in k:
+            ach = k["flops"] / k["sec"] / 1e12
+            roof = dict(kernel=name, bound="mfma", achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        avg_launch_us=round(k["sec"] * 1e6, 1), algorithmic_flops_per_launch=k["flops"])
+        else:
+            by = k.get("bytes", 12.0 * B * L)
+            ach = by / k["sec"] / 1e9
+            roof = dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
+                        frac=round(ach / PEAK_HBM_GBPS, 4), traffic=None, avg_launch_us=round(k["sec"] * 1e6, 1),
+                        algorithmic_bytes_per_launch=by)
+        out = {
+            "metric": "slate-items/sec training (WEB30K synth, slate 240)", "value": round(value, 1),
+            "unit": "slate-items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["desc"], "slates_per_gpu": B, "slate_len": L, "global_batch": B * world,
+                       "optimizer": "Adam lr=1e-3", "parallelism": "slate-sharded dp%d" % world,
+                       "train_flops_per_item": fl_item},
+            "model_tflops": round(value * fl_item / 1e12, 2),
+            "model_mfma_frac_fp32": round(value * fl_item / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+            "algorithmic_hbm_frac": round(value * (4 * w["n_features"] + 8) / 1e9 / (PEAK_HBM_GBPS * world), 6),
+            "last_loss": last_loss,
+            "roofline": roof,
+            "kernel_times_us": {n: round(v["sec"] * 1e6, 1) for n, v in kern.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w, L)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

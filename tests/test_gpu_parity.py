@@ -258,3 +258,77 @@ def test_attention_forward_backward(B, L, h, dk):
     _log("attention_%d_%d_%d_%d" % (B, L, h, dk), err)
     assert err["o"] < 2e-5 and err["dq"] < 1e-4 and err["dk"] < 1e-4 and err["dv"] < 1e-4, err
     assert np.all(g[:, :, d:][np.broadcast_to(mask[:, :, None], (B, L, 2 * d))] == 0)   # padded keys get exactly 0
+
+
+def _cfg_from_golden(g, pre):
+    acts = {"ReLU": "ReLU", "Tanh": "Tanh", "Sigmoid": "Sigmoid", "-1": None}
+    v = lambda k: g[pre + "cfg." + k]  # noqa: E731
+    return dict(n_features=int(v("n_features")), fc_sizes=[int(x) for x in np.atleast_1d(v("fc_sizes"))],
+                fc_activation=acts[str(v("fc_activation"))], fc_input_norm=bool(v("fc_input_norm")), N=int(v("N")),
+                d_ff=int(v("d_ff")), h=int(v("h")), output_activation=acts[str(v("output_activation"))])
+
+
+def _make_engine_model(cfg, params=None):
+    from allrank_amd.model import make_model
+    tr = dict(N=cfg["N"], d_ff=cfg["d_ff"], h=cfg["h"], positional_encoding=None, dropout=0.0) if cfg["N"] else None
+    fc = dict(sizes=list(cfg["fc_sizes"]), input_norm=cfg["fc_input_norm"], activation=cfg["fc_activation"], dropout=0.0)
+    model = make_model(fc, tr, dict(d_output=1, output_activation=cfg["output_activation"]), cfg["n_features"])
+    if params is not None:
+        missing = model.load_state_dict({k: torch.tensor(v) for k, v in params.items()}, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+    return model.to(DEV)
+
+
+def test_model_matches_reference_golden(model_golden):
+    """scores and every parameter gradient (through approxNDCG) vs the reference's own CPU run; the golden state_dict
+    loads with strict=True, i.e. keys and shapes are the reference's (checkpoint contract)."""
+    from allrank_amd import losses as E
+    g = model_golden
+    rows = []
+    for mi in range(int(g["n_models"])):
+        pre = "m%d." % mi
+        cfg = _cfg_from_golden(g, pre)
+        params = {k[len(pre + "param."):]: v for k, v in g.items() if k.startswith(pre + "param.")}
+        model = _make_engine_model(cfg, params)
+        x, y = _t(g[pre + "x"]), _t(g[pre + "y"])
+        mask = y == -1
+        sc = model(x, mask, None)
+        loss = E.approxNDCGLoss(sc, y)
+        loss.backward()
+        valid = ~mask.cpu().numpy()
+        serr = float(np.abs(sc.detach().cpu().numpy() - g[pre + "scores"])[valid].max())
+        allg = np.concatenate([g[pre + "grad." + k].ravel() for k in params])
+        scale = float(np.abs(allg).max())
+        gerr = max(float(np.abs(p.grad.cpu().numpy() - g[pre + "grad." + n]).max()) for n, p in model.named_parameters())
+        rows.append(dict(model=mi, score_err=serr, loss=float(loss.item()), ref_loss=float(g[pre + "loss"]), grad_err=gerr, grad_scale=scale))
+        assert serr < 2e-5 and close(loss.item(), g[pre + "loss"]) and gerr <= 2e-4 * scale + 1e-8, rows[-1]
+        assert torch.equal(model.score(x, mask, None), model(x, mask, None))
+    _log("model_golden", rows)
+
+
+def test_model_config3_matches_oracle():
+    """BASELINE.json config (3): F=136, fc [512], N=2, h=8, d_ff=2048, slate 240 -- forward + backward vs the numpy oracle."""
+    from allrank_amd import losses as E
+    cfg = dict(n_features=136, fc_sizes=[512], fc_activation=None, fc_input_norm=False, N=2, d_ff=2048, h=8, output_activation=None)
+    params = M.init_params(cfg, seed=5)
+    model = _make_engine_model(cfg, params)
+    rng = np.random.default_rng(6)
+    B, L = 4, 240
+    x = rng.standard_normal((B, L, 136)).astype(np.float32)
+    y = rng.choice(5, size=(B, L), p=[0.52, 0.32, 0.13, 0.02, 0.01]).astype(np.float32)
+    y[1, 200:] = -1
+    x[1, 200:] = 0
+    y[3, 17:] = -1
+    x[3, 17:] = 0
+    mask = y == -1
+    sc = model(_t(x), _t(mask), None)
+    loss = E.approxNDCGLoss(sc, _t(y))
+    loss.backward()
+    so, cache = M.forward(params, cfg, x, mask)
+    lo, gs, _ = O.approxndcg(so, y)
+    grads = M.backward(params, cfg, cache, gs)
+    serr = float(np.abs(sc.detach().cpu().numpy() - so)[~mask].max())
+    scale = max(float(np.abs(v).max()) for v in grads.values())
+    gerr = max(float(np.abs(p.grad.cpu().numpy() - grads[n]).max()) for n, p in model.named_parameters())
+    _log("model_cfg3", dict(score_err=serr, loss=float(loss.item()), oracle_loss=float(lo), grad_err=gerr, grad_scale=scale))
+    assert serr < 5e-5 and close(loss.item(), lo) and gerr <= 5e-4 * scale
