@@ -11,3 +11,4 @@ Behind it: libltrx.so, a C-ABI library of hand-written HIP kernels (include/ltrx
 __version__ = "0.1.0"
 
 from . import losses, metrics  # noqa: F401,E402
+from .install import install, uninstall  # noqa: F401,E402

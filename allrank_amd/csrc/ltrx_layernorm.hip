@@ -115,23 +115,39 @@ __global__ void __launch_bounds__(256) ltrx_layernorm_bwd_kernel(const float* __
   }
 }
 
+// One workgroup per 64 columns; its 4 waves split the partial rows, lanes own consecutive columns (coalesced),
+// the 4 wave partials are combined through LDS in a fixed order (deterministic).
 __global__ void __launch_bounds__(256) ltrx_layernorm_bwd_reduce_kernel(const float* __restrict__ partial, int nblk,
                                                                         int D, float* __restrict__ da,
                                                                         float* __restrict__ db) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
-  float sa = 0.f, sb = 0.f;
-  for (int k = 0; k < nblk; ++k) {
-    sa += partial[(size_t)k * 2 * D + c];
-    sb += partial[(size_t)k * 2 * D + D + c];
+  __shared__ float sa[4][64];
+  __shared__ float sb[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float a = 0.f, b = 0.f;
+  if (c < D) {
+    for (int k = w; k < nblk; k += 4) {
+      a += partial[(size_t)k * 2 * D + c];
+      b += partial[(size_t)k * 2 * D + D + c];
+    }
   }
-  da[c] = sa;
-  db[c] = sb;
+  sa[w][lane] = a;
+  sb[w][lane] = b;
+  __syncthreads();
+  if (w == 0 && c < D) {
+    da[c] = (sa[0][lane] + sa[1][lane]) + (sa[2][lane] + sa[3][lane]);
+    db[c] = (sb[0][lane] + sb[1][lane]) + (sb[2][lane] + sb[3][lane]);
+  }
 }
 
 static int ln_grid(int rows) {
   int g = (rows + 3) / 4;
   return g > 1024 ? 1024 : (g < 1 ? 1 : g);
+}
+// the backward keeps per-block column partials: fewer, fatter blocks (each wave walks many rows)
+static int ln_bwd_grid(int rows) {
+  int g = (rows + 15) / 16;
+  return g > 256 ? 256 : (g < 1 ? 1 : g);
 }
 
 extern "C" int ltrx_layernorm_fwd(const float* x, const float* res, const float* a, const float* b, int rows, int D,
@@ -147,7 +163,7 @@ extern "C" int ltrx_layernorm_fwd(const float* x, const float* res, const float*
 
 extern "C" size_t ltrx_layernorm_bwd_workspace_bytes(int rows, int D) {
   if (rows <= 0 || D <= 0) return 0;
-  return (size_t)ln_grid(rows) * 2 * D * sizeof(float);
+  return (size_t)ln_bwd_grid(rows) * 2 * D * sizeof(float);
 }
 
 extern "C" int ltrx_layernorm_bwd(const float* dy, const float* xsum, const float* a, const float* mean,
@@ -156,11 +172,11 @@ extern "C" int ltrx_layernorm_bwd(const float* dy, const float* xsum, const floa
   if (!dy || !xsum || !a || !mean || !rstd || !dx_out || !da_out || !db_out || !ws || rows <= 0 || D < 2) return LTRX_EINVAL;
   if ((size_t)4 * 2 * D * sizeof(float) > 64 * 1024) return LTRX_EUNSUPPORTED;   // D <= 2048
   hipStream_t s = (hipStream_t)stream;
-  const int grid = ln_grid(rows);
+  const int grid = ln_bwd_grid(rows);
   hipLaunchKernelGGL(ltrx_layernorm_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * 2 * D * sizeof(float), s, dy, xsum, a,
                      mean, rstd, dres_in, rows, D, eps, dx_out, (float*)ws);
   LTRX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ltrx_layernorm_bwd_reduce_kernel, dim3((D + 255) / 256), dim3(256), 0, s, (const float*)ws, grid, D,
+  hipLaunchKernelGGL(ltrx_layernorm_bwd_reduce_kernel, dim3((D + 63) / 64), dim3(256), 0, s, (const float*)ws, grid, D,
                      da_out, db_out);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;

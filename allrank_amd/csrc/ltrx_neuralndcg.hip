@@ -28,6 +28,11 @@
 // (A register-resident variant for L <= 256 is the planned optimisation; this kernel is general in L.)
 #include "ltrx_device.h"
 
+// No FMA contraction in this file: the row max of P_max/tau and the exponent argument must be the SAME rounded
+// number (the reference materialises P_max/tau, loss_utils.py:65-66); a contracted fma((..), 1/tau, -max) differs
+// from the rounded product by one ulp of ~1e12 when tau is small and the scores are huge -> exp(+6e4) = inf.
+#pragma clang fp contract(off)
+
 using namespace ltrx;
 
 namespace {
@@ -152,7 +157,7 @@ __device__ __forceinline__ int load_slate(const SlateLds& t, const float* __rest
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) ltrx_neural_forward_kernel(const float* __restrict__ y_pred,
                                                                    const float* __restrict__ y_true, int L, float pad,
-                                                                   float inv_tau, int max_iter,
+                                                                   float tau, int max_iter,
                                                                    float* __restrict__ Sws, float* __restrict__ cnws,
                                                                    float* __restrict__ rnws, float* __restrict__ resws) {
   extern __shared__ float lds[];
@@ -174,11 +179,11 @@ __global__ void __launch_bounds__(1024) ltrx_neural_forward_kernel(const float* 
   for (int i = wave; i < n; i += nw) {
     const float sc_i = t.scal[i];
     float m = -INFINITY;
-    for (int j = lane; j < n; j += 64) m = fmaxf(m, (sc_i * t.sc[j] - t.bs[j]) * inv_tau);
+    for (int j = lane; j < n; j += 64) m = fmaxf(m, (sc_i * t.sc[j] - t.bs[j]) / tau);
     m = wave_max(m);
     float sum = 0.f;
     for (int j = lane; j < n; j += 64) {
-      const float e = expf((sc_i * t.sc[j] - t.bs[j]) * inv_tau - m);
+      const float e = expf((sc_i * t.sc[j] - t.bs[j]) / tau - m);
       S[(size_t)i * n + j] = e;
       sum += e;
     }
@@ -415,7 +420,7 @@ extern "C" int ltrx_neuralndcg_fwd_bwd(const float* y_pred, const float* y_true,
   const int threads = L <= 256 ? 256 : (L <= 512 ? 512 : 1024);
   const size_t lds = LTRX_NEURAL_LDS_FLOATS(L) * sizeof(float);
   hipLaunchKernelGGL(ltrx_neural_forward_kernel, dim3(B), dim3(threads), lds, s, y_pred, y_true, L, pad_value,
-                     1.0f / temperature, max_iter, w.S, w.cn, w.rn, w.res);
+                     temperature, max_iter, w.S, w.cn, w.rn, w.res);
   LTRX_LAUNCH_CHECK();
   hipLaunchKernelGGL(ltrx_neural_pick_iter_kernel, dim3(1), dim3(256), 0, s, w.res, B, max_iter, tol, w.titer, iters_out);
   LTRX_LAUNCH_CHECK();

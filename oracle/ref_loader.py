@@ -83,7 +83,7 @@ def load_reference(stable_sort=True):
         _stub("flatten_dict", flatten=_flatten)
         _stub("flatten_dict.reducers", make_reducer=lambda delimiter="/": "path")
     if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
+        sys.path.append(REFERENCE_ROOT)       # appended, not prepended: the reference has its own `tests` package
     import allrank  # noqa: E402
     import allrank.models.losses  # noqa: F401,E402
     import allrank.models.metrics  # noqa: F401,E402
