@@ -34,6 +34,14 @@ SIGNATURES = {
     "ltrx_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_mha_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "ltrx_mha_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ltrx_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp, _f, _vp]),
+    "ltrx_colsum_workspace_bytes": (_sz, [_i, _i]),
+    "ltrx_colsum": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "ltrx_relu_bwd": (_i, [_vp, _vp, _sz, _vp]),
+    "ltrx_bias_act": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "ltrx_score_head_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "ltrx_score_head_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "ltrx_score_head_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_selftest_mfma32x32x2": (_i, [_vp, _vp, _vp, _vp]),
     "ltrx_mha_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
 }

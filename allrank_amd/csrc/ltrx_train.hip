@@ -1,0 +1,272 @@
+// Small HBM-bound kernels of the explicit training step (allrank_amd/engine.py FusedTrainer): everything between
+// the library GEMMs that the reference leaves to dozens of separate ATen launches.
+//   ltrx_adam_step        torch.optim.Adam.step over ONE flat fp32 buffer (allrank/main.py:82; Adam lr 1e-3 in every
+//                         shipped config) -- 4 streams in, 3 out, 16-B accesses; bias correction on the device step count
+//   ltrx_colsum           bias gradients: out[n] = sum_m dY[m][n]   (nn.Linear backward; deterministic two-stage)
+//   ltrx_relu_bwd         dz = dr * (r > 0) in place                 (transformer.py:227 / FCModel activation)
+//   ltrx_bias_act         y = act(y + bias) in place                 (model.py:42-43: activation after every FC layer)
+//   ltrx_score_head_fwd/bwd  OutputLayer with d_output == 1 (model.py:111-117): s[m] = <x[m,:], w> + b, and its backward
+#include "ltrx_device.h"
+
+using namespace ltrx;
+
+// ---------------------------------------------------------------------------------------------------------------
+// Adam (torch defaults: amsgrad off, weight_decay 0, maximize off).  `step` is the 1-based step count, read from
+// device memory so that the launch is graph-replayable; the kernel of block 0 does NOT bump it (the host wrapper
+// enqueues a separate 1-thread increment first).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void ltrx_bump_step_kernel(float* __restrict__ step) { step[0] += 1.0f; }
+
+__global__ void __launch_bounds__(256) ltrx_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                        float lr, float b1, float b2, float eps,
+                                                        const float* __restrict__ step, float grad_scale) {
+  const float t = step[0];
+  const float bc1 = 1.0f - powf(b1, t);
+  const float bc2s = sqrtf(1.0f - powf(b2, t));
+  const float step_size = lr / bc1;
+  const size_t n4 = n / 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+#define LTRX_ADAM1(c)                                                   \
+  {                                                                     \
+    const float gr = gg.c * grad_scale;                                 \
+    mm.c = b1 * mm.c + (1.0f - b1) * gr;                                \
+    vv.c = b2 * vv.c + (1.0f - b2) * gr * gr;                           \
+    pp.c -= step_size * (mm.c / (sqrtf(vv.c) / bc2s + eps));            \
+  }
+    LTRX_ADAM1(x) LTRX_ADAM1(y) LTRX_ADAM1(z) LTRX_ADAM1(w)
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  // tail (n % 4 elements)
+  for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gr = g[i] * grad_scale;
+    const float mi = b1 * m[i] + (1.0f - b1) * gr;
+    const float vi = b2 * v[i] + (1.0f - b2) * gr * gr;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + eps));
+  }
+#undef LTRX_ADAM1
+}
+
+extern "C" int ltrx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                              float beta1, float beta2, float eps, float* step_count, float grad_scale,
+                              ltrx_stream_t stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !step_count || n == 0) return LTRX_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ltrx_bump_step_kernel, dim3(1), dim3(1), 0, s, step_count);
+  LTRX_LAUNCH_CHECK();
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(ltrx_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n, lr,
+                     beta1, beta2, eps, step_count, grad_scale);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// column sums of a row-major [M, N] matrix (row stride ld): out[n] = sum_m a[m][n]
+// stage 1: grid (ceil(N/64), R) blocks; each block's 4 waves stride over its row range, lanes own consecutive columns;
+// stage 2: fixed-order combine of the R partial rows.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ltrx_colsum_partial_kernel(const float* __restrict__ a, int M, int N, int ld,
+                                                                  float* __restrict__ partial) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int R = gridDim.y;
+  const int rows_per = (M + R - 1) / R;
+  const int r0 = blockIdx.y * rows_per;
+  const int r1 = min(M, r0 + rows_per);
+  float acc = 0.f;
+  if (c < N)
+    for (int r = r0 + w; r < r1; r += 4) acc += a[(size_t)r * ld + c];
+  sh[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && c < N) partial[(size_t)blockIdx.y * N + c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+
+__global__ void __launch_bounds__(256) ltrx_colsum_final_kernel(const float* __restrict__ partial, int R, int N,
+                                                                float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float acc = 0.f;
+  for (int r = 0; r < R; ++r) acc += partial[(size_t)r * N + c];
+  out[c] = accumulate ? out[c] + acc : acc;
+}
+
+static int colsum_rows(int M) {
+  int r = (M + 255) / 256;
+  return r > 64 ? 64 : (r < 1 ? 1 : r);
+}
+
+extern "C" size_t ltrx_colsum_workspace_bytes(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (size_t)colsum_rows(M) * N * sizeof(float);
+}
+
+extern "C" int ltrx_colsum(const float* a, int M, int N, int ld, float* out, int accumulate, void* ws,
+                           ltrx_stream_t stream) {
+  if (!a || !out || !ws || M <= 0 || N <= 0 || ld < N) return LTRX_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int R = colsum_rows(M);
+  hipLaunchKernelGGL(ltrx_colsum_partial_kernel, dim3((N + 63) / 64, R), dim3(256), 0, s, a, M, N, ld, (float*)ws);
+  LTRX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ltrx_colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)ws, R, N, out, accumulate);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// elementwise helpers
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ltrx_relu_bwd_kernel(float* __restrict__ dr, const float* __restrict__ r, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 d = reinterpret_cast<float4*>(dr)[i];
+    const float4 a = reinterpret_cast<const float4*>(r)[i];
+    d.x = a.x > 0.f ? d.x : 0.f;
+    d.y = a.y > 0.f ? d.y : 0.f;
+    d.z = a.z > 0.f ? d.z : 0.f;
+    d.w = a.w > 0.f ? d.w : 0.f;
+    reinterpret_cast<float4*>(dr)[i] = d;
+  }
+}
+
+extern "C" int ltrx_relu_bwd(float* dr_inout, const float* r_post_act, size_t n, ltrx_stream_t stream) {
+  if (!dr_inout || !r_post_act || n == 0 || (n & 3)) return LTRX_EINVAL;
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ltrx_relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dr_inout, r_post_act, n / 4);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+// y = act(y + bias) in place; act: 0 identity, 1 ReLU.  [M, N] contiguous, N % 4 == 0.
+__global__ void __launch_bounds__(256) ltrx_bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, size_t M,
+                                                            int N4, int act) {
+  const size_t total = M * (size_t)N4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % N4);
+    float4 v = reinterpret_cast<float4*>(y)[i];
+    const float4 b = reinterpret_cast<const float4*>(bias)[c4];
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    if (act == 1) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+}
+
+extern "C" int ltrx_bias_act(float* y_inout, const float* bias, int M, int N, int act, ltrx_stream_t stream) {
+  if (!y_inout || !bias || M <= 0 || N <= 0 || (N & 3) || act < 0 || act > 1) return LTRX_EINVAL;
+  size_t total = (size_t)M * (N / 4);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ltrx_bias_act_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y_inout, bias, (size_t)M, N / 4, act);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// OutputLayer, d_output == 1:  s[m] = <x[m,:], w> + b     (wave per row)
+// backward: dx[m][c] = ds[m] * w[c];  dw[c] = sum_m ds[m] x[m][c];  db = sum_m ds[m]   (dw/db two-stage like colsum)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ltrx_score_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                  const float* __restrict__ b, int M, int D,
+                                                                  float* __restrict__ s) {
+  const int lane = lane_id(), wpb = blockDim.x >> 6;
+  for (int row = blockIdx.x * wpb + wave_id(); row < M; row += gridDim.x * wpb) {
+    const float* xr = x + (size_t)row * D;
+    float acc = 0.f;
+    for (int c = lane; c < D; c += 64) acc += xr[c] * w[c];
+    acc = wave_sum(acc);
+    if (lane == 0) s[row] = acc + b[0];
+  }
+}
+
+__global__ void __launch_bounds__(256) ltrx_score_head_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ x,
+                                                                  const float* __restrict__ w, int M, int D,
+                                                                  float* __restrict__ dx, float* __restrict__ partial) {
+  extern __shared__ float lds[];   // [wpb][D] dw partials + [wpb] db partials
+  const int lane = lane_id(), wv = wave_id(), wpb = blockDim.x >> 6;
+  float* my = lds + (size_t)wv * D;
+  for (int c = lane; c < D; c += 64) my[c] = 0.f;
+  float dbacc = 0.f;
+  for (int row = blockIdx.x * wpb + wv; row < M; row += gridDim.x * wpb) {
+    const float g = ds[row];
+    const float* xr = x + (size_t)row * D;
+    float* dxr = dx + (size_t)row * D;
+    for (int c = lane; c < D; c += 64) {
+      dxr[c] = g * w[c];
+      my[c] += g * xr[c];
+    }
+    dbacc += g;   // identical in every lane
+  }
+  float* dbs = lds + (size_t)wpb * D;
+  if (lane == 0) dbs[wv] = dbacc;
+  __syncthreads();
+  float* pa = partial + (size_t)blockIdx.x * (D + 1);
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    float a = 0.f;
+    for (int k = 0; k < wpb; ++k) a += lds[(size_t)k * D + c];
+    pa[c] = a;
+  }
+  if (threadIdx.x == 0) {
+    float a = 0.f;
+    for (int k = 0; k < wpb; ++k) a += dbs[k];
+    pa[D] = a;
+  }
+}
+
+__global__ void __launch_bounds__(256) ltrx_score_head_reduce_kernel(const float* __restrict__ partial, int nblk, int D,
+                                                                     float* __restrict__ dw, float* __restrict__ db) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > D) return;
+  float a = 0.f;
+  for (int k = 0; k < nblk; ++k) a += partial[(size_t)k * (D + 1) + c];
+  if (c < D) dw[c] = a; else db[0] = a;
+}
+
+static int head_grid(int M) {
+  int g = (M + 63) / 64;
+  return g > 128 ? 128 : (g < 1 ? 1 : g);
+}
+
+extern "C" int ltrx_score_head_fwd(const float* x, const float* w, const float* b, int M, int D, float* scores,
+                                   ltrx_stream_t stream) {
+  if (!x || !w || !b || !scores || M <= 0 || D <= 0) return LTRX_EINVAL;
+  int g = (M + 3) / 4;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(ltrx_score_head_fwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, w, b, M, D, scores);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+extern "C" size_t ltrx_score_head_bwd_workspace_bytes(int M, int D) {
+  if (M <= 0 || D <= 0) return 0;
+  return (size_t)head_grid(M) * (D + 1) * sizeof(float);
+}
+
+extern "C" int ltrx_score_head_bwd(const float* dscores, const float* x, const float* w, int M, int D, float* dx,
+                                   float* dw, float* db, void* ws, ltrx_stream_t stream) {
+  if (!dscores || !x || !w || !dx || !dw || !db || !ws || M <= 0 || D <= 0) return LTRX_EINVAL;
+  if ((size_t)(4 * D + 4) * sizeof(float) > 64 * 1024) return LTRX_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int g = head_grid(M);
+  hipLaunchKernelGGL(ltrx_score_head_bwd_kernel, dim3(g), dim3(256), (size_t)(4 * D + 4) * sizeof(float), s, dscores, x, w, M,
+                     D, dx, (float*)ws);
+  LTRX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ltrx_score_head_reduce_kernel, dim3((D + 1 + 255) / 256), dim3(256), 0, s, (const float*)ws, g, D, dw, db);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}

@@ -43,3 +43,329 @@ class Trainer(object):
         self.opt.step()
         self.flat.zero()          # == opt.zero_grad(set_to_none=False): grads stay views of the flat buffer
         return loss
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# FusedTrainer: the same training step, written out explicitly (no autograd) on preallocated buffers
+# ------------------------------------------------------------------------------------------------------------------
+class FusedTrainer(object):
+    """One training step of train_utils.py:18-29 as a fixed launch sequence on persistent HBM buffers:
+
+        FC -> N x [LN -> QKV GEMM -> fused attention -> out GEMM -> (+res, LN) -> FFN GEMMs(+ReLU)] -> (+res, LN)
+           -> score head -> fused listwise loss (value + d/dscores) -> hand-written backward -> [RCCL all-reduce]
+           -> fused Adam over ONE flat parameter buffer.
+
+    * parameters / gradients / Adam moments are single flat fp32 buffers; the nn.Module's parameters are re-pointed
+      at views of the flat buffer, so ``model.state_dict()`` / ``model.score()`` always see the trained weights, and
+      the Q,K,V projection weights of a layer sit adjacently => ONE [3d, d] GEMM feeds the attention kernel in place.
+    * every gradient is written exactly once per step straight into the flat gradient buffer (GEMM ``out=`` views):
+      no zero_grad pass, no accumulation kernels, one collective for multi-GPU.
+    * dense projections are library GEMMs (torch.mm/addmm -> hipBLASLt); everything else is libltrx kernels.
+    * the whole sequence is captured in a hipGraph after warm-up (``use_graph=True``) -- at 64 slates/GPU the step is
+      ~100 launches of 10-300 us, so launch latency matters.
+    Supported model family = what the hot path names: FCModel (no input_norm, activation None/ReLU, dropout 0) ->
+    optional encoder (no positional encoding, dropout 0) -> OutputLayer(d_output=1, no activation).  Anything else
+    raises NotImplementedError (use ``Trainer``).
+    """
+
+    def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
+                 use_graph=True):
+        import torch.nn as nn
+        from . import _lib as LB
+        from .losses import FusedLoss
+        from .model import FCModel, Encoder, LTRModel
+        self.LB = LB
+        self.lib = LB.lib()
+        self.model = model
+        self.B, self.L, self.M = B, L, B * L
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.world, self.group = world_size, group
+        if not isinstance(model, LTRModel) or not isinstance(model.input_layer, FCModel):
+            raise NotImplementedError("FusedTrainer needs an allrank_amd LTRModel with an FCModel input block")
+        fc = model.input_layer
+        if not isinstance(fc.input_norm, nn.Identity) or fc.dropout.p != 0:
+            raise NotImplementedError("FusedTrainer: FCModel.input_norm / dropout are not on the fused path")
+        if isinstance(fc.activation, nn.Identity):
+            self.fc_act = 0
+        elif isinstance(fc.activation, nn.ReLU):
+            self.fc_act = 1
+        else:
+            raise NotImplementedError("FusedTrainer: FC activation %r" % (fc.activation,))
+        enc = model.encoder if isinstance(model.encoder, Encoder) else None
+        if enc is not None and enc.position is not None:
+            raise NotImplementedError("positional encoding")
+        out = model.output_layer
+        if out.d_output != 1 or not isinstance(out.activation, nn.Identity):
+            raise NotImplementedError("FusedTrainer: OutputLayer must have d_output == 1 and no activation")
+        dev = next(model.parameters()).device
+        self.dev = dev
+        self.enc = enc
+        self.nfc = len(fc.layers)
+        self.fc_sizes = [fc.layers[0].in_features] + [l.out_features for l in fc.layers]
+        self.d = self.fc_sizes[-1]
+        self.N = len(enc.layers) if enc is not None else 0
+        if enc is not None:
+            l0 = enc.layers[0]
+            self.h = l0.self_attn.h
+            self.dff = l0.feed_forward.w_1.out_features
+            for lay in enc.layers:
+                for sl in lay.sublayer:
+                    if sl.dropout.p != 0:
+                        raise NotImplementedError("FusedTrainer: dropout > 0")
+                if lay.self_attn.dropout.p != 0 or lay.feed_forward.dropout.p != 0:
+                    raise NotImplementedError("FusedTrainer: dropout > 0")
+            self.ln_eps = enc.norm.eps
+
+        # ---- flat parameter layout (16-byte aligned segments; q,k,v weights and biases adjacent) ----
+        order = []
+        for lyr in fc.layers:
+            order += [lyr.weight, lyr.bias]
+        if enc is not None:
+            for lay in enc.layers:
+                lin = lay.self_attn.linears
+                order += [lin[0].weight, lin[1].weight, lin[2].weight, lin[0].bias, lin[1].bias, lin[2].bias,
+                          lin[3].weight, lin[3].bias, lay.feed_forward.w_1.weight, lay.feed_forward.w_1.bias,
+                          lay.feed_forward.w_2.weight, lay.feed_forward.w_2.bias,
+                          lay.sublayer[0].norm.a_2, lay.sublayer[0].norm.b_2, lay.sublayer[1].norm.a_2, lay.sublayer[1].norm.b_2]
+            order += [enc.norm.a_2, enc.norm.b_2]
+        order += [out.w_1.weight, out.w_1.bias]
+        assert len(order) == len(list(model.parameters()))
+        offs, n = [], 0
+        for p in order:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.nflat = n
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._pv, self._gv = {}, {}
+        with torch.no_grad():
+            for p, o in zip(order, offs):
+                view = self.flat_p[o:o + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+                self._pv[id(p)] = (o, p.shape)
+
+        def W(p):
+            return p.data
+
+        def G(p):
+            return p.grad
+
+        self.W, self.G = W, G
+
+        def fused_view(buf, first, count_rows, cols=None):
+            o, _ = self._pv[id(first)]
+            if cols is None:
+                return buf[o:o + count_rows]
+            return buf[o:o + count_rows * cols].view(count_rows, cols)
+
+        M, d = self.M, self.d
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.x_in = torch.zeros((M, self.fc_sizes[0]), **f32)
+        self.y_in = torch.zeros((B, L), **f32)
+        self.mask = torch.zeros((B, L), dtype=torch.uint8, device=dev)
+        self.fc_out = [torch.zeros((M, s), **f32) for s in self.fc_sizes[1:]]
+        self.layers = []
+        for i in range(self.N):
+            lay = enc.layers[i]
+            lin = lay.self_attn.linears
+            st = dict(
+                wqkv=fused_view(self.flat_p, lin[0].weight, 3 * d, d), bqkv=fused_view(self.flat_p, lin[0].bias, 3 * d),
+                gwqkv=fused_view(self.flat_g, lin[0].weight, 3 * d, d), gbqkv=fused_view(self.flat_g, lin[0].bias, 3 * d),
+                xsum0=None if i == 0 else torch.zeros((M, d), **f32),      # residual stream entering the layer
+                xn0=torch.zeros((M, d), **f32), mean0=torch.zeros(M, **f32), rstd0=torch.zeros(M, **f32),
+                qkv=torch.zeros((M, 3 * d), **f32), o=torch.zeros((M, d), **f32), lse=torch.zeros((B, self.h, L), **f32),
+                x1=torch.zeros((M, d), **f32), xn1=torch.zeros((M, d), **f32), mean1=torch.zeros(M, **f32),
+                rstd1=torch.zeros(M, **f32), r=torch.zeros((M, self.dff), **f32), mod=lay)
+            self.layers.append(st)
+        if self.N:
+            self.branch = torch.zeros((M, d), **f32)          # attention-proj / FFN output before the residual add
+            self.xsum_f = torch.zeros((M, d), **f32)
+            self.xf = torch.zeros((M, d), **f32)
+            self.mean_f = torch.zeros(M, **f32)
+            self.rstd_f = torch.zeros(M, **f32)
+            self.d_r = torch.zeros((M, self.dff), **f32)
+            self.dqkv = torch.zeros((M, 3 * d), **f32)
+            self.d_o = torch.zeros((M, d), **f32)
+            self.tmp_d = torch.zeros((M, d), **f32)
+            self.ws_ln = torch.empty(max(self.lib.ltrx_layernorm_bwd_workspace_bytes(M, d), 64), dtype=torch.uint8, device=dev)
+            self.ws_mha = torch.empty(max(self.lib.ltrx_mha_bwd_workspace_bytes(B, L, self.h), 64), dtype=torch.uint8, device=dev)
+        self.scores = torch.zeros((B, L), **f32)
+        self.d_a = torch.zeros((M, d), **f32)                 # gradient w.r.t. the residual stream (ping)
+        self.d_b = torch.zeros((M, d), **f32)                 # (pong)
+        maxn = max([3 * d, self.dff if self.N else 0] + self.fc_sizes[1:])
+        self.ws_col = torch.empty(max(self.lib.ltrx_colsum_workspace_bytes(M, maxn), 64), dtype=torch.uint8, device=dev)
+        self.ws_head = torch.empty(max(self.lib.ltrx_score_head_bwd_workspace_bytes(M, d), 64), dtype=torch.uint8, device=dev)
+        self.fc_dgrad = [torch.zeros((M, s), **f32) for s in self.fc_sizes[1:-1]]
+        self.loss = FusedLoss(loss_name, B, L, dev, **(loss_args or {}))
+        self.use_graph = use_graph
+        self.graph = None
+        self._warm = 0
+
+    # ---- thin launch helpers -----------------------------------------------------------------------------------
+    def _st(self):
+        return self.LB.ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _ln_fwd(self, x, res, a, b, xsum, y, mean, rstd):
+        P = self.LB.ptr
+        self.LB.check(self.lib.ltrx_layernorm_fwd(P(x), P(res), P(a), P(b), self.M, self.d, float(self.ln_eps), P(xsum), P(y),
+                                                  P(mean), P(rstd), self._st()), "layernorm_fwd")
+
+    def _ln_bwd(self, dy, xsum, a, mean, rstd, dres, dx, da, db):
+        P = self.LB.ptr
+        self.LB.check(self.lib.ltrx_layernorm_bwd(P(dy), P(xsum), P(a), P(mean), P(rstd), P(dres), self.M, self.d,
+                                                  float(self.ln_eps), P(dx), P(da), P(db), P(self.ws_ln), self._st()),
+                      "layernorm_bwd")
+
+    def _colsum(self, a, out):
+        P = self.LB.ptr
+        self.LB.check(self.lib.ltrx_colsum(P(a), a.shape[0], a.shape[1], a.stride(0), P(out), 0, P(self.ws_col), self._st()),
+                      "colsum")
+
+    def _relu_bwd(self, dr, r):
+        self.LB.check(self.lib.ltrx_relu_bwd(self.LB.ptr(dr), self.LB.ptr(r), dr.numel(), self._st()), "relu_bwd")
+
+    # ---- the step body (capturable) ----------------------------------------------------------------------------
+    def _body(self):
+        P = self.LB.ptr
+        lib, M, d, B, L = self.lib, self.M, self.d, self.B, self.L
+        W, G = self.W, self.G
+        fc = self.model.input_layer
+        # ---------------- forward ----------------
+        h = self.x_in
+        for i, lyr in enumerate(fc.layers):
+            torch.addmm(W(lyr.bias), h, W(lyr.weight).t(), out=self.fc_out[i])
+            if self.fc_act == 1:
+                torch.relu_(self.fc_out[i])
+            h = self.fc_out[i]
+        x = h                                                     # residual stream
+        for i, st in enumerate(self.layers):
+            lay = st["mod"]
+            n0, n1 = lay.sublayer[0].norm, lay.sublayer[1].norm
+            if i == 0:
+                self._ln_fwd(x, None, W(n0.a_2), W(n0.b_2), None, st["xn0"], st["mean0"], st["rstd0"])
+            else:                                                 # x = x1_prev + ffn_prev, fused with this layer's first norm
+                self._ln_fwd(x, self.branch, W(n0.a_2), W(n0.b_2), st["xsum0"], st["xn0"], st["mean0"], st["rstd0"])
+                x = st["xsum0"]
+            st["xin"] = x
+            torch.addmm(st["bqkv"], st["xn0"], st["wqkv"].t(), out=st["qkv"])
+            qkv = st["qkv"]
+            self.LB.check(lib.ltrx_mha_fwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(self.mask), B, L, self.h,
+                                           d // self.h, 3 * d, P(st["o"]), d, P(st["lse"]), self._st()), "mha_fwd")
+            lo = lay.self_attn.linears[3]
+            torch.addmm(W(lo.bias), st["o"], W(lo.weight).t(), out=self.branch)
+            self._ln_fwd(x, self.branch, W(n1.a_2), W(n1.b_2), st["x1"], st["xn1"], st["mean1"], st["rstd1"])
+            ff = lay.feed_forward
+            torch.addmm(W(ff.w_1.bias), st["xn1"], W(ff.w_1.weight).t(), out=st["r"])
+            torch.relu_(st["r"])
+            torch.addmm(W(ff.w_2.bias), st["r"], W(ff.w_2.weight).t(), out=self.branch)
+            x = st["x1"]
+        out = self.model.output_layer
+        if self.N:
+            nf = self.enc.norm
+            self._ln_fwd(x, self.branch, W(nf.a_2), W(nf.b_2), self.xsum_f, self.xf, self.mean_f, self.rstd_f)
+            feat = self.xf
+        else:
+            feat = x
+        self.LB.check(lib.ltrx_score_head_fwd(P(feat), P(W(out.w_1.weight)), P(W(out.w_1.bias)), M, d, P(self.scores), self._st()),
+                      "score_head_fwd")
+        # ---------------- loss (value + d/dscores) ----------------
+        loss, dsc = self.loss.run(self.scores, self.y_in, self._divisor)
+        # ---------------- backward ----------------
+        ga, gb = self.d_a, self.d_b
+        self.LB.check(lib.ltrx_score_head_bwd(P(dsc), P(feat), P(W(out.w_1.weight)), M, d, P(ga), P(G(out.w_1.weight)),
+                                              P(G(out.w_1.bias)), P(self.ws_head), self._st()), "score_head_bwd")
+        if self.N:
+            nf = self.enc.norm
+            self._ln_bwd(ga, self.xsum_f, W(nf.a_2), self.mean_f, self.rstd_f, None, gb, G(nf.a_2), G(nf.b_2))
+            ds = gb                                               # d loss / d (x1_last + ffn_last)
+            other = ga
+            for i in range(self.N - 1, -1, -1):
+                st = self.layers[i]
+                lay = st["mod"]
+                n0, n1 = lay.sublayer[0].norm, lay.sublayer[1].norm
+                ff = lay.feed_forward
+                # FFN branch
+                self._colsum(ds, G(ff.w_2.bias))
+                torch.mm(ds.t(), st["r"], out=G(ff.w_2.weight))
+                torch.mm(ds, W(ff.w_2.weight), out=self.d_r)
+                self._relu_bwd(self.d_r, st["r"])
+                self._colsum(self.d_r, G(ff.w_1.bias))
+                torch.mm(self.d_r.t(), st["xn1"], out=G(ff.w_1.weight))
+                torch.mm(self.d_r, W(ff.w_1.weight), out=self.tmp_d)
+                self._ln_bwd(self.tmp_d, st["x1"], W(n1.a_2), st["mean1"], st["rstd1"], ds, other, G(n1.a_2), G(n1.b_2))
+                ds, other = other, ds                              # ds = d loss / d x1
+                # attention branch
+                lo = lay.self_attn.linears[3]
+                self._colsum(ds, G(lo.bias))
+                torch.mm(ds.t(), st["o"], out=G(lo.weight))
+                torch.mm(ds, W(lo.weight), out=self.d_o)
+                qkv, dq = st["qkv"], self.dqkv
+                self.LB.check(lib.ltrx_mha_bwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(self.mask), P(st["o"]),
+                                               P(self.d_o), P(st["lse"]), B, L, self.h, d // self.h, 3 * d, d, P(dq),
+                                               dq.data_ptr() + 4 * d, dq.data_ptr() + 8 * d, 3 * d, P(self.ws_mha), self._st()),
+                              "mha_bwd")
+                self._colsum(dq, st["gbqkv"])
+                torch.mm(dq.t(), st["xn0"], out=st["gwqkv"])
+                torch.mm(dq, st["wqkv"], out=self.tmp_d)
+                self._ln_bwd(self.tmp_d, st["xin"], W(n0.a_2), st["mean0"], st["rstd0"], ds, other, G(n0.a_2), G(n0.b_2))
+                ds, other = other, ds                              # ds = d loss / d (layer input)
+        else:
+            ds, other = ga, gb
+        # FC stack
+        for i in range(self.nfc - 1, -1, -1):
+            lyr = fc.layers[i]
+            if self.fc_act == 1:
+                self._relu_bwd(ds, self.fc_out[i])
+            self._colsum(ds, G(lyr.bias))
+            inp = self.x_in if i == 0 else self.fc_out[i - 1]
+            torch.mm(ds.t(), inp, out=G(lyr.weight))
+            if i > 0:
+                torch.mm(ds, W(lyr.weight), out=self.fc_dgrad[i - 1])
+                ds = self.fc_dgrad[i - 1]
+        return loss
+
+    def _adam(self):
+        P = self.LB.ptr
+        self.LB.check(self.lib.ltrx_adam_step(P(self.flat_p), P(self.flat_g), P(self.flat_m), P(self.flat_v), self.nflat,
+                                              float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                              P(self.step_count), 1.0, self._st()), "adam_step")
+
+    def _full(self):
+        loss = self._body()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+        self._adam()
+        return loss
+
+    def step(self, xb, yb, indices=None, global_batch=None):
+        """copy the batch into the static input buffers and run (or replay) the step; returns the device loss [1]."""
+        self._divisor = float(global_batch if global_batch is not None else self.B * self.world)
+        self.x_in.copy_(xb.reshape(self.M, -1))
+        self.y_in.copy_(yb)
+        self.mask.copy_(yb == PADDED_Y_VALUE)
+        if not self.use_graph or self.world > 1:
+            with sharding.shard_context(int(self._divisor), self.group) if self.world > 1 else _null():
+                return self._full()
+        if self.graph is None:
+            if self._warm < 2:                        # warm up hipBLASLt heuristics / workspaces outside capture
+                self._warm += 1
+                return self._full()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._graph_loss = self._full()       # capture only records; the replay below executes this step
+        self.graph.replay()
+        return self._graph_loss
+
+
+class _null(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False

@@ -172,3 +172,94 @@ def neuralNDCG_transposed(y_pred, y_true, padded_value_indicator=PADDED_Y_VALUE,
     """NeuralNDCG transposed (allrank/models/losses/neuralNDCG.py:73-136)."""
     return _neural(y_pred, y_true, padded_value_indicator, temperature, powered_relevancies, k, stochastic, True,
                    max_iter, tol)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Allocation-free launchers for the explicit training step (allrank_amd.engine.FusedTrainer): same kernels, persistent
+# output / workspace buffers, no autograd node -> capturable in a hipGraph.
+# ----------------------------------------------------------------------------------------------------------------
+class FusedLoss(object):
+    """``run(scores[B,L], y[B,L], batch_divisor)`` -> (loss[1], dloss/dscores[B,L]) on persistent device buffers."""
+
+    def __init__(self, name, B, SL, device, **args):
+        self.name, self.B, self.SL, self.args = name, B, SL, dict(args)
+        lib = L.lib()
+        self.loss = torch.zeros(1, dtype=torch.float32, device=device)
+        self.grad = torch.zeros((B, SL), dtype=torch.float32, device=device)
+        pad = float(args.get("padded_value_indicator", PADDED_Y_VALUE))
+        eps = float(args.get("eps", DEFAULT_EPS))
+        self.pad, self.eps = pad, eps
+        if name == "listNet":
+            nb = lib.ltrx_listnet_workspace_bytes(B, SL)
+        elif name == "listMLE":
+            nb = lib.ltrx_listmle_workspace_bytes(B, SL)
+            self.perm = torch.arange(SL, dtype=torch.int64, device=device)
+        elif name == "approxNDCGLoss":
+            nb = lib.ltrx_approxndcg_workspace_bytes(B, SL)
+        elif name == "lambdaLoss":
+            if args.get("weighing_scheme") not in _SCHEMES:
+                raise KeyError(args.get("weighing_scheme"))
+            if args.get("reduction_log", "binary") not in ("natural", "binary"):
+                raise ValueError("Reduction logarithm base can be either natural or binary")
+            if args.get("reduction", "sum") not in ("sum", "mean"):
+                raise ValueError("Reduction method can be either sum or mean")
+            nb = lib.ltrx_lambdaloss_workspace_bytes(B, SL)
+            self.cnt = torch.zeros(1, dtype=torch.float32, device=device)
+        elif name in ("neuralNDCG", "neuralNDCG_transposed"):
+            if args.get("stochastic", False):
+                raise NotImplementedError("stochastic NeuralSort is not on the MI355X hot path yet")
+            self.max_iter = int(args.get("max_iter", 50))
+            nb = lib.ltrx_neuralndcg_workspace_bytes(B, SL, self.max_iter)
+            self.idcg = torch.zeros(B, dtype=torch.float32, device=device)
+            self.cnt = torch.zeros(1, dtype=torch.float32, device=device)
+        else:
+            raise KeyError("no fused launcher for loss %r" % (name,))
+        self.ws = torch.empty(max(int(nb), 64), dtype=torch.uint8, device=device)
+
+    def set_perm(self, perm):
+        self.perm.copy_(perm.to(self.perm.device))
+
+    def run(self, yp, yt, batch_divisor=None):
+        lib = L.lib()
+        B, SL, a = self.B, self.SL, self.args
+        div = float(batch_divisor if batch_divisor is not None else B)
+        st = L.stream_of(yp)
+        n = self.name
+        if n == "listNet":
+            rc = lib.ltrx_listnet_fwd_bwd(L.ptr(yp), L.ptr(yt), B, SL, self.eps, self.pad, div, L.ptr(self.loss), None,
+                                          L.ptr(self.grad), L.ptr(self.ws), st)
+        elif n == "listMLE":
+            rc = lib.ltrx_listmle_fwd_bwd(L.ptr(yp), L.ptr(yt), L.ptr(self.perm), B, SL, self.eps, self.pad, div,
+                                          L.ptr(self.loss), None, L.ptr(self.grad), None, L.ptr(self.ws), st)
+        elif n == "approxNDCGLoss":
+            rc = lib.ltrx_approxndcg_fwd_bwd(L.ptr(yp), L.ptr(yt), B, SL, self.eps, self.pad, float(a.get("alpha", 1.)), div,
+                                             L.ptr(self.loss), None, L.ptr(self.grad), L.ptr(self.ws), st)
+        elif n == "lambdaLoss":
+            k = a.get("k")
+            red = 0 if a.get("reduction", "sum") == "sum" else 1
+            lg = 0 if a.get("reduction_log", "binary") == "binary" else 1
+            ext = None
+            if red == 1 and sharding.active():
+                rc = lib.ltrx_lambdaloss_fwd_bwd(L.ptr(yp), L.ptr(yt), B, SL, self.eps, self.pad, _SCHEMES[a.get("weighing_scheme")],
+                                                 0 if k is None else int(k), float(a.get("sigma", 1.)), float(a.get("mu", 10.)), 0, lg,
+                                                 None, L.ptr(self.loss), L.ptr(self.cnt), None, None, L.ptr(self.ws), st)
+                L.check(rc, "lambdaloss(count)")
+                ext = sharding.allreduce_sum_(self.cnt)
+            rc = lib.ltrx_lambdaloss_fwd_bwd(L.ptr(yp), L.ptr(yt), B, SL, self.eps, self.pad, _SCHEMES[a.get("weighing_scheme")],
+                                             0 if k is None else int(k), float(a.get("sigma", 1.)), float(a.get("mu", 10.)), red, lg,
+                                             L.ptr(ext), L.ptr(self.loss), None, L.ptr(self.grad), None, L.ptr(self.ws), st)
+        else:
+            tr = n == "neuralNDCG_transposed"
+            pw = bool(a.get("powered_relevancies", True))
+            k = a.get("k")
+            kk = 0 if k is None else int(k)
+            rc = lib.ltrx_neuralndcg_prepare(L.ptr(yt), B, SL, self.pad, kk, 1 if (pw or tr) else 0, L.ptr(self.idcg),
+                                             L.ptr(self.cnt), L.ptr(self.ws), st)
+            L.check(rc, "neuralndcg_prepare")
+            sharding.allreduce_sum_(self.cnt)
+            rc = lib.ltrx_neuralndcg_fwd_bwd(L.ptr(yp), L.ptr(yt), L.ptr(self.idcg), L.ptr(self.cnt), B, SL, self.pad,
+                                             float(a.get("temperature", 1.)), 1 if pw else 0, kk, 1 if tr else 0, self.max_iter,
+                                             float(a.get("tol", 1e-6)), L.ptr(self.loss), None, L.ptr(self.grad), None,
+                                             L.ptr(self.ws), st)
+        L.check(rc, n)
+        return self.loss, self.grad

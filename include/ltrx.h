@@ -148,6 +148,34 @@ int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* 
                  const float* dout, const float* lse, int B, int L, int h, int d_k, int row_stride, int o_row_stride,
                  float* dq, float* dk, float* dv, int d_row_stride, void* ws, ltrx_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training-step glue (allrank/training/train_utils.py:18-29 around the model): the pieces between the library
+ * GEMMs that the explicit, graph-capturable step of allrank_amd/engine.py needs.
+ * ------------------------------------------------------------------------------------------- */
+
+/* torch.optim.Adam.step (allrank/main.py:82, Adam in every shipped config) over one flat fp32 buffer of n elements;
+ * step_count[1] (device, float) is incremented first and used for the bias corrections; grads are multiplied by
+ * grad_scale on the fly (1.0 normally). */
+int ltrx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                   float beta2, float eps, float* step_count, float grad_scale, ltrx_stream_t stream);
+
+/* nn.Linear bias gradient: out[n] (+)= sum_m a[m*ld + n] for a row-major [M,N] matrix; deterministic two-stage. */
+size_t ltrx_colsum_workspace_bytes(int M, int N);
+int ltrx_colsum(const float* a, int M, int N, int ld, float* out, int accumulate, void* ws, ltrx_stream_t stream);
+
+/* ReLU backward in place (transformer.py:227, FCModel activation): dr[i] = r[i] > 0 ? dr[i] : 0; n % 4 == 0. */
+int ltrx_relu_bwd(float* dr_inout, const float* r_post_act, size_t n, ltrx_stream_t stream);
+
+/* y = act(y + bias) in place over a contiguous [M,N] matrix (model.py:42-43); act 0 = identity, 1 = ReLU; N % 4 == 0. */
+int ltrx_bias_act(float* y_inout, const float* bias, int M, int N, int act, ltrx_stream_t stream);
+
+/* OutputLayer with d_output == 1 (model.py:111-117): scores[m] = <x[m,:], w> + b, and its backward
+ * (dx[m,:] = dscores[m] * w; dw = sum_m dscores[m] x[m,:]; db = sum_m dscores[m]). */
+int ltrx_score_head_fwd(const float* x, const float* w, const float* b, int M, int D, float* scores, ltrx_stream_t stream);
+size_t ltrx_score_head_bwd_workspace_bytes(int M, int D);
+int ltrx_score_head_bwd(const float* dscores, const float* x, const float* w, int M, int D, float* dx, float* dw,
+                        float* db, void* ws, ltrx_stream_t stream);
+
 /* Test hook: D[32x32] = A[32x2] * B[2x32] with ONE v_mfma_f32_32x32x2_f32, written through the operand / result
  * lane layout the attention kernels assume.  Lets the parity suite tell a layout bug from a logic bug. */
 int ltrx_selftest_mfma32x32x2(const float* A, const float* B, float* D, ltrx_stream_t stream);

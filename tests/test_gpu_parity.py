@@ -332,3 +332,62 @@ def test_model_config3_matches_oracle():
     gerr = max(float(np.abs(p.grad.cpu().numpy() - grads[n]).max()) for n, p in model.named_parameters())
     _log("model_cfg3", dict(score_err=serr, loss=float(loss.item()), oracle_loss=float(lo), grad_err=gerr, grad_scale=scale))
     assert serr < 5e-5 and close(loss.item(), lo) and gerr <= 5e-4 * scale
+
+
+@pytest.mark.parametrize("loss_name,loss_args", [("approxNDCGLoss", {}), ("listNet", {}),
+                                                  ("lambdaLoss", dict(weighing_scheme="lambdaRank_scheme", k=10)),
+                                                  ("neuralNDCG", dict(temperature=1.0))])
+def test_fused_trainer_matches_oracle_and_autograd_path(loss_name, loss_args):
+    """the explicit (hipGraph-captured) training step == the autograd path == the numpy oracle, step after step."""
+    import copy
+    from allrank_amd import losses as E
+    from allrank_amd.engine import FusedTrainer, Trainer
+    cfg = dict(n_features=20, fc_sizes=[32], fc_activation=None, fc_input_norm=False, N=2, d_ff=64, h=4, output_activation=None)
+    params = M.init_params(cfg, seed=11)
+    m1 = _make_engine_model(cfg, params)
+    m2 = copy.deepcopy(m1)
+    rng = np.random.default_rng(12)
+    B, L = 4, 70
+    x = rng.standard_normal((B, L, 20)).astype(np.float32)
+    y = rng.integers(0, 5, (B, L)).astype(np.float32)
+    y[2, 40:] = -1
+    x[2, 40:] = 0
+    xt, yt = _t(x), _t(y)
+    ft = FusedTrainer(m1, loss_name, loss_args, B, L, lr=1e-3, use_graph=True)
+    lossfn = (lambda s, t: getattr(E, loss_name)(s, t, **loss_args))
+    tr = Trainer(m2, lossfn, torch.optim.Adam(m2.parameters(), lr=1e-3))
+    ofn = {"approxNDCGLoss": lambda s, t: O.approxndcg(s, t), "listNet": lambda s, t: O.listnet(s, t),
+           "lambdaLoss": lambda s, t: O.lambdaloss(s, t, **loss_args), "neuralNDCG": lambda s, t: O.neuralndcg(s, t, **loss_args)}[loss_name]
+    oopt = M.Adam(params, lr=1e-3)
+    rows = []
+    for step in range(5):                       # steps 0,1 eager warm-up, step 2 captures + replays, 3,4 replay
+        lf = float(ft.step(xt, yt).item())
+        la = float(tr.step(xt, yt).item())
+        lo = float(M.train_step(params, cfg, oopt, x, y, ofn)[0])
+        rows.append((lf, la, lo))
+        tol = 1e-5 if step == 0 else 2e-3       # after the first Adam step round-off of ~0 gradients is amplified to +-lr
+        assert abs(lf - la) <= tol * (1 + abs(la)) and abs(lf - lo) <= tol * (1 + abs(lo)), rows
+    _log("fused_trainer_" + loss_name, rows)
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:                               # weights live in the flat buffer but are visible through the module
+        assert (sd1[k] - sd2[k]).abs().max().item() < 5e-3, k
+    with torch.no_grad():
+        s1 = m1.score(xt, yt == -1, None)
+    assert torch.isfinite(s1).all()
+
+
+def test_fused_trainer_fc_only_relu():
+    from allrank_amd.engine import FusedTrainer
+    cfg = dict(n_features=20, fc_sizes=[24, 16], fc_activation="ReLU", fc_input_norm=False, N=0, d_ff=0, h=1, output_activation=None)
+    params = M.init_params(cfg, seed=3)
+    m1 = _make_engine_model(cfg, params)
+    rng = np.random.default_rng(4)
+    B, L = 8, 24
+    x = rng.standard_normal((B, L, 20)).astype(np.float32)
+    y = rng.integers(0, 5, (B, L)).astype(np.float32)
+    ft = FusedTrainer(m1, "listNet", {}, B, L, lr=1e-3, use_graph=False)
+    oopt = M.Adam(params, lr=1e-3)
+    for step in range(2):
+        lf = float(ft.step(_t(x), _t(y)).item())
+        lo = float(M.train_step(params, cfg, oopt, x, y, lambda s, t: O.listnet(s, t))[0])
+        assert abs(lf - lo) <= (1e-5 if step == 0 else 1e-3) * (1 + abs(lo)), (step, lf, lo)
