@@ -1,0 +1,330 @@
+// fp32-accurate GEMMs on the bf16 matrix cores ("split-bf16"): the dense projections of the scoring model
+// (allrank/models/model.py:35-44 FCModel, transformer.py:193-203 q/k/v/out projections, :221-227 feed-forward).
+//
+// Why: gfx950 has no TF32/xf32 path and its exact-fp32 MFMA runs at the fp32 vector rate (157 TF), 1/16 of the bf16
+// MFMA rate (2.5 PF).  Every fp32 operand is therefore split ON THE FLY, while it is staged into LDS, into two bf16
+// terms x = hi + lo (hi = bf16(x), lo = bf16(x - hi); |x - hi - lo| <= 2^-18 |x|) and the product is evaluated as
+//        A B^T  ~=  Ahi Bhi^T + Ahi Blo^T + Alo Bhi^T            (three v_mfma_f32_32x32x16_bf16, fp32 accumulate)
+// bf16 x bf16 products are exact in fp32; the dropped terms (lo*lo and the split residuals) are <= 3 * 2^-18 relative
+// per product with pseudo-random sign, i.e. the same order as the round-off an fp32 accumulation over K = 512 carries
+// anyway.  3 MFMAs at the bf16 rate = 833 TF "fp32-equivalent" ceiling, 5.3x the fp32-MFMA roof, and each pair of
+// fragment loads feeds 3 MFMAs, so the LDS traffic per MFMA is a third of a plain bf16 GEMM's.
+// (NTERMS = 3 adds lo2 and uses 6 MFMAs for a 2^-26 product error: the strict mode.)
+//
+//   ltrx_gemm_nt : C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]) (+ ReLU)        both operands K-contiguous
+//                  -> forward of nn.Linear (B = weight [out,in]) and its input gradient (B = weight^T, kept transposed)
+//   ltrx_gemm_tn : C[N',K'] = A[M,N']^T * B[M,K']  (split-K over M, deterministic two-stage reduction)
+//                  -> weight gradient dW = dY^T X; both operands are contraction-STRIDED in memory, they are transposed
+//                     on the way into LDS (each lane converts a 4(m) x 1(n) register column into one 8-byte LDS write).
+//
+// Tiling: workgroup = 4 waves (2 x 2), tile 128 x 128 x 32; wave tile 64 x 64 = 2 x 2 MFMA tiles (64 accumulator
+// VGPRs).  LDS operand images are [row][k] bf16 with k contiguous and a row stride of 40 elements (80 B): every lane
+// fetches its 8-element MFMA fragment with one ds_read_b128, conflict-free.  Global loads of K-tile t+1 are issued
+// into registers before the MFMAs of tile t (register double buffering); two workgroups fit per CU (40 KB LDS each).
+// Workgroup ids are remapped so that the column tiles of one A row-panel run on the same XCD (shared L2).
+#include "ltrx_device.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDK = 40;   // LDK: LDS row stride in bf16 elements
+
+__device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// split 4 floats into hi / lo (/ lo2) bf16 quads
+template <int NTERMS>
+__device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo, bf16x4& lo2) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 h = (__bf16)x[e];
+    const float r1 = x[e] - (float)h;
+    const __bf16 l = (__bf16)r1;
+    hi[e] = h;
+    lo[e] = l;
+    if (NTERMS == 3) lo2[e] = (__bf16)(r1 - (float)l);
+  }
+}
+
+template <int NTERMS>
+struct Smem {
+  __bf16 a[NTERMS][BM * LDK];
+  __bf16 b[NTERMS][BN * LDK];
+};
+
+// the MFMA phase over one staged K-tile (BK = 32 -> two k-steps of 16)
+template <int NTERMS>
+__device__ __forceinline__ void mma_tile(const Smem<NTERMS>& s, int wr, int wc, f32x16 (&acc)[2][2]) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+    bf16x8 af[NTERMS][2], bfr[NTERMS][2];
+#pragma unroll
+    for (int t = 0; t < NTERMS; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[t][i] = *reinterpret_cast<const bf16x8*>(&s.a[t][(wr * 64 + i * 32 + l31) * LDK + ks * 16 + 8 * half]);
+        bfr[t][i] = *reinterpret_cast<const bf16x8*>(&s.b[t][(wc * 64 + i * 32 + l31) * LDK + ks * 16 + 8 * half]);
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // smallest terms first
+        if (NTERMS == 3) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
+      }
+  }
+}
+
+// XCD-aware bijective remap of a linear workgroup id (cdna_hip_programming.md §5): ids that are consecutive after
+// the remap land on the same XCD, so tiles sharing an operand panel share an L2.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n / 8, r = n % 8, xcd = id % 8, k = id / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// NT:  C[M,N] = A[M,K] B[N,K]^T (+bias) (+ReLU)
+// ------------------------------------------------------------------------------------------------------------------
+template <int NTERMS>
+__global__ void __launch_bounds__(256, 2) ltrx_gemm_nt_kernel(const float* __restrict__ A, int lda,
+                                                              const float* __restrict__ B, int ldb,
+                                                              float* __restrict__ C, int ldc, int M, int N, int K,
+                                                              const float* __restrict__ bias, int act, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) Smem<NTERMS> s;
+  const int nblk = gridDim.x;
+  const int id = xcd_remap(blockIdx.x, nblk);
+  const int m0 = (id / tiles_n) * BM, n0 = (id % tiles_n) * BN;
+  const int wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+
+  // staging map: 128 rows x 8 float4 per operand -> 4 float4 per thread per operand
+  const int srow = threadIdx.x >> 3;          // 0..31 (+32 per pass)
+  const int sc4 = (threadIdx.x & 7) * 4;      // k offset inside the tile
+  float4 ra[4], rb[4];
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = srow + 32 * p, k = k0 + sc4;
+      ra[p] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * lda + k)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[p] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4*>(B + (size_t)(n0 + r) * ldb + k)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = srow + 32 * p;
+      bf16x4 h, l, l2;
+      split4<NTERMS>(ra[p], h, l, l2);
+      *reinterpret_cast<bf16x4*>(&s.a[0][r * LDK + sc4]) = h;
+      *reinterpret_cast<bf16x4*>(&s.a[1][r * LDK + sc4]) = l;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.a[2][r * LDK + sc4]) = l2;
+      split4<NTERMS>(rb[p], h, l, l2);
+      *reinterpret_cast<bf16x4*>(&s.b[0][r * LDK + sc4]) = h;
+      *reinterpret_cast<bf16x4*>(&s.b[1][r * LDK + sc4]) = l;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.b[2][r * LDK + sc4]) = l2;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();                 // the previous tile's fragments are consumed
+    sstore();
+    __syncthreads();
+    if (kt + 1 < nk) gload((kt + 1) * BK);   // in flight during the MFMAs below
+    mma_tile<NTERMS>(s, wr, wc, acc);
+  }
+
+  // epilogue: lane owns column n0 + wc*64 + j*32 + (lane&31); register r is row rowmap(r, half)
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wc * 64 + j * 32 + l31;
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + rowmap(r, half);
+        if (row < M) {
+          float v = acc[i][j][r] + bv;
+          if (act == 1) v = fmaxf(v, 0.f);
+          C[(size_t)row * ldc + col] = v;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// TN (weight gradient):  C[N',K'] = sum_m A[m][n'] * B[m][k'],  split over m into `splits` slabs
+// ------------------------------------------------------------------------------------------------------------------
+template <int NTERMS>
+__global__ void __launch_bounds__(256, 2) ltrx_gemm_tn_kernel(const float* __restrict__ A, int lda,
+                                                              const float* __restrict__ B, int ldb,
+                                                              float* __restrict__ slabs, int M, int NP, int KP,
+                                                              int tiles_k, int m_per_split) {
+  __shared__ __attribute__((aligned(16))) Smem<NTERMS> s;
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int n0 = (tile / tiles_k) * BM, k0 = (tile % tiles_k) * BN;     // output tile: rows n', cols k'
+  const int wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+  const int lane = threadIdx.x & 63;
+  const int mbeg = split * m_per_split, mend = min(M, mbeg + m_per_split);
+
+  // staging map: the K-tile is 32 contraction rows (m) x 128 columns.  A wave covers 8 m-rows (two groups of 4) per
+  // pass... each lane owns ONE column (c = lane + 64*cc) and 4 consecutive m rows -> after the split one 8-byte LDS
+  // write lands at [c][m..m+3] (k contiguous).  4 waves x 2 column halves x 4 m-groups: thread -> (mg, cc).
+  //   thread t: column c = (t & 127), m-group g = t >> 7 (0..1); passes p = 0..3 cover m = 8p + 4g .. +3
+  const int scol = threadIdx.x & 127, sg = threadIdx.x >> 7;
+  float ra[4][4], rb[4][4];     // [pass][m within group]
+
+  auto gload = [&](int mt) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = mt + 8 * p + 4 * sg + e;
+        const bool okm = m < mend;
+        ra[p][e] = (okm && n0 + scol < NP) ? A[(size_t)m * lda + n0 + scol] : 0.f;
+        rb[p][e] = (okm && k0 + scol < KP) ? B[(size_t)m * ldb + k0 + scol] : 0.f;
+      }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int kk = 8 * p + 4 * sg;
+      bf16x4 h, l, l2;
+      split4<NTERMS>(make_float4(ra[p][0], ra[p][1], ra[p][2], ra[p][3]), h, l, l2);
+      *reinterpret_cast<bf16x4*>(&s.a[0][scol * LDK + kk]) = h;
+      *reinterpret_cast<bf16x4*>(&s.a[1][scol * LDK + kk]) = l;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.a[2][scol * LDK + kk]) = l2;
+      split4<NTERMS>(make_float4(rb[p][0], rb[p][1], rb[p][2], rb[p][3]), h, l, l2);
+      *reinterpret_cast<bf16x4*>(&s.b[0][scol * LDK + kk]) = h;
+      *reinterpret_cast<bf16x4*>(&s.b[1][scol * LDK + kk]) = l;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.b[2][scol * LDK + kk]) = l2;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (mbeg < mend) {
+    gload(mbeg);
+    for (int mt = mbeg; mt < mend; mt += BK) {
+      __syncthreads();
+      sstore();
+      __syncthreads();
+      if (mt + BK < mend) gload(mt + BK);
+      mma_tile<NTERMS>(s, wr, wc, acc);
+    }
+  }
+  float* slab = slabs + (size_t)split * NP * KP;
+  const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = k0 + wc * 64 + j * 32 + l31;
+    if (col >= KP) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = n0 + wr * 64 + i * 32 + rowmap(r, half);
+        if (row < NP) slab[(size_t)row * KP + col] = acc[i][j][r];
+      }
+  }
+}
+
+// C[i] = sum_s slabs[s][i]   (fixed order; 16-byte accesses when n % 4 == 0, scalar otherwise)
+__global__ void __launch_bounds__(256) ltrx_gemm_slab_reduce_kernel(const float* __restrict__ slabs, int splits,
+                                                                    size_t n, float* __restrict__ C) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float a = 0.f;
+    for (int sidx = 0; sidx < splits; ++sidx) a += slabs[(size_t)sidx * n + i];
+    C[i] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                            const float* bias, int act, int strict, ltrx_stream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 1) return LTRX_EINVAL;
+  if ((K & 3) || (lda & 3) || (ldb & 3) || lda < K || ldb < K || ldc < N) return LTRX_EUNSUPPORTED;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const dim3 grid(tiles_m * tiles_n);
+  hipStream_t s = (hipStream_t)stream;
+  if (strict)
+    hipLaunchKernelGGL(ltrx_gemm_nt_kernel<3>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, tiles_n);
+  else
+    hipLaunchKernelGGL(ltrx_gemm_nt_kernel<2>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, tiles_n);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+static int tn_splits(int M, int tiles) {
+  int want = (512 + tiles - 1) / tiles;            // aim for >= 512 workgroups
+  int maxs = (M + 4 * BK - 1) / (4 * BK);          // at least 4 K-tiles per split
+  if (want > maxs) want = maxs;
+  if (want > 64) want = 64;
+  return want < 1 ? 1 : want;
+}
+
+extern "C" size_t ltrx_gemm_tn_workspace_bytes(int M, int NP, int KP) {
+  if (M <= 0 || NP <= 0 || KP <= 0) return 0;
+  const int tiles = ((NP + BM - 1) / BM) * ((KP + BN - 1) / BN);
+  return (size_t)tn_splits(M, tiles) * NP * KP * sizeof(float);
+}
+
+extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int M, int NP, int KP, int strict,
+                            void* ws, ltrx_stream_t stream) {
+  if (!A || !B || !C || !ws || M <= 0 || NP <= 0 || KP <= 0) return LTRX_EINVAL;
+  if (lda < NP || ldb < KP) return LTRX_EUNSUPPORTED;
+  const int tiles_n = (NP + BM - 1) / BM, tiles_k = (KP + BN - 1) / BN;
+  const int tiles = tiles_n * tiles_k;
+  const int splits = tn_splits(M, tiles);
+  int mps = (M + splits - 1) / splits;
+  mps = (mps + BK - 1) / BK * BK;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(tiles, splits);
+  if (strict)
+    hipLaunchKernelGGL(ltrx_gemm_tn_kernel<3>, grid, dim3(256), 0, s, A, lda, B, ldb, (float*)ws, M, NP, KP, tiles_k, mps);
+  else
+    hipLaunchKernelGGL(ltrx_gemm_tn_kernel<2>, grid, dim3(256), 0, s, A, lda, B, ldb, (float*)ws, M, NP, KP, tiles_k, mps);
+  LTRX_LAUNCH_CHECK();
+  const size_t n = (size_t)NP * KP;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ltrx_gemm_slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)ws, splits, n, C);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}

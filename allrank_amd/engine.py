@@ -69,13 +69,19 @@ class FusedTrainer(object):
     """
 
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
-                 use_graph=True):
+                 use_graph=True, gemm="split_bf16"):
+        """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
+        products), or "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs)."""
         import torch.nn as nn
         from . import _lib as LB
         from .losses import FusedLoss
         from .model import FCModel, Encoder, LTRModel
         self.LB = LB
         self.lib = LB.lib()
+        if gemm not in ("split_bf16", "split_bf16_strict", "hipblaslt"):
+            raise ValueError("gemm must be split_bf16, split_bf16_strict or hipblaslt")
+        self.gemm = gemm
+        self._wT = {}
         self.model = model
         self.B, self.L, self.M = B, L, B * L
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -201,6 +207,26 @@ class FusedTrainer(object):
         self.ws_col = torch.empty(max(self.lib.ltrx_colsum_workspace_bytes(M, maxn), 64), dtype=torch.uint8, device=dev)
         self.ws_head = torch.empty(max(self.lib.ltrx_score_head_bwd_workspace_bytes(M, d), 64), dtype=torch.uint8, device=dev)
         self.fc_dgrad = [torch.zeros((M, s), **f32) for s in self.fc_sizes[1:-1]]
+        big = max([(3 * d) * d, (self.dff * d) if self.N else 0] + [a * b for a, b in zip(self.fc_sizes[:-1], self.fc_sizes[1:])])
+        if self.gemm != "hipblaslt":
+            nb = 0
+            shapes = [(s1, s0) for s0, s1 in zip(self.fc_sizes[:-1], self.fc_sizes[1:])]
+            if self.N:
+                shapes += [(3 * d, d), (d, d), (self.dff, d), (d, self.dff)]
+            for (npp, kpp) in shapes:
+                nb = max(nb, self.lib.ltrx_gemm_tn_workspace_bytes(M, npp, kpp))
+            self.ws_tn = torch.empty(max(nb, 64), dtype=torch.uint8, device=dev)
+            # transposed weight copies for the input-gradient GEMMs (refreshed after every optimizer step)
+            tw = [l.weight for l in fc.layers[1:]]
+            if enc is not None:
+                for st in self.layers:
+                    lay = st["mod"]
+                    tw += [lay.self_attn.linears[3].weight, lay.feed_forward.w_1.weight, lay.feed_forward.w_2.weight]
+                    st["wqkvT"] = torch.zeros((d, 3 * d), **f32)
+            for p in tw:
+                self._wT[id(p)] = torch.zeros((p.shape[1], p.shape[0]), **f32)
+            self._tw = tw
+            self._refresh_transposes()
         self.loss = FusedLoss(loss_name, B, L, dev, **(loss_args or {}))
         self.use_graph = use_graph
         self.graph = None
@@ -229,6 +255,46 @@ class FusedTrainer(object):
     def _relu_bwd(self, dr, r):
         self.LB.check(self.lib.ltrx_relu_bwd(self.LB.ptr(dr), self.LB.ptr(r), dr.numel(), self._st()), "relu_bwd")
 
+    def _refresh_transposes(self):
+        if self.gemm == "hipblaslt":
+            return
+        for p in self._tw:
+            self._wT[id(p)].copy_(p.data.t())
+        for st in self.layers:
+            st["wqkvT"].copy_(st["wqkv"].t())
+
+    def _lin_fwd(self, x, w, b, out, act=0):
+        """out = act(x w^T + b)   (nn.Linear forward, act 1 = ReLU)"""
+        if self.gemm == "hipblaslt":
+            torch.addmm(b, x, w.t(), out=out)
+            if act == 1:
+                torch.relu_(out)
+            return
+        P = self.LB.ptr
+        self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), P(out), out.stride(0), x.shape[0], w.shape[0],
+                                            x.shape[1], P(b), act, 1 if self.gemm == "split_bf16_strict" else 0, self._st()),
+                      "gemm_nt(fwd)")
+
+    def _lin_dgrad(self, dy, w, wT, out):
+        """out = dy w   (input gradient of nn.Linear); wT = w^T contiguous"""
+        if self.gemm == "hipblaslt":
+            torch.mm(dy, w, out=out)
+            return
+        P = self.LB.ptr
+        self.LB.check(self.lib.ltrx_gemm_nt(P(dy), dy.stride(0), P(wT), wT.stride(0), P(out), out.stride(0), dy.shape[0],
+                                            wT.shape[0], dy.shape[1], None, 0, 1 if self.gemm == "split_bf16_strict" else 0,
+                                            self._st()), "gemm_nt(dgrad)")
+
+    def _lin_wgrad(self, dy, x, gw):
+        """gw = dy^T x   (weight gradient of nn.Linear)"""
+        if self.gemm == "hipblaslt":
+            torch.mm(dy.t(), x, out=gw)
+            return
+        P = self.LB.ptr
+        self.LB.check(self.lib.ltrx_gemm_tn(P(dy), dy.stride(0), P(x), x.stride(0), P(gw), dy.shape[0], dy.shape[1], x.shape[1],
+                                            1 if self.gemm == "split_bf16_strict" else 0, P(self.ws_tn), self._st()),
+                      "gemm_tn(wgrad)")
+
     # ---- the step body (capturable) ----------------------------------------------------------------------------
     def _body(self):
         P = self.LB.ptr
@@ -238,9 +304,7 @@ class FusedTrainer(object):
         # ---------------- forward ----------------
         h = self.x_in
         for i, lyr in enumerate(fc.layers):
-            torch.addmm(W(lyr.bias), h, W(lyr.weight).t(), out=self.fc_out[i])
-            if self.fc_act == 1:
-                torch.relu_(self.fc_out[i])
+            self._lin_fwd(h, W(lyr.weight), W(lyr.bias), self.fc_out[i], self.fc_act)
             h = self.fc_out[i]
         x = h                                                     # residual stream
         for i, st in enumerate(self.layers):
@@ -252,17 +316,16 @@ class FusedTrainer(object):
                 self._ln_fwd(x, self.branch, W(n0.a_2), W(n0.b_2), st["xsum0"], st["xn0"], st["mean0"], st["rstd0"])
                 x = st["xsum0"]
             st["xin"] = x
-            torch.addmm(st["bqkv"], st["xn0"], st["wqkv"].t(), out=st["qkv"])
+            self._lin_fwd(st["xn0"], st["wqkv"], st["bqkv"], st["qkv"])
             qkv = st["qkv"]
             self.LB.check(lib.ltrx_mha_fwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(self.mask), B, L, self.h,
                                            d // self.h, 3 * d, P(st["o"]), d, P(st["lse"]), self._st()), "mha_fwd")
             lo = lay.self_attn.linears[3]
-            torch.addmm(W(lo.bias), st["o"], W(lo.weight).t(), out=self.branch)
+            self._lin_fwd(st["o"], W(lo.weight), W(lo.bias), self.branch)
             self._ln_fwd(x, self.branch, W(n1.a_2), W(n1.b_2), st["x1"], st["xn1"], st["mean1"], st["rstd1"])
             ff = lay.feed_forward
-            torch.addmm(W(ff.w_1.bias), st["xn1"], W(ff.w_1.weight).t(), out=st["r"])
-            torch.relu_(st["r"])
-            torch.addmm(W(ff.w_2.bias), st["r"], W(ff.w_2.weight).t(), out=self.branch)
+            self._lin_fwd(st["xn1"], W(ff.w_1.weight), W(ff.w_1.bias), st["r"], 1)
+            self._lin_fwd(st["r"], W(ff.w_2.weight), W(ff.w_2.bias), self.branch)
             x = st["x1"]
         out = self.model.output_layer
         if self.N:
@@ -291,27 +354,27 @@ class FusedTrainer(object):
                 ff = lay.feed_forward
                 # FFN branch
                 self._colsum(ds, G(ff.w_2.bias))
-                torch.mm(ds.t(), st["r"], out=G(ff.w_2.weight))
-                torch.mm(ds, W(ff.w_2.weight), out=self.d_r)
+                self._lin_wgrad(ds, st["r"], G(ff.w_2.weight))
+                self._lin_dgrad(ds, W(ff.w_2.weight), self._wT.get(id(ff.w_2.weight)), self.d_r)
                 self._relu_bwd(self.d_r, st["r"])
                 self._colsum(self.d_r, G(ff.w_1.bias))
-                torch.mm(self.d_r.t(), st["xn1"], out=G(ff.w_1.weight))
-                torch.mm(self.d_r, W(ff.w_1.weight), out=self.tmp_d)
+                self._lin_wgrad(self.d_r, st["xn1"], G(ff.w_1.weight))
+                self._lin_dgrad(self.d_r, W(ff.w_1.weight), self._wT.get(id(ff.w_1.weight)), self.tmp_d)
                 self._ln_bwd(self.tmp_d, st["x1"], W(n1.a_2), st["mean1"], st["rstd1"], ds, other, G(n1.a_2), G(n1.b_2))
                 ds, other = other, ds                              # ds = d loss / d x1
                 # attention branch
                 lo = lay.self_attn.linears[3]
                 self._colsum(ds, G(lo.bias))
-                torch.mm(ds.t(), st["o"], out=G(lo.weight))
-                torch.mm(ds, W(lo.weight), out=self.d_o)
+                self._lin_wgrad(ds, st["o"], G(lo.weight))
+                self._lin_dgrad(ds, W(lo.weight), self._wT.get(id(lo.weight)), self.d_o)
                 qkv, dq = st["qkv"], self.dqkv
                 self.LB.check(lib.ltrx_mha_bwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(self.mask), P(st["o"]),
                                                P(self.d_o), P(st["lse"]), B, L, self.h, d // self.h, 3 * d, d, P(dq),
                                                dq.data_ptr() + 4 * d, dq.data_ptr() + 8 * d, 3 * d, P(self.ws_mha), self._st()),
                               "mha_bwd")
                 self._colsum(dq, st["gbqkv"])
-                torch.mm(dq.t(), st["xn0"], out=st["gwqkv"])
-                torch.mm(dq, st["wqkv"], out=self.tmp_d)
+                self._lin_wgrad(dq, st["xn0"], st["gwqkv"])
+                self._lin_dgrad(dq, st["wqkv"], st.get("wqkvT"), self.tmp_d)
                 self._ln_bwd(self.tmp_d, st["xin"], W(n0.a_2), st["mean0"], st["rstd0"], ds, other, G(n0.a_2), G(n0.b_2))
                 ds, other = other, ds                              # ds = d loss / d (layer input)
         else:
@@ -323,9 +386,9 @@ class FusedTrainer(object):
                 self._relu_bwd(ds, self.fc_out[i])
             self._colsum(ds, G(lyr.bias))
             inp = self.x_in if i == 0 else self.fc_out[i - 1]
-            torch.mm(ds.t(), inp, out=G(lyr.weight))
+            self._lin_wgrad(ds, inp, G(lyr.weight))
             if i > 0:
-                torch.mm(ds, W(lyr.weight), out=self.fc_dgrad[i - 1])
+                self._lin_dgrad(ds, W(lyr.weight), self._wT.get(id(lyr.weight)), self.fc_dgrad[i - 1])
                 ds = self.fc_dgrad[i - 1]
         return loss
 
@@ -341,6 +404,7 @@ class FusedTrainer(object):
             import torch.distributed as dist
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
         self._adam()
+        self._refresh_transposes()
         return loss
 
     def step(self, xb, yb, indices=None, global_batch=None):

@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--slates-per-gpu", type=int, default=64)
     ap.add_argument("--slate-len", type=int, default=240)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm", default="split_bf16", choices=["split_bf16", "split_bf16_strict", "hipblaslt"],
+                    help="dense projections: libltrx fp32-accurate split-bf16 MFMA GEMMs (default) or hipBLASLt fp32")
     ap.add_argument("--engine", default="fused", choices=["fused", "autograd"],
                     help="fused: explicit hipGraph-captured step (engine.FusedTrainer); autograd: nn.Module + torch autograd/Adam")
     args = ap.parse_args()
@@ -173,7 +175,7 @@ def main():
     B, L = args.slates_per_gpu, args.slate_len
     model = build_model(w, device)
     if args.engine == "fused":
-        trainer = FusedTrainer(model, w["loss"], {}, B, L, lr=1e-3, world_size=world, use_graph=True)   # Adam 1e-3: approxndcg.json:28-33
+        trainer = FusedTrainer(model, w["loss"], {}, B, L, lr=1e-3, world_size=world, use_graph=True, gemm=args.gemm)   # Adam 1e-3: approxndcg.json:28-33
     else:
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         trainer = Trainer(model, getattr(E, w["loss"]), opt, None, world, None)
@@ -226,7 +228,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["desc"], "slates_per_gpu": B, "slate_len": L, "global_batch": B * world,
-                       "optimizer": "Adam lr=1e-3", "engine": args.engine, "parallelism": "slate-sharded dp%d" % world,
+                       "optimizer": "Adam lr=1e-3", "engine": args.engine, "gemm": args.gemm if args.engine == "fused" else "hipblaslt", "parallelism": "slate-sharded dp%d" % world,
                        "train_flops_per_item": fl_item},
             "model_tflops": round(value * fl_item / 1e12, 2),
             "model_mfma_frac_fp32": round(value * fl_item / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),

@@ -334,10 +334,11 @@ def test_model_config3_matches_oracle():
     assert serr < 5e-5 and close(loss.item(), lo) and gerr <= 5e-4 * scale
 
 
+@pytest.mark.parametrize("gemm", ["split_bf16", "hipblaslt", "split_bf16_strict"])
 @pytest.mark.parametrize("loss_name,loss_args", [("approxNDCGLoss", {}), ("listNet", {}),
                                                   ("lambdaLoss", dict(weighing_scheme="lambdaRank_scheme", k=10)),
                                                   ("neuralNDCG", dict(temperature=1.0))])
-def test_fused_trainer_matches_oracle_and_autograd_path(loss_name, loss_args):
+def test_fused_trainer_matches_oracle_and_autograd_path(loss_name, loss_args, gemm):
     """the explicit (hipGraph-captured) training step == the autograd path == the numpy oracle, step after step."""
     import copy
     from allrank_amd import losses as E
@@ -353,7 +354,7 @@ def test_fused_trainer_matches_oracle_and_autograd_path(loss_name, loss_args):
     y[2, 40:] = -1
     x[2, 40:] = 0
     xt, yt = _t(x), _t(y)
-    ft = FusedTrainer(m1, loss_name, loss_args, B, L, lr=1e-3, use_graph=True)
+    ft = FusedTrainer(m1, loss_name, loss_args, B, L, lr=1e-3, use_graph=True, gemm=gemm)
     lossfn = (lambda s, t: getattr(E, loss_name)(s, t, **loss_args))
     tr = Trainer(m2, lossfn, torch.optim.Adam(m2.parameters(), lr=1e-3))
     ofn = {"approxNDCGLoss": lambda s, t: O.approxndcg(s, t), "listNet": lambda s, t: O.listnet(s, t),
@@ -367,10 +368,12 @@ def test_fused_trainer_matches_oracle_and_autograd_path(loss_name, loss_args):
         rows.append((lf, la, lo))
         tol = 1e-5 if step == 0 else 2e-3       # after the first Adam step round-off of ~0 gradients is amplified to +-lr
         assert abs(lf - la) <= tol * (1 + abs(la)) and abs(lf - lo) <= tol * (1 + abs(lo)), rows
-    _log("fused_trainer_" + loss_name, rows)
+    _log("fused_trainer_%s_%s" % (loss_name, gemm), rows)
     sd1, sd2 = m1.state_dict(), m2.state_dict()
     for k in sd1:                               # weights live in the flat buffer but are visible through the module
-        assert (sd1[k] - sd2[k]).abs().max().item() < 5e-3, k
+        # 5 Adam steps move a parameter by at most 5*lr; parameters whose true gradient is 0 (output bias under a
+        # shift-invariant loss, key bias) follow the SIGN of round-off noise, so the two paths may differ by up to 2*5*lr
+        assert (sd1[k] - sd2[k]).abs().max().item() <= 1.01e-2, k
     with torch.no_grad():
         s1 = m1.score(xt, yt == -1, None)
     assert torch.isfinite(s1).all()
@@ -385,9 +388,46 @@ def test_fused_trainer_fc_only_relu():
     B, L = 8, 24
     x = rng.standard_normal((B, L, 20)).astype(np.float32)
     y = rng.integers(0, 5, (B, L)).astype(np.float32)
-    ft = FusedTrainer(m1, "listNet", {}, B, L, lr=1e-3, use_graph=False)
+    ft = FusedTrainer(m1, "listNet", {}, B, L, lr=1e-3, use_graph=False, gemm="split_bf16")
     oopt = M.Adam(params, lr=1e-3)
     for step in range(2):
         lf = float(ft.step(_t(x), _t(y)).item())
         lo = float(M.train_step(params, cfg, oopt, x, y, lambda s, t: O.listnet(s, t))[0])
         assert abs(lf - lo) <= (1e-5 if step == 0 else 1e-3) * (1 + abs(lo)), (step, lf, lo)
+
+
+@pytest.mark.parametrize("strict", [0, 1])
+def test_split_bf16_gemm_matches_fp64(strict):
+    """fp32-accurate GEMMs on the bf16 MFMA: error relative to sum_k |a||b| must be fp32-class
+    (2-term split: <= 3*2^-18 per product worst case; 3-term 'strict': <= 2^-24-ish)."""
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    rng = np.random.default_rng(0)
+    rows = []
+    for (Mm, N, K) in [(300, 200, 136), (1024, 512, 512), (129, 1, 512), (15360, 96, 136)]:
+        A = rng.standard_normal((Mm, K)).astype(np.float32)
+        Bw = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        At, Bt, bt = _t(A), _t(Bw), _t(bias)
+        C = torch.empty((Mm, N), device=DEV)
+        LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, LB.ptr(C), N, Mm, N, K, LB.ptr(bt), 1, strict, None), "gemm_nt")
+        ref = np.maximum(A.astype(np.float64) @ Bw.astype(np.float64).T + bias, 0)
+        scale = (np.abs(A).astype(np.float64) @ np.abs(Bw).astype(np.float64).T).max()
+        err = float(np.abs(C.cpu().numpy() - ref).max() / scale)
+        tref = torch.relu(torch.addmm(bt, At, Bt.t())).cpu().numpy()
+        err_blas = float(np.abs(tref - ref).max() / scale)
+        rows.append(dict(kind="nt", shape=(Mm, N, K), strict=strict, rel_err=err, rel_err_hipblaslt_fp32=err_blas))
+        assert err < (4e-7 if strict else 4e-6), rows[-1]
+    for (Mm, NP, KP) in [(1000, 200, 136), (15360, 512, 136), (4096, 1536, 512), (77, 5, 3)]:
+        A = rng.standard_normal((Mm, NP)).astype(np.float32)
+        Bx = rng.standard_normal((Mm, KP)).astype(np.float32)
+        At, Bt = _t(A), _t(Bx)
+        C = torch.empty((NP, KP), device=DEV)
+        ws = torch.empty(max(lib.ltrx_gemm_tn_workspace_bytes(Mm, NP, KP), 64), dtype=torch.uint8, device=DEV)
+        LB.check(lib.ltrx_gemm_tn(LB.ptr(At), NP, LB.ptr(Bt), KP, LB.ptr(C), Mm, NP, KP, strict, LB.ptr(ws), None), "gemm_tn")
+        ref = A.astype(np.float64).T @ Bx.astype(np.float64)
+        scale = (np.abs(A).astype(np.float64).T @ np.abs(Bx).astype(np.float64)).max()
+        err = float(np.abs(C.cpu().numpy() - ref).max() / scale)
+        rows.append(dict(kind="tn", shape=(Mm, NP, KP), strict=strict, rel_err=err))
+        assert err < (4e-7 if strict else 4e-6), rows[-1]
+    _log("split_gemm_strict%d" % strict, rows)
