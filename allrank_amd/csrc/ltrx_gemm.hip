@@ -102,7 +102,8 @@ template <int NTERMS>
 __global__ void __launch_bounds__(256, 2) ltrx_gemm_nt_kernel(const float* __restrict__ A, int lda,
                                                               const float* __restrict__ B, int ldb,
                                                               float* __restrict__ C, int ldc, int M, int N, int K,
-                                                              const float* __restrict__ bias, int act, int tiles_n) {
+                                                              const float* __restrict__ bias, int act,
+                                                              const float* __restrict__ aux, int ldaux, int tiles_n) {
   __shared__ __attribute__((aligned(16))) Smem<NTERMS> s;
   const int nblk = gridDim.x;
   const int id = xcd_remap(blockIdx.x, nblk);
@@ -173,6 +174,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_gemm_nt_kernel(const float* __res
         if (row < M) {
           float v = acc[i][j][r] + bv;
           if (act == 1) v = fmaxf(v, 0.f);
+          if (act == 2) v = (aux[(size_t)row * ldaux + col] > 0.f) ? v : 0.f;    // ReLU backward fused into the dgrad
           C[(size_t)row * ldc + col] = v;
         }
       }
@@ -185,8 +187,8 @@ __global__ void __launch_bounds__(256, 2) ltrx_gemm_nt_kernel(const float* __res
 template <int NTERMS>
 __global__ void __launch_bounds__(256, 2) ltrx_gemm_tn_kernel(const float* __restrict__ A, int lda,
                                                               const float* __restrict__ B, int ldb,
-                                                              float* __restrict__ slabs, int M, int NP, int KP,
-                                                              int tiles_k, int m_per_split) {
+                                                              float* __restrict__ slabs, float* __restrict__ bias_slabs,
+                                                              int M, int NP, int KP, int tiles_k, int m_per_split) {
   __shared__ __attribute__((aligned(16))) Smem<NTERMS> s;
   const int tile = blockIdx.x, split = blockIdx.y;
   const int n0 = (tile / tiles_k) * BM, k0 = (tile % tiles_k) * BN;     // output tile: rows n', cols k'
@@ -200,6 +202,8 @@ __global__ void __launch_bounds__(256, 2) ltrx_gemm_tn_kernel(const float* __res
   //   thread t: column c = (t & 127), m-group g = t >> 7 (0..1); passes p = 0..3 cover m = 8p + 4g .. +3
   const int scol = threadIdx.x & 127, sg = threadIdx.x >> 7;
   float ra[4][4], rb[4][4];     // [pass][m within group]
+  const bool want_bias = (bias_slabs != nullptr) && (tile % tiles_k == 0);   // column sums of A = the bias gradient
+  float bsum = 0.f;
 
   auto gload = [&](int mt) {
 #pragma unroll
@@ -241,11 +245,16 @@ __global__ void __launch_bounds__(256, 2) ltrx_gemm_tn_kernel(const float* __res
     for (int mt = mbeg; mt < mend; mt += BK) {
       __syncthreads();
       sstore();
+      if (want_bias) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) bsum += (ra[p][0] + ra[p][1]) + (ra[p][2] + ra[p][3]);
+      }
       __syncthreads();
       if (mt + BK < mend) gload(mt + BK);
       mma_tile<NTERMS>(s, wr, wc, acc);
     }
   }
+  if (want_bias && n0 + scol < NP) bias_slabs[((size_t)split * 2 + sg) * NP + n0 + scol] = bsum;
   float* slab = slabs + (size_t)split * NP * KP;
   const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -277,16 +286,17 @@ __global__ void __launch_bounds__(256) ltrx_gemm_slab_reduce_kernel(const float*
 // host side
 // ------------------------------------------------------------------------------------------------------------------
 extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
-                            const float* bias, int act, int strict, ltrx_stream_t stream) {
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 1) return LTRX_EINVAL;
+                            const float* bias, int act, const float* aux, int ldaux, int strict, ltrx_stream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return LTRX_EINVAL;
+  if (act == 2 && (!aux || ldaux < N)) return LTRX_EINVAL;
   if ((K & 3) || (lda & 3) || (ldb & 3) || lda < K || ldb < K || ldc < N) return LTRX_EUNSUPPORTED;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const dim3 grid(tiles_m * tiles_n);
   hipStream_t s = (hipStream_t)stream;
   if (strict)
-    hipLaunchKernelGGL(ltrx_gemm_nt_kernel<3>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, tiles_n);
+    hipLaunchKernelGGL(ltrx_gemm_nt_kernel<3>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, tiles_n);
   else
-    hipLaunchKernelGGL(ltrx_gemm_nt_kernel<2>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, tiles_n);
+    hipLaunchKernelGGL(ltrx_gemm_nt_kernel<2>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, tiles_n);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }
@@ -302,11 +312,12 @@ static int tn_splits(int M, int tiles) {
 extern "C" size_t ltrx_gemm_tn_workspace_bytes(int M, int NP, int KP) {
   if (M <= 0 || NP <= 0 || KP <= 0) return 0;
   const int tiles = ((NP + BM - 1) / BM) * ((KP + BN - 1) / BN);
-  return (size_t)tn_splits(M, tiles) * NP * KP * sizeof(float);
+  const size_t sp = (size_t)tn_splits(M, tiles);
+  return (sp * NP * KP + 2 * sp * NP) * sizeof(float);
 }
 
-extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int M, int NP, int KP, int strict,
-                            void* ws, ltrx_stream_t stream) {
+extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, float* bias_out, int M, int NP,
+                            int KP, int strict, void* ws, ltrx_stream_t stream) {
   if (!A || !B || !C || !ws || M <= 0 || NP <= 0 || KP <= 0) return LTRX_EINVAL;
   if (lda < NP || ldb < KP) return LTRX_EUNSUPPORTED;
   const int tiles_n = (NP + BM - 1) / BM, tiles_k = (KP + BN - 1) / BN;
@@ -316,11 +327,17 @@ extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, fl
   mps = (mps + BK - 1) / BK * BK;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(tiles, splits);
+  float* bslabs = bias_out ? (float*)ws + (size_t)splits * NP * KP : nullptr;
   if (strict)
-    hipLaunchKernelGGL(ltrx_gemm_tn_kernel<3>, grid, dim3(256), 0, s, A, lda, B, ldb, (float*)ws, M, NP, KP, tiles_k, mps);
+    hipLaunchKernelGGL(ltrx_gemm_tn_kernel<3>, grid, dim3(256), 0, s, A, lda, B, ldb, (float*)ws, bslabs, M, NP, KP, tiles_k, mps);
   else
-    hipLaunchKernelGGL(ltrx_gemm_tn_kernel<2>, grid, dim3(256), 0, s, A, lda, B, ldb, (float*)ws, M, NP, KP, tiles_k, mps);
+    hipLaunchKernelGGL(ltrx_gemm_tn_kernel<2>, grid, dim3(256), 0, s, A, lda, B, ldb, (float*)ws, bslabs, M, NP, KP, tiles_k, mps);
   LTRX_LAUNCH_CHECK();
+  if (bias_out) {
+    hipLaunchKernelGGL(ltrx_gemm_slab_reduce_kernel, dim3((NP + 255) / 256), dim3(256), 0, s, (const float*)bslabs, 2 * splits,
+                       (size_t)NP, bias_out);
+    LTRX_LAUNCH_CHECK();
+  }
   const size_t n = (size_t)NP * KP;
   size_t blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;

@@ -115,6 +115,130 @@ __global__ void __launch_bounds__(256) ltrx_layernorm_bwd_kernel(const float* __
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fast path, D = 256 * NV (NV = 1..4): the row lives in registers (NV float4 per lane, 16-byte coalesced accesses),
+// one HBM read per input, statistics from registers; the backward keeps the per-lane column partials of da/db in
+// registers across all rows of the wave and spills them once at the end.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NV>
+__global__ void __launch_bounds__(256) ltrx_layernorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                                     const float* __restrict__ a, const float* __restrict__ b,
+                                                                     int rows, float eps, float* __restrict__ xsum_out,
+                                                                     float* __restrict__ y, float* __restrict__ mean_out,
+                                                                     float* __restrict__ rstd_out) {
+  constexpr int D = 256 * NV;
+  const int lane = lane_id(), wpb = blockDim.x >> 6;
+  float4 av[NV], bv[NV];
+#pragma unroll
+  for (int t = 0; t < NV; ++t) {
+    av[t] = reinterpret_cast<const float4*>(a)[lane + 64 * t];
+    bv[t] = reinterpret_cast<const float4*>(b)[lane + 64 * t];
+  }
+  for (int row = blockIdx.x * wpb + wave_id(); row < rows; row += gridDim.x * wpb) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    float4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      v[t] = xr[lane + 64 * t];
+      if (res) {
+        const float4 r = reinterpret_cast<const float4*>(res + (size_t)row * D)[lane + 64 * t];
+        v[t].x += r.x; v[t].y += r.y; v[t].z += r.z; v[t].w += r.w;
+      }
+      sum += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      const float dx = v[t].x - mean, dy = v[t].y - mean, dz = v[t].z - mean, dw = v[t].w - mean;
+      sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+    const float stdv = sqrtf(wave_sum(sq) / (float)(D - 1));
+    const float r = 1.0f / (stdv + eps);
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      if (xsum_out) reinterpret_cast<float4*>(xsum_out + (size_t)row * D)[lane + 64 * t] = v[t];
+      float4 o;
+      o.x = av[t].x * ((v[t].x - mean) * r) + bv[t].x;
+      o.y = av[t].y * ((v[t].y - mean) * r) + bv[t].y;
+      o.z = av[t].z * ((v[t].z - mean) * r) + bv[t].z;
+      o.w = av[t].w * ((v[t].w - mean) * r) + bv[t].w;
+      reinterpret_cast<float4*>(y + (size_t)row * D)[lane + 64 * t] = o;
+    }
+    if (lane == 0) {
+      mean_out[row] = mean;
+      rstd_out[row] = r;
+    }
+  }
+}
+
+template <int NV>
+__global__ void __launch_bounds__(256) ltrx_layernorm_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ xsum,
+                                                                     const float* __restrict__ a, const float* __restrict__ mean_in,
+                                                                     const float* __restrict__ rstd_in, const float* __restrict__ dres,
+                                                                     int rows, float eps, float* __restrict__ dx,
+                                                                     float* __restrict__ partial) {
+  constexpr int D = 256 * NV;
+  __shared__ __attribute__((aligned(16))) float lds[4 * 2 * D];
+  const int lane = lane_id(), w = wave_id(), wpb = blockDim.x >> 6;
+  float4 av[NV], da[NV], db[NV];
+#pragma unroll
+  for (int t = 0; t < NV; ++t) {
+    av[t] = reinterpret_cast<const float4*>(a)[lane + 64 * t];
+    da[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int row = blockIdx.x * wpb + w; row < rows; row += gridDim.x * wpb) {
+    const float mean = mean_in[row], r = rstd_in[row];
+    float4 g[NV], xc[NV];
+    float gsum = 0.f, dot = 0.f;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      g[t] = reinterpret_cast<const float4*>(dy + (size_t)row * D)[lane + 64 * t];
+      xc[t] = reinterpret_cast<const float4*>(xsum + (size_t)row * D)[lane + 64 * t];
+      xc[t].x -= mean; xc[t].y -= mean; xc[t].z -= mean; xc[t].w -= mean;
+      // da/db use the raw dy; then g becomes dy * a
+      da[t].x += g[t].x * (xc[t].x * r); da[t].y += g[t].y * (xc[t].y * r);
+      da[t].z += g[t].z * (xc[t].z * r); da[t].w += g[t].w * (xc[t].w * r);
+      db[t].x += g[t].x; db[t].y += g[t].y; db[t].z += g[t].z; db[t].w += g[t].w;
+      g[t].x *= av[t].x; g[t].y *= av[t].y; g[t].z *= av[t].z; g[t].w *= av[t].w;
+      gsum += (g[t].x + g[t].y) + (g[t].z + g[t].w);
+      dot += (g[t].x * xc[t].x + g[t].y * xc[t].y) + (g[t].z * xc[t].z + g[t].w * xc[t].w);
+    }
+    const float gm = wave_sum(gsum) / (float)D;
+    dot = wave_sum(dot);
+    const float stdv = 1.0f / r - eps;
+    const float tc = (stdv > 0.f) ? r * r * dot / ((float)(D - 1) * stdv) : 0.f;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      float4 o;
+      o.x = r * (g[t].x - gm) - tc * xc[t].x;
+      o.y = r * (g[t].y - gm) - tc * xc[t].y;
+      o.z = r * (g[t].z - gm) - tc * xc[t].z;
+      o.w = r * (g[t].w - gm) - tc * xc[t].w;
+      if (dres) {
+        const float4 d = reinterpret_cast<const float4*>(dres + (size_t)row * D)[lane + 64 * t];
+        o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
+      }
+      reinterpret_cast<float4*>(dx + (size_t)row * D)[lane + 64 * t] = o;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NV; ++t) {
+    reinterpret_cast<float4*>(lds + (size_t)w * 2 * D)[lane + 64 * t] = da[t];
+    reinterpret_cast<float4*>(lds + (size_t)w * 2 * D + D)[lane + 64 * t] = db[t];
+  }
+  __syncthreads();
+  float* pa = partial + (size_t)blockIdx.x * 2 * D;
+  for (int c = threadIdx.x; c < 2 * D; c += blockDim.x) {
+    float sacc = 0.f;
+    for (int ww = 0; ww < wpb; ++ww) sacc += lds[(size_t)ww * 2 * D + c];
+    pa[c] = sacc;
+  }
+}
+
 // One workgroup per 64 columns; its 4 waves split the partial rows, lanes own consecutive columns (coalesced),
 // the 4 wave partials are combined through LDS in a fixed order (deterministic).
 __global__ void __launch_bounds__(256) ltrx_layernorm_bwd_reduce_kernel(const float* __restrict__ partial, int nblk,
@@ -147,7 +271,14 @@ static int ln_grid(int rows) {
 // the backward keeps per-block column partials: fewer, fatter blocks (each wave walks many rows)
 static int ln_bwd_grid(int rows) {
   int g = (rows + 15) / 16;
-  return g > 256 ? 256 : (g < 1 ? 1 : g);
+  return g > 512 ? 512 : (g < 1 ? 1 : g);
+}
+static int ln_fwd_vec_grid(int rows) {
+  int g = (rows + 7) / 8;
+  return g > 1024 ? 1024 : (g < 1 ? 1 : g);
+}
+static bool ln_vec_ok(int D, const void* p0, const void* p1, const void* p2) {
+  return D % 256 == 0 && D <= 1024 && (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15) == 0;
 }
 
 extern "C" int ltrx_layernorm_fwd(const float* x, const float* res, const float* a, const float* b, int rows, int D,
@@ -155,8 +286,21 @@ extern "C" int ltrx_layernorm_fwd(const float* x, const float* res, const float*
                                   ltrx_stream_t stream) {
   if (!x || !a || !b || !y_out || !mean_out || !rstd_out || rows <= 0 || D < 2) return LTRX_EINVAL;
   if (res && !xsum_out) return LTRX_EINVAL;
-  hipLaunchKernelGGL(ltrx_layernorm_fwd_kernel, dim3(ln_grid(rows)), dim3(256), 0, (hipStream_t)stream, x, res, a, b,
-                     rows, D, eps, xsum_out, y_out, mean_out, rstd_out);
+  hipStream_t s = (hipStream_t)stream;
+  if (ln_vec_ok(D, x, y_out, res) && ln_vec_ok(D, a, b, xsum_out)) {
+    const dim3 g(ln_fwd_vec_grid(rows));
+#define LTRX_LN_FWD(NV) hipLaunchKernelGGL(ltrx_layernorm_fwd_vec_kernel<NV>, g, dim3(256), 0, s, x, res, a, b, rows, eps, xsum_out, y_out, mean_out, rstd_out)
+    switch (D / 256) {
+      case 1: LTRX_LN_FWD(1); break;
+      case 2: LTRX_LN_FWD(2); break;
+      case 3: LTRX_LN_FWD(3); break;
+      default: LTRX_LN_FWD(4); break;
+    }
+#undef LTRX_LN_FWD
+  } else {
+    hipLaunchKernelGGL(ltrx_layernorm_fwd_kernel, dim3(ln_grid(rows)), dim3(256), 0, s, x, res, a, b, rows, D, eps, xsum_out,
+                       y_out, mean_out, rstd_out);
+  }
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }
@@ -173,8 +317,19 @@ extern "C" int ltrx_layernorm_bwd(const float* dy, const float* xsum, const floa
   if ((size_t)4 * 2 * D * sizeof(float) > 64 * 1024) return LTRX_EUNSUPPORTED;   // D <= 2048
   hipStream_t s = (hipStream_t)stream;
   const int grid = ln_bwd_grid(rows);
-  hipLaunchKernelGGL(ltrx_layernorm_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * 2 * D * sizeof(float), s, dy, xsum, a,
-                     mean, rstd, dres_in, rows, D, eps, dx_out, (float*)ws);
+  if (ln_vec_ok(D, dy, xsum, dx_out) && ln_vec_ok(D, a, dres_in, ws)) {
+#define LTRX_LN_BWD(NV) hipLaunchKernelGGL(ltrx_layernorm_bwd_vec_kernel<NV>, dim3(grid), dim3(256), 0, s, dy, xsum, a, mean, rstd, dres_in, rows, eps, dx_out, (float*)ws)
+    switch (D / 256) {
+      case 1: LTRX_LN_BWD(1); break;
+      case 2: LTRX_LN_BWD(2); break;
+      case 3: LTRX_LN_BWD(3); break;
+      default: LTRX_LN_BWD(4); break;
+    }
+#undef LTRX_LN_BWD
+  } else {
+    hipLaunchKernelGGL(ltrx_layernorm_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * 2 * D * sizeof(float), s, dy, xsum, a,
+                       mean, rstd, dres_in, rows, D, eps, dx_out, (float*)ws);
+  }
   LTRX_LAUNCH_CHECK();
   hipLaunchKernelGGL(ltrx_layernorm_bwd_reduce_kernel, dim3((D + 63) / 64), dim3(256), 0, s, (const float*)ws, grid, D,
                      da_out, db_out);

@@ -207,37 +207,14 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// backward: delta[b,h,l] = sum_c dO[b,l,h,c] * O[b,l,h,c]
-// ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) ltrx_mha_delta_kernel(const float* __restrict__ o, const float* __restrict__ dout,
-                                                             int B, int L, int h, int dk, int ors,
-                                                             float* __restrict__ delta) {
-  const size_t n = (size_t)B * L * h;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-    const int head = (int)(idx % h);
-    const size_t bl = idx / h;            // b*L + l
-    const int b = (int)(bl / L), lq = (int)(bl % L);
-    const float* op = o + bl * ors + (size_t)head * dk;
-    const float* dp = dout + bl * ors + (size_t)head * dk;
-    float acc = 0.f;
-    for (int c = 0; c < dk; c += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(op + c);
-      const float4 g = *reinterpret_cast<const float4*>(dp + c);
-      acc += a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
-    }
-    delta[((size_t)b * h + head) * L + lq] = acc;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // backward: dQ   (wave owns 32 queries, streams key tiles)
 // ------------------------------------------------------------------------------------------------------------------
 template <int DKP>
 __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-    const uint8_t* __restrict__ kpm, const float* __restrict__ dout, const float* __restrict__ lse,
-    const float* __restrict__ delta, int L, int h, int dk, int rs, int ors, float* __restrict__ dq, int drs,
-    float scale) {
+    const uint8_t* __restrict__ kpm, const float* __restrict__ o, const float* __restrict__ dout,
+    const float* __restrict__ lse, float* __restrict__ delta, int L, int h, int dk, int rs, int ors,
+    float* __restrict__ dq, int drs, float scale) {
   __shared__ __attribute__((aligned(16))) float ktile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float vtile[Tile<DKP>::FLOATS];
   __shared__ float kmask[32];
@@ -253,7 +230,17 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
   const int qrow = q0 + (lane & 31);
   const size_t stat = ((size_t)b * h + head) * L + qrow;
   const float lse_q = (qrow < L) ? lse[stat] : 0.f;
-  const float del_q = (qrow < L) ? delta[stat] : 0.f;
+  // delta_q = <dO_q, O_q> (rowsum(dP * P)); each half-wave holds half of the head dimension.  Published for the
+  // dK/dV kernel, which is launched after this one on the same stream.
+  float del_q = 0.f;
+  {
+    float ofrag[DKP / 2];
+    load_fixed<DKP>(ofrag, o + slate * ors + (size_t)head * dk, q0, L, dk, ors);
+#pragma unroll
+    for (int t = 0; t < DKP / 2; ++t) del_q += dofrag[t] * ofrag[t];
+    del_q += __shfl_xor(del_q, 32, 64);
+    if (half == 0 && qrow < L) delta[stat] = del_q;
+  }
   f32x16 dqacc[DKP / 32];
   zero_acc<DKP>(dqacc);
   const int nkt = (L + 31) / 32;
@@ -401,15 +388,10 @@ extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, cons
   if (d_row_stride % 4 != 0 || d_row_stride < h * d_k) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* delta = (float*)ws;
-  const size_t n = (size_t)B * L * h;
-  int dblocks = (int)((n + 255) / 256);
-  if (dblocks > 4096) dblocks = 4096;
-  hipLaunchKernelGGL(ltrx_mha_delta_kernel, dim3(dblocks), dim3(256), 0, s, o, dout, B, L, h, d_k, o_row_stride, delta);
-  LTRX_LAUNCH_CHECK();
   const dim3 grid((L + 127) / 128, B * h);
   const float scale = 1.0f / sqrtf((float)d_k);
 #define CALLQ(DKP)                                                                                                   \
-  hipLaunchKernelGGL(ltrx_mha_bwd_dq_kernel<DKP>, grid, dim3(256), 0, s, q, k, v, key_pad_mask, dout, lse, delta, L, h, \
+  hipLaunchKernelGGL(ltrx_mha_bwd_dq_kernel<DKP>, grid, dim3(256), 0, s, q, k, v, key_pad_mask, o, dout, lse, delta, L, h, \
                      d_k, row_stride, o_row_stride, dq, d_row_stride, scale)
   LTRX_DKP_DISPATCH(d_k, CALLQ);
 #undef CALLQ

@@ -272,27 +272,32 @@ class FusedTrainer(object):
             return
         P = self.LB.ptr
         self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), P(out), out.stride(0), x.shape[0], w.shape[0],
-                                            x.shape[1], P(b), act, 1 if self.gemm == "split_bf16_strict" else 0, self._st()),
-                      "gemm_nt(fwd)")
+                                            x.shape[1], P(b), act, None, 0, 1 if self.gemm == "split_bf16_strict" else 0,
+                                            self._st()), "gemm_nt(fwd)")
 
-    def _lin_dgrad(self, dy, w, wT, out):
-        """out = dy w   (input gradient of nn.Linear); wT = w^T contiguous"""
+    def _lin_dgrad(self, dy, w, wT, out, relu_of=None):
+        """out = dy w   (input gradient of nn.Linear); wT = w^T contiguous.  With ``relu_of`` (the saved post-ReLU
+        activation that produced the layer input) the ReLU backward mask is applied in the GEMM epilogue."""
         if self.gemm == "hipblaslt":
             torch.mm(dy, w, out=out)
+            if relu_of is not None:
+                self._relu_bwd(out, relu_of)
             return
         P = self.LB.ptr
         self.LB.check(self.lib.ltrx_gemm_nt(P(dy), dy.stride(0), P(wT), wT.stride(0), P(out), out.stride(0), dy.shape[0],
-                                            wT.shape[0], dy.shape[1], None, 0, 1 if self.gemm == "split_bf16_strict" else 0,
-                                            self._st()), "gemm_nt(dgrad)")
+                                            wT.shape[0], dy.shape[1], None, 2 if relu_of is not None else 0, P(relu_of),
+                                            relu_of.stride(0) if relu_of is not None else 0,
+                                            1 if self.gemm == "split_bf16_strict" else 0, self._st()), "gemm_nt(dgrad)")
 
-    def _lin_wgrad(self, dy, x, gw):
-        """gw = dy^T x   (weight gradient of nn.Linear)"""
+    def _lin_wgrad(self, dy, x, gw, gb):
+        """gw = dy^T x, gb = column sums of dy   (weight and bias gradients of nn.Linear)"""
         if self.gemm == "hipblaslt":
             torch.mm(dy.t(), x, out=gw)
+            self._colsum(dy, gb)
             return
         P = self.LB.ptr
-        self.LB.check(self.lib.ltrx_gemm_tn(P(dy), dy.stride(0), P(x), x.stride(0), P(gw), dy.shape[0], dy.shape[1], x.shape[1],
-                                            1 if self.gemm == "split_bf16_strict" else 0, P(self.ws_tn), self._st()),
+        self.LB.check(self.lib.ltrx_gemm_tn(P(dy), dy.stride(0), P(x), x.stride(0), P(gw), P(gb), dy.shape[0], dy.shape[1],
+                                            x.shape[1], 1 if self.gemm == "split_bf16_strict" else 0, P(self.ws_tn), self._st()),
                       "gemm_tn(wgrad)")
 
     # ---- the step body (capturable) ----------------------------------------------------------------------------
@@ -353,27 +358,22 @@ class FusedTrainer(object):
                 n0, n1 = lay.sublayer[0].norm, lay.sublayer[1].norm
                 ff = lay.feed_forward
                 # FFN branch
-                self._colsum(ds, G(ff.w_2.bias))
-                self._lin_wgrad(ds, st["r"], G(ff.w_2.weight))
-                self._lin_dgrad(ds, W(ff.w_2.weight), self._wT.get(id(ff.w_2.weight)), self.d_r)
-                self._relu_bwd(self.d_r, st["r"])
-                self._colsum(self.d_r, G(ff.w_1.bias))
-                self._lin_wgrad(self.d_r, st["xn1"], G(ff.w_1.weight))
+                self._lin_wgrad(ds, st["r"], G(ff.w_2.weight), G(ff.w_2.bias))
+                self._lin_dgrad(ds, W(ff.w_2.weight), self._wT.get(id(ff.w_2.weight)), self.d_r, relu_of=st["r"])
+                self._lin_wgrad(self.d_r, st["xn1"], G(ff.w_1.weight), G(ff.w_1.bias))
                 self._lin_dgrad(self.d_r, W(ff.w_1.weight), self._wT.get(id(ff.w_1.weight)), self.tmp_d)
                 self._ln_bwd(self.tmp_d, st["x1"], W(n1.a_2), st["mean1"], st["rstd1"], ds, other, G(n1.a_2), G(n1.b_2))
                 ds, other = other, ds                              # ds = d loss / d x1
                 # attention branch
                 lo = lay.self_attn.linears[3]
-                self._colsum(ds, G(lo.bias))
-                self._lin_wgrad(ds, st["o"], G(lo.weight))
+                self._lin_wgrad(ds, st["o"], G(lo.weight), G(lo.bias))
                 self._lin_dgrad(ds, W(lo.weight), self._wT.get(id(lo.weight)), self.d_o)
                 qkv, dq = st["qkv"], self.dqkv
                 self.LB.check(lib.ltrx_mha_bwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(self.mask), P(st["o"]),
                                                P(self.d_o), P(st["lse"]), B, L, self.h, d // self.h, 3 * d, d, P(dq),
                                                dq.data_ptr() + 4 * d, dq.data_ptr() + 8 * d, 3 * d, P(self.ws_mha), self._st()),
                               "mha_bwd")
-                self._colsum(dq, st["gbqkv"])
-                self._lin_wgrad(dq, st["xn0"], st["gwqkv"])
+                self._lin_wgrad(dq, st["xn0"], st["gwqkv"], st["gbqkv"])
                 self._lin_dgrad(dq, st["wqkv"], st.get("wqkvT"), self.tmp_d)
                 self._ln_bwd(self.tmp_d, st["xin"], W(n0.a_2), st["mean0"], st["rstd0"], ds, other, G(n0.a_2), G(n0.b_2))
                 ds, other = other, ds                              # ds = d loss / d (layer input)
@@ -382,13 +382,13 @@ class FusedTrainer(object):
         # FC stack
         for i in range(self.nfc - 1, -1, -1):
             lyr = fc.layers[i]
-            if self.fc_act == 1:
-                self._relu_bwd(ds, self.fc_out[i])
-            self._colsum(ds, G(lyr.bias))
+            if self.fc_act == 1 and i == self.nfc - 1:
+                self._relu_bwd(ds, self.fc_out[i])               # the last FC activation feeds the encoder / head
             inp = self.x_in if i == 0 else self.fc_out[i - 1]
-            self._lin_wgrad(ds, inp, G(lyr.weight))
+            self._lin_wgrad(ds, inp, G(lyr.weight), G(lyr.bias))
             if i > 0:
-                self._lin_dgrad(ds, W(lyr.weight), self._wT.get(id(lyr.weight)), self.fc_dgrad[i - 1])
+                self._lin_dgrad(ds, W(lyr.weight), self._wT.get(id(lyr.weight)), self.fc_dgrad[i - 1],
+                                relu_of=self.fc_out[i - 1] if self.fc_act == 1 else None)
                 ds = self.fc_dgrad[i - 1]
         return loss
 

@@ -179,14 +179,17 @@ int ltrx_score_head_bwd(const float* dscores, const float* x, const float* w, in
 /* fp32-accurate dense projections on the bf16 matrix cores ("split-bf16": each fp32 operand is split into bf16 hi + lo
  * while staged into LDS; A B^T ~= Ahi Bhi^T + Ahi Blo^T + Alo Bhi^T with fp32 accumulation; strict != 0 uses a 3-term
  * split and 6 products).  Replaces the nn.Linear GEMMs of model.py:35-44 and transformer.py:193-203,221-227.
- *   ltrx_gemm_nt: C[M,N] (ld ldc) = A[M,K] (ld lda) * B[N,K]^T (ld ldb) (+ bias[N]) (+ ReLU if act == 1)
+ *   ltrx_gemm_nt: C[M,N] (ld ldc) = epi( A[M,K] (ld lda) * B[N,K]^T (ld ldb) + bias[N] )
  *                 -- forward (B = weight) and input gradient (B = weight^T);  K, lda, ldb multiples of 4.
- *   ltrx_gemm_tn: C[NP,KP] (dense) = A[M,NP]^T * B[M,KP]  -- weight gradient dW = dY^T X (split over M, deterministic). */
+ *                 epilogue `act`: 0 none, 1 ReLU (transformer.py:227 fused), 2 multiply by (aux[m,n] > 0): the ReLU
+ *                 backward fused into the input-gradient GEMM (aux = the saved post-activation tensor, ld ldaux).
+ *   ltrx_gemm_tn: C[NP,KP] (dense) = A[M,NP]^T * B[M,KP]  -- weight gradient dW = dY^T X (split over M, deterministic);
+ *                 bias_out[NP] (optional) = column sums of A = the bias gradient, produced in the same pass. */
 int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,
-                 int act, int strict, ltrx_stream_t stream);
+                 int act, const float* aux, int ldaux, int strict, ltrx_stream_t stream);
 size_t ltrx_gemm_tn_workspace_bytes(int M, int NP, int KP);
-int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int M, int NP, int KP, int strict, void* ws,
-                 ltrx_stream_t stream);
+int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, float* bias_out, int M, int NP, int KP, int strict,
+                 void* ws, ltrx_stream_t stream);
 
 /* Test hook: D[32x32] = A[32x2] * B[2x32] with ONE v_mfma_f32_32x32x2_f32, written through the operand / result
  * lane layout the attention kernels assume.  Lets the parity suite tell a layout bug from a logic bug. */

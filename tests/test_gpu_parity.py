@@ -410,7 +410,12 @@ def test_split_bf16_gemm_matches_fp64(strict):
         bias = rng.standard_normal(N).astype(np.float32)
         At, Bt, bt = _t(A), _t(Bw), _t(bias)
         C = torch.empty((Mm, N), device=DEV)
-        LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, LB.ptr(C), N, Mm, N, K, LB.ptr(bt), 1, strict, None), "gemm_nt")
+        LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, LB.ptr(C), N, Mm, N, K, LB.ptr(bt), 1, None, 0, strict, None), "gemm_nt")
+        aux = rng.standard_normal((Mm, N)).astype(np.float32)
+        C2 = torch.empty((Mm, N), device=DEV)
+        LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, LB.ptr(C2), N, Mm, N, K, None, 2, LB.ptr(_t(aux)), N, strict, None), "gemm_nt(mask)")
+        ref2 = (A.astype(np.float64) @ Bw.astype(np.float64).T) * (aux > 0)
+        assert float(np.abs(C2.cpu().numpy() - ref2).max()) < 1e-4
         ref = np.maximum(A.astype(np.float64) @ Bw.astype(np.float64).T + bias, 0)
         scale = (np.abs(A).astype(np.float64) @ np.abs(Bw).astype(np.float64).T).max()
         err = float(np.abs(C.cpu().numpy() - ref).max() / scale)
@@ -423,8 +428,11 @@ def test_split_bf16_gemm_matches_fp64(strict):
         Bx = rng.standard_normal((Mm, KP)).astype(np.float32)
         At, Bt = _t(A), _t(Bx)
         C = torch.empty((NP, KP), device=DEV)
+        gb = torch.empty(NP, device=DEV)
         ws = torch.empty(max(lib.ltrx_gemm_tn_workspace_bytes(Mm, NP, KP), 64), dtype=torch.uint8, device=DEV)
-        LB.check(lib.ltrx_gemm_tn(LB.ptr(At), NP, LB.ptr(Bt), KP, LB.ptr(C), Mm, NP, KP, strict, LB.ptr(ws), None), "gemm_tn")
+        LB.check(lib.ltrx_gemm_tn(LB.ptr(At), NP, LB.ptr(Bt), KP, LB.ptr(C), LB.ptr(gb), Mm, NP, KP, strict, LB.ptr(ws), None), "gemm_tn")
+        bref = A.astype(np.float64).sum(0)
+        assert float(np.abs(gb.cpu().numpy() - bref).max()) < 1e-5 * max(1.0, np.abs(A).sum(0).max())
         ref = A.astype(np.float64).T @ Bx.astype(np.float64)
         scale = (np.abs(A).astype(np.float64).T @ np.abs(Bx).astype(np.float64)).max()
         err = float(np.abs(C.cpu().numpy() - ref).max() / scale)
