@@ -43,6 +43,7 @@ SIGNATURES = {
     "ltrx_score_head_bwd_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_score_head_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "ltrx_gemm_set_variant": (None, [_i]),
     "ltrx_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltrx_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ltrx_selftest_mfma32x32x2": (_i, [_vp, _vp, _vp, _vp]),

@@ -30,7 +30,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, LDK = 40;   // LDK: LDS row stride in bf16 elements
+constexpr int BN = 128;   // output-tile columns (rows of B); the row count BM_ and the K-tile depth BK_ are template parameters
 
 __device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
@@ -49,18 +49,22 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo, b
   }
 }
 
-template <int NTERMS>
+// LDS operand images: [term][row][k] bf16, k contiguous, row stride BK_+8 elements (16-byte aligned rows whose
+// stride in dwords is 4 mod 16 -> the 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots).
+template <int NTERMS, int BM_, int BK_>
 struct Smem {
-  __bf16 a[NTERMS][BM * LDK];
+  static constexpr int LDK = BK_ + 8;
+  __bf16 a[NTERMS][BM_ * LDK];
   __bf16 b[NTERMS][BN * LDK];
 };
 
-// the MFMA phase over one staged K-tile (BK = 32 -> two k-steps of 16)
-template <int NTERMS>
-__device__ __forceinline__ void mma_tile(const Smem<NTERMS>& s, int wr, int wc, f32x16 (&acc)[2][2]) {
+// the MFMA phase over one staged K-tile: wave (wr, wc) owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles
+template <int NTERMS, int BM_, int BK_>
+__device__ __forceinline__ void mma_tile(const Smem<NTERMS, BM_, BK_>& s, int wr, int wc, f32x16 (&acc)[2][2]) {
+  constexpr int LDK = Smem<NTERMS, BM_, BK_>::LDK;
   const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
-  for (int ks = 0; ks < BK / 16; ++ks) {
+  for (int ks = 0; ks < BK_ / 16; ++ks) {
     bf16x8 af[NTERMS][2], bfr[NTERMS][2];
 #pragma unroll
     for (int t = 0; t < NTERMS; ++t)
@@ -96,44 +100,57 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
-// NT:  C[M,N] = A[M,K] B[N,K]^T (+bias) (+ReLU)
+// NT:  C[M,N] = A[M,K] B[N,K]^T (+bias) (+ReLU | * mask)
+// workgroup = 2 * BM_/64 waves: (BM_/64) x 2 grid of 64 x 64 wave tiles over a BM_ x 128 output tile
 // ------------------------------------------------------------------------------------------------------------------
-template <int NTERMS>
-__global__ void __launch_bounds__(256, 2) ltrx_gemm_nt_kernel(const float* __restrict__ A, int lda,
-                                                              const float* __restrict__ B, int ldb,
-                                                              float* __restrict__ C, int ldc, int M, int N, int K,
-                                                              const float* __restrict__ bias, int act,
-                                                              const float* __restrict__ aux, int ldaux, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) Smem<NTERMS> s;
-  const int nblk = gridDim.x;
-  const int id = xcd_remap(blockIdx.x, nblk);
-  const int m0 = (id / tiles_n) * BM, n0 = (id % tiles_n) * BN;
+template <int NTERMS, int BM_, int BK_>
+__global__ void __launch_bounds__(BM_ * 2, 2) ltrx_gemm_nt_kernel(const float* __restrict__ A, int lda,
+                                                                  const float* __restrict__ B, int ldb,
+                                                                  float* __restrict__ C, int ldc, int M, int N, int K,
+                                                                  const float* __restrict__ bias, int act,
+                                                                  const float* __restrict__ aux, int ldaux, int tiles_n) {
+  constexpr int T = BM_ * 2;                    // threads
+  constexpr int C4 = BK_ / 4;                   // float4 per tile row
+  constexpr int LDK = Smem<NTERMS, BM_, BK_>::LDK;
+  constexpr int PA = BM_ * C4 / T;              // float4 per thread for the A tile
+  constexpr int PB = BN * C4 / T;               //                     ... B tile
+  __shared__ __attribute__((aligned(16))) Smem<NTERMS, BM_, BK_> s;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (id / tiles_n) * BM_, n0 = (id % tiles_n) * BN;
   const int wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
-
-  // staging map: 128 rows x 8 float4 per operand -> 4 float4 per thread per operand
-  const int srow = threadIdx.x >> 3;          // 0..31 (+32 per pass)
-  const int sc4 = (threadIdx.x & 7) * 4;      // k offset inside the tile
-  float4 ra[4], rb[4];
+  const int srow = threadIdx.x / C4;            // staging: thread -> (row, float4 column); passes step T / C4 rows
+  const int sc4 = (threadIdx.x % C4) * 4;
+  constexpr int RSTEP = T / C4;
+  float4 ra[PA], rb[PB];
 
   auto gload = [&](int k0) {
+    const int k = k0 + sc4;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int r = srow + 32 * p, k = k0 + sc4;
+    for (int p = 0; p < PA; ++p) {
+      const int r = srow + RSTEP * p;
       ra[p] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * lda + k)
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int r = srow + RSTEP * p;
       rb[p] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4*>(B + (size_t)(n0 + r) * ldb + k)
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto sstore = [&]() {
+    bf16x4 h, l, l2;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int r = srow + 32 * p;
-      bf16x4 h, l, l2;
+    for (int p = 0; p < PA; ++p) {
+      const int r = srow + RSTEP * p;
       split4<NTERMS>(ra[p], h, l, l2);
       *reinterpret_cast<bf16x4*>(&s.a[0][r * LDK + sc4]) = h;
       *reinterpret_cast<bf16x4*>(&s.a[1][r * LDK + sc4]) = l;
       if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.a[2][r * LDK + sc4]) = l2;
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int r = srow + RSTEP * p;
       split4<NTERMS>(rb[p], h, l, l2);
       *reinterpret_cast<bf16x4*>(&s.b[0][r * LDK + sc4]) = h;
       *reinterpret_cast<bf16x4*>(&s.b[1][r * LDK + sc4]) = l;
@@ -149,14 +166,14 @@ __global__ void __launch_bounds__(256, 2) ltrx_gemm_nt_kernel(const float* __res
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (K + BK - 1) / BK;
+  const int nk = (K + BK_ - 1) / BK_;
   gload(0);
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();                 // the previous tile's fragments are consumed
     sstore();
     __syncthreads();
-    if (kt + 1 < nk) gload((kt + 1) * BK);   // in flight during the MFMAs below
-    mma_tile<NTERMS>(s, wr, wc, acc);
+    if (kt + 1 < nk) gload((kt + 1) * BK_);   // in flight during the MFMAs below
+    mma_tile<NTERMS, BM_, BK_>(s, wr, wc, acc);
   }
 
   // epilogue: lane owns column n0 + wc*64 + j*32 + (lane&31); register r is row rowmap(r, half)
@@ -189,7 +206,9 @@ __global__ void __launch_bounds__(256, 2) ltrx_gemm_tn_kernel(const float* __res
                                                               const float* __restrict__ B, int ldb,
                                                               float* __restrict__ slabs, float* __restrict__ bias_slabs,
                                                               int M, int NP, int KP, int tiles_k, int m_per_split) {
-  __shared__ __attribute__((aligned(16))) Smem<NTERMS> s;
+  constexpr int BM = 128, BK = 32;
+  constexpr int LDK = Smem<NTERMS, BM, BK>::LDK;
+  __shared__ __attribute__((aligned(16))) Smem<NTERMS, BM, BK> s;
   const int tile = blockIdx.x, split = blockIdx.y;
   const int n0 = (tile / tiles_k) * BM, k0 = (tile % tiles_k) * BN;     // output tile: rows n', cols k'
   const int wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
@@ -251,7 +270,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_gemm_tn_kernel(const float* __res
       }
       __syncthreads();
       if (mt + BK < mend) gload(mt + BK);
-      mma_tile<NTERMS>(s, wr, wc, acc);
+      mma_tile<NTERMS, BM, BK>(s, wr, wc, acc);
     }
   }
   if (want_bias && n0 + scol < NP) bias_slabs[((size_t)split * 2 + sg) * NP + n0 + scol] = bsum;
@@ -285,25 +304,43 @@ __global__ void __launch_bounds__(256) ltrx_gemm_slab_reduce_kernel(const float*
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
+// tile variant: 0 = auto; 1 = 128x128x32 (4 waves); 2 = 128x128x64; 3 = 256x128x32 (8 waves); 4 = 256x128x64
+static int g_nt_variant = 0;
+extern "C" void ltrx_gemm_set_variant(int v) { g_nt_variant = v; }
+
+template <int NTERMS, int BM_, int BK_>
+static void launch_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                      const float* bias, int act, const float* aux, int ldaux, hipStream_t s) {
+  const int tiles_m = (M + BM_ - 1) / BM_, tiles_n = (N + BN - 1) / BN;
+  hipLaunchKernelGGL((ltrx_gemm_nt_kernel<NTERMS, BM_, BK_>), dim3(tiles_m * tiles_n), dim3(BM_ * 2), 0, s, A, lda, B, ldb, C,
+                     ldc, M, N, K, bias, act, aux, ldaux, tiles_n);
+}
+
 extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                             const float* bias, int act, const float* aux, int ldaux, int strict, ltrx_stream_t stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return LTRX_EINVAL;
   if (act == 2 && (!aux || ldaux < N)) return LTRX_EINVAL;
   if ((K & 3) || (lda & 3) || (ldb & 3) || lda < K || ldb < K || ldc < N) return LTRX_EUNSUPPORTED;
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const dim3 grid(tiles_m * tiles_n);
   hipStream_t s = (hipStream_t)stream;
-  if (strict)
-    hipLaunchKernelGGL(ltrx_gemm_nt_kernel<3>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, tiles_n);
-  else
-    hipLaunchKernelGGL(ltrx_gemm_nt_kernel<2>, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, tiles_n);
+  int v = g_nt_variant;
+  if (v == 0) v = 1;
+  if (strict) {
+    launch_nt<3, 128, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s);
+  } else {
+    switch (v) {
+      case 2: launch_nt<2, 128, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s); break;
+      case 3: launch_nt<2, 256, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s); break;
+      case 4: launch_nt<2, 256, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s); break;
+      default: launch_nt<2, 128, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s); break;
+    }
+  }
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }
 
 static int tn_splits(int M, int tiles) {
   int want = (512 + tiles - 1) / tiles;            // aim for >= 512 workgroups
-  int maxs = (M + 4 * BK - 1) / (4 * BK);          // at least 4 K-tiles per split
+  int maxs = (M + 4 * 32 - 1) / (4 * 32);          // at least 4 K-tiles per split
   if (want > maxs) want = maxs;
   if (want > 64) want = 64;
   return want < 1 ? 1 : want;
@@ -311,7 +348,7 @@ static int tn_splits(int M, int tiles) {
 
 extern "C" size_t ltrx_gemm_tn_workspace_bytes(int M, int NP, int KP) {
   if (M <= 0 || NP <= 0 || KP <= 0) return 0;
-  const int tiles = ((NP + BM - 1) / BM) * ((KP + BN - 1) / BN);
+  const int tiles = ((NP + 127) / 128) * ((KP + BN - 1) / BN);
   const size_t sp = (size_t)tn_splits(M, tiles);
   return (sp * NP * KP + 2 * sp * NP) * sizeof(float);
 }
@@ -320,11 +357,11 @@ extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, fl
                             int KP, int strict, void* ws, ltrx_stream_t stream) {
   if (!A || !B || !C || !ws || M <= 0 || NP <= 0 || KP <= 0) return LTRX_EINVAL;
   if (lda < NP || ldb < KP) return LTRX_EUNSUPPORTED;
-  const int tiles_n = (NP + BM - 1) / BM, tiles_k = (KP + BN - 1) / BN;
+  const int tiles_n = (NP + 127) / 128, tiles_k = (KP + BN - 1) / BN;
   const int tiles = tiles_n * tiles_k;
   const int splits = tn_splits(M, tiles);
   int mps = (M + splits - 1) / splits;
-  mps = (mps + BK - 1) / BK * BK;
+  mps = (mps + 31) / 32 * 32;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(tiles, splits);
   float* bslabs = bias_out ? (float*)ws + (size_t)splits * NP * KP : nullptr;

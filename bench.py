@@ -163,11 +163,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)                # (test hook: several ranks may share one GPU with LTRX_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("LTRX_DIST_BACKEND", "nccl")       # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from allrank_amd import losses as E
     from allrank_amd.engine import Trainer, FusedTrainer

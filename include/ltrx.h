@@ -187,6 +187,8 @@ int ltrx_score_head_bwd(const float* dscores, const float* x, const float* w, in
  *                 bias_out[NP] (optional) = column sums of A = the bias gradient, produced in the same pass. */
 int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,
                  int act, const float* aux, int ldaux, int strict, ltrx_stream_t stream);
+/* tuning hook: tile variant of ltrx_gemm_nt (0 auto, 1 128x128x32, 2 128x128x64, 3 256x128x32, 4 256x128x64) */
+void ltrx_gemm_set_variant(int variant);
 size_t ltrx_gemm_tn_workspace_bytes(int M, int NP, int KP);
 int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, float* bias_out, int M, int NP, int KP, int strict,
                  void* ws, ltrx_stream_t stream);

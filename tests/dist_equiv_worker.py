@@ -1,0 +1,54 @@
+"""torchrun worker for test_sharded_step_equals_single_rank_step (2 ranks on one GPU, gloo)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from allrank_amd.engine import FusedTrainer  # noqa: E402
+from allrank_amd.model import make_model  # noqa: E402
+from allrank_amd import parallel  # noqa: E402
+
+
+def build():
+    torch.manual_seed(7)
+    return make_model(dict(sizes=[32], input_norm=False, activation=None, dropout=0.0),
+                      dict(N=1, d_ff=64, h=4, positional_encoding=None, dropout=0.0),
+                      dict(d_output=1, output_activation=None), 20).to("cuda:0")
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    G, L = 8, 40
+    rng = np.random.default_rng(3)
+    x = torch.tensor(rng.standard_normal((G, L, 20)).astype(np.float32), device="cuda:0")
+    y = torch.tensor(rng.integers(0, 5, (G, L)).astype(np.float32), device="cuda:0")
+    y[5, 30:] = -1
+    for loss_name, args in (("approxNDCGLoss", {}), ("neuralNDCG", {}), ("lambdaLoss", dict(weighing_scheme="lambdaRank_scheme", reduction="mean"))):
+        lo, hi = parallel.shard_slates(G, rank, world)
+        m_sh = build()
+        ft = FusedTrainer(m_sh, loss_name, args, hi - lo, L, lr=1e-3, world_size=world, use_graph=False, gemm="hipblaslt")
+        share = ft.step(x[lo:hi], y[lo:hi], global_batch=G).clone()
+        dist.all_reduce(share)
+        m_1 = build()
+        f1 = FusedTrainer(m_1, loss_name, args, G, L, lr=1e-3, world_size=1, use_graph=False, gemm="hipblaslt")
+        full = f1.step(x, y)
+        if loss_name == "lambdaLoss":
+            pass                                  # mean over the global pair count: every rank already holds loss_share
+        assert abs(share.item() - full.item()) <= 1e-5 * (1 + abs(full.item())), (loss_name, share.item(), full.item())
+        gerr = (ft.flat_g - f1.flat_g).abs().max().item() / max(f1.flat_g.abs().max().item(), 1e-12)
+        assert gerr < 1e-4, (loss_name, "grad", gerr)
+        werr = (ft.flat_p - f1.flat_p).abs().max().item()
+        assert werr <= 2.1e-3, (loss_name, "weights", werr)   # one Adam step of lr=1e-3; ~0-gradient params may flip sign
+    if rank == 0:
+        print("EQUIV_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -439,3 +439,33 @@ def test_split_bf16_gemm_matches_fp64(strict):
         rows.append(dict(kind="tn", shape=(Mm, NP, KP), strict=strict, rel_err=err))
         assert err < (4e-7 if strict else 4e-6), rows[-1]
     _log("split_gemm_strict%d" % strict, rows)
+
+
+def test_bench_two_ranks_on_one_gpu_gloo():
+    """the N>1 path of bench.py (torchrun, slate sharding, flat-gradient all-reduce, max-over-ranks timing) end to end:
+    two ranks share the single GPU of the test box and exchange gradients over gloo (RCCL needs one GPU per rank)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, LTRX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--slates-per-gpu", "8", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 16 and rec["value"] > 0 and np.isfinite(rec["last_loss"])
+
+
+def test_sharded_step_equals_single_rank_step():
+    """slate-sharded data parallelism reproduces the single-process step: 2 ranks x 4 slates (gloo, one GPU) vs
+    1 rank x 8 slates -- same loss (sum of rank shares) and same updated weights."""
+    import subprocess
+    import sys
+    script = os.path.join(ROOT, "tests", "dist_equiv_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29618", script]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    assert "EQUIV_OK" in out.stdout, out.stdout[-2000:]
