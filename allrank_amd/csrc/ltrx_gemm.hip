@@ -49,19 +49,28 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo, b
   }
 }
 
-// LDS operand images: [term][row][k] bf16, k contiguous, row stride BK_+8 elements (16-byte aligned rows whose
-// stride in dwords is 4 mod 16 -> the 16-lane groups of ds_read_b128 hit 16 distinct 4-bank slots).
+// LDS operand images: [term][row][k] bf16, k contiguous, UNPADDED rows of BK_ elements (64 B at BK_ = 32); the 16-byte
+// chunk c of row r is stored at chunk position c ^ swz(r), swz(r) = (r >> 2) & (BK_/8 - 1).  With that swizzle the
+// 16-lane groups of a fragment ds_read_b128 (rows {0-3,12-15,20-27}+..., same logical chunk) hit 16 distinct 4-bank
+// slots, and the staging ds_write_b64 (8 lanes per row, 2 rows per 16-lane group, rows 64 B apart) covers all 32 write
+// banks exactly once: both directions are conflict-free (SQ_LDS_BANK_CONFLICT was 33 % of LDS cycles with padded rows).
 template <int NTERMS, int BM_, int BK_>
 struct Smem {
-  static constexpr int LDK = BK_ + 8;
+  static constexpr int LDK = BK_;
   __bf16 a[NTERMS][BM_ * LDK];
   __bf16 b[NTERMS][BN * LDK];
 };
 
+template <int BK_>
+__device__ __forceinline__ int swz_off(int row, int k) {       // element offset of (row, k) inside an operand image
+  constexpr int CH = BK_ / 8;                                   // 16-byte chunks per row
+  const int c = (k >> 3) ^ ((row >> 2) & (CH - 1));
+  return row * BK_ + c * 8 + (k & 7);
+}
+
 // the MFMA phase over one staged K-tile: wave (wr, wc) owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles
 template <int NTERMS, int BM_, int BK_>
 __device__ __forceinline__ void mma_tile(const Smem<NTERMS, BM_, BK_>& s, int wr, int wc, f32x16 (&acc)[2][2]) {
-  constexpr int LDK = Smem<NTERMS, BM_, BK_>::LDK;
   const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
   for (int ks = 0; ks < BK_ / 16; ++ks) {
@@ -70,23 +79,23 @@ __device__ __forceinline__ void mma_tile(const Smem<NTERMS, BM_, BK_>& s, int wr
     for (int t = 0; t < NTERMS; ++t)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        af[t][i] = *reinterpret_cast<const bf16x8*>(&s.a[t][(wr * 64 + i * 32 + l31) * LDK + ks * 16 + 8 * half]);
-        bfr[t][i] = *reinterpret_cast<const bf16x8*>(&s.b[t][(wc * 64 + i * 32 + l31) * LDK + ks * 16 + 8 * half]);
+        af[t][i] = *reinterpret_cast<const bf16x8*>(&s.a[t][swz_off<BK_>(wr * 64 + i * 32 + l31, ks * 16 + 8 * half)]);
+        bfr[t][i] = *reinterpret_cast<const bf16x8*>(&s.b[t][swz_off<BK_>(wc * 64 + i * 32 + l31, ks * 16 + 8 * half)]);
       }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        // smallest terms first
-        if (NTERMS == 3) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], acc[i][j], 0, 0, 0);
-        }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], acc[i][j], 0, 0, 0);
-      }
+    // term-major order: consecutive MFMAs write DIFFERENT accumulators (no back-to-back dependent issue); the
+    // smallest terms are accumulated first.
+#define LTRX_MMA_TERM(TA, TB)                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA][i], bfr[TB][j], acc[i][j], 0, 0, 0);
+    if (NTERMS == 3) {
+      LTRX_MMA_TERM(NTERMS - 2, NTERMS - 2)
+      LTRX_MMA_TERM(0, NTERMS - 1)
+      LTRX_MMA_TERM(NTERMS - 1, 0)
+    }
+    LTRX_MMA_TERM(0, 1)
+    LTRX_MMA_TERM(1, 0)
+    LTRX_MMA_TERM(0, 0)
+#undef LTRX_MMA_TERM
   }
 }
 
@@ -104,14 +113,13 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // workgroup = 2 * BM_/64 waves: (BM_/64) x 2 grid of 64 x 64 wave tiles over a BM_ x 128 output tile
 // ------------------------------------------------------------------------------------------------------------------
 template <int NTERMS, int BM_, int BK_>
-__global__ void __launch_bounds__(BM_ * 2, 2) ltrx_gemm_nt_kernel(const float* __restrict__ A, int lda,
+__global__ void __launch_bounds__(BM_ * 2) __attribute__((amdgpu_waves_per_eu(2, 3))) ltrx_gemm_nt_kernel(const float* __restrict__ A, int lda,
                                                                   const float* __restrict__ B, int ldb,
                                                                   float* __restrict__ C, int ldc, int M, int N, int K,
                                                                   const float* __restrict__ bias, int act,
                                                                   const float* __restrict__ aux, int ldaux, int tiles_n) {
   constexpr int T = BM_ * 2;                    // threads
   constexpr int C4 = BK_ / 4;                   // float4 per tile row
-  constexpr int LDK = Smem<NTERMS, BM_, BK_>::LDK;
   constexpr int PA = BM_ * C4 / T;              // float4 per thread for the A tile
   constexpr int PB = BN * C4 / T;               //                     ... B tile
   __shared__ __attribute__((aligned(16))) Smem<NTERMS, BM_, BK_> s;
@@ -142,19 +150,19 @@ __global__ void __launch_bounds__(BM_ * 2, 2) ltrx_gemm_nt_kernel(const float* _
     bf16x4 h, l, l2;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      const int r = srow + RSTEP * p;
+      const int o = swz_off<BK_>(srow + RSTEP * p, sc4);
       split4<NTERMS>(ra[p], h, l, l2);
-      *reinterpret_cast<bf16x4*>(&s.a[0][r * LDK + sc4]) = h;
-      *reinterpret_cast<bf16x4*>(&s.a[1][r * LDK + sc4]) = l;
-      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.a[2][r * LDK + sc4]) = l2;
+      *reinterpret_cast<bf16x4*>(&s.a[0][o]) = h;
+      *reinterpret_cast<bf16x4*>(&s.a[1][o]) = l;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.a[2][o]) = l2;
     }
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-      const int r = srow + RSTEP * p;
+      const int o = swz_off<BK_>(srow + RSTEP * p, sc4);
       split4<NTERMS>(rb[p], h, l, l2);
-      *reinterpret_cast<bf16x4*>(&s.b[0][r * LDK + sc4]) = h;
-      *reinterpret_cast<bf16x4*>(&s.b[1][r * LDK + sc4]) = l;
-      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.b[2][r * LDK + sc4]) = l2;
+      *reinterpret_cast<bf16x4*>(&s.b[0][o]) = h;
+      *reinterpret_cast<bf16x4*>(&s.b[1][o]) = l;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.b[2][o]) = l2;
     }
   };
 
@@ -198,16 +206,111 @@ __global__ void __launch_bounds__(BM_ * 2, 2) ltrx_gemm_nt_kernel(const float* _
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// NT, software-pipelined: two LDS buffers and two register sets.  Per K-tile ONE barrier; the global loads of tile
+// t+2 are in flight for a whole iteration; the bf16 split + LDS store of tile t+1 sits in the same basic block as the
+// MFMAs of tile t, so the VALU / LDS-write work overlaps the matrix pipe.  128 x 128 x 32 tile, 4 waves, 80 KB LDS
+// (two workgroups per CU).
+// ------------------------------------------------------------------------------------------------------------------
+template <int NTERMS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ltrx_gemm_nt_pipe_kernel(const float* __restrict__ A, int lda,
+                                                                   const float* __restrict__ B, int ldb,
+                                                                   float* __restrict__ C, int ldc, int M, int N, int K,
+                                                                   const float* __restrict__ bias, int act,
+                                                                   const float* __restrict__ aux, int ldaux, int tiles_n) {
+  constexpr int BM_ = 128, BK_ = 32;
+  __shared__ __attribute__((aligned(16))) Smem<NTERMS, BM_, BK_> s[2];
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (id / tiles_n) * BM_, n0 = (id % tiles_n) * BN;
+  const int wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+  const int srow = threadIdx.x >> 3, sc4 = (threadIdx.x & 7) * 4;
+  float4 ra0[4], rb0[4], ra1[4], rb1[4];
+
+  auto gload = [&](float4 (&ra)[4], float4 (&rb)[4], int k0) {
+    const int k = k0 + sc4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = srow + 32 * p;
+      ra[p] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * lda + k)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[p] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4*>(B + (size_t)(n0 + r) * ldb + k)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto sstore = [&](Smem<NTERMS, BM_, BK_>& d, const float4 (&ra)[4], const float4 (&rb)[4]) {
+    bf16x4 h, l, l2;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int o = swz_off<BK_>(srow + 32 * p, sc4);
+      split4<NTERMS>(ra[p], h, l, l2);
+      *reinterpret_cast<bf16x4*>(&d.a[0][o]) = h;
+      *reinterpret_cast<bf16x4*>(&d.a[1][o]) = l;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&d.a[2][o]) = l2;
+      split4<NTERMS>(rb[p], h, l, l2);
+      *reinterpret_cast<bf16x4*>(&d.b[0][o]) = h;
+      *reinterpret_cast<bf16x4*>(&d.b[1][o]) = l;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&d.b[2][o]) = l2;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (K + BK_ - 1) / BK_;
+  gload(ra0, rb0, 0);
+  sstore(s[0], ra0, rb0);
+  if (nk > 1) gload(ra0, rb0, BK_);          // set 0 now holds tile 1
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even step: compute tile kt from s[0]; stage tile kt+1 (set 0) into s[1]; prefetch tile kt+2 into set 1
+    if (kt + 2 < nk) gload(ra1, rb1, (kt + 2) * BK_);
+    mma_tile<NTERMS, BM_, BK_>(s[0], wr, wc, acc);
+    if (kt + 1 < nk) sstore(s[1], ra0, rb0);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    // odd step: compute tile kt+1 from s[1]; stage tile kt+2 (set 1) into s[0]; prefetch tile kt+3 into set 0
+    if (kt + 3 < nk) gload(ra0, rb0, (kt + 3) * BK_);
+    mma_tile<NTERMS, BM_, BK_>(s[1], wr, wc, acc);
+    if (kt + 2 < nk) sstore(s[0], ra1, rb1);
+    __syncthreads();
+  }
+
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wc * 64 + j * 32 + l31;
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + rowmap(r, half);
+        if (row < M) {
+          float v = acc[i][j][r] + bv;
+          if (act == 1) v = fmaxf(v, 0.f);
+          if (act == 2) v = (aux[(size_t)row * ldaux + col] > 0.f) ? v : 0.f;
+          C[(size_t)row * ldc + col] = v;
+        }
+      }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // TN (weight gradient):  C[N',K'] = sum_m A[m][n'] * B[m][k'],  split over m into `splits` slabs
 // ------------------------------------------------------------------------------------------------------------------
 template <int NTERMS>
-__global__ void __launch_bounds__(256, 2) ltrx_gemm_tn_kernel(const float* __restrict__ A, int lda,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) ltrx_gemm_tn_kernel(const float* __restrict__ A, int lda,
                                                               const float* __restrict__ B, int ldb,
                                                               float* __restrict__ slabs, float* __restrict__ bias_slabs,
                                                               int M, int NP, int KP, int tiles_k, int m_per_split) {
   constexpr int BM = 128, BK = 32;
-  constexpr int LDK = Smem<NTERMS, BM, BK>::LDK;
   __shared__ __attribute__((aligned(16))) Smem<NTERMS, BM, BK> s;
   const int tile = blockIdx.x, split = blockIdx.y;
   const int n0 = (tile / tiles_k) * BM, k0 = (tile % tiles_k) * BN;     // output tile: rows n', cols k'
@@ -224,30 +327,42 @@ __global__ void __launch_bounds__(256, 2) ltrx_gemm_tn_kernel(const float* __res
   const bool want_bias = (bias_slabs != nullptr) && (tile % tiles_k == 0);   // column sums of A = the bias gradient
   float bsum = 0.f;
 
-  auto gload = [&](int mt) {
+  const bool cola = n0 + scol < NP, colb = k0 + scol < KP;
+  const float* pA = A + (cola ? n0 + scol : NP - 1);
+  const float* pB = B + (colb ? k0 + scol : KP - 1);
+  int mt_held = 0;                   // first contraction row of the tile currently held in ra/rb
+  auto gload = [&](int mt) {         // raw loads (clamped rows); zero-select deferred to sstore
+    mt_held = mt;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int m = mt + 8 * p + 4 * sg + e;
-        const bool okm = m < mend;
-        ra[p][e] = (okm && n0 + scol < NP) ? A[(size_t)m * lda + n0 + scol] : 0.f;
-        rb[p][e] = (okm && k0 + scol < KP) ? B[(size_t)m * ldb + k0 + scol] : 0.f;
+        const int m = min(mt + 8 * p + 4 * sg + e, mend - 1);
+        ra[p][e] = pA[(size_t)m * lda];
+        rb[p][e] = pB[(size_t)m * ldb];
       }
   };
   auto sstore = [&]() {
 #pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool okm = mt_held + 8 * p + 4 * sg + e < mend;
+        ra[p][e] = (okm && cola) ? ra[p][e] : 0.f;
+        rb[p][e] = (okm && colb) ? rb[p][e] : 0.f;
+      }
+#pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int kk = 8 * p + 4 * sg;
+      const int o = swz_off<BK>(scol, 8 * p + 4 * sg);
       bf16x4 h, l, l2;
       split4<NTERMS>(make_float4(ra[p][0], ra[p][1], ra[p][2], ra[p][3]), h, l, l2);
-      *reinterpret_cast<bf16x4*>(&s.a[0][scol * LDK + kk]) = h;
-      *reinterpret_cast<bf16x4*>(&s.a[1][scol * LDK + kk]) = l;
-      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.a[2][scol * LDK + kk]) = l2;
+      *reinterpret_cast<bf16x4*>(&s.a[0][o]) = h;
+      *reinterpret_cast<bf16x4*>(&s.a[1][o]) = l;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.a[2][o]) = l2;
       split4<NTERMS>(make_float4(rb[p][0], rb[p][1], rb[p][2], rb[p][3]), h, l, l2);
-      *reinterpret_cast<bf16x4*>(&s.b[0][scol * LDK + kk]) = h;
-      *reinterpret_cast<bf16x4*>(&s.b[1][scol * LDK + kk]) = l;
-      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.b[2][scol * LDK + kk]) = l2;
+      *reinterpret_cast<bf16x4*>(&s.b[0][o]) = h;
+      *reinterpret_cast<bf16x4*>(&s.b[1][o]) = l;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.b[2][o]) = l2;
     }
   };
 
@@ -323,6 +438,11 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
   if ((K & 3) || (lda & 3) || (ldb & 3) || lda < K || ldb < K || ldc < N) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   int v = g_nt_variant;
+  if (v >= 100) {            // tuning experiment: all rows alias row 0 -> every operand load is an L2 hit (results are garbage)
+    v -= 100;
+    lda = 0;
+    ldb = 0;
+  }
   if (v == 0) v = 1;
   if (strict) {
     launch_nt<3, 128, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s);
@@ -331,6 +451,12 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
       case 2: launch_nt<2, 128, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s); break;
       case 3: launch_nt<2, 256, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s); break;
       case 4: launch_nt<2, 256, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s); break;
+      case 5: {
+        const int tiles_m = (M + 127) / 128, tiles_n = (N + BN - 1) / BN;
+        hipLaunchKernelGGL(ltrx_gemm_nt_pipe_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N,
+                           K, bias, act, aux, ldaux, tiles_n);
+        break;
+      }
       default: launch_nt<2, 128, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s); break;
     }
   }

@@ -271,7 +271,7 @@ static int ln_grid(int rows) {
 // the backward keeps per-block column partials: fewer, fatter blocks (each wave walks many rows)
 static int ln_bwd_grid(int rows) {
   int g = (rows + 15) / 16;
-  return g > 512 ? 512 : (g < 1 ? 1 : g);
+  return g > 160 ? 160 : (g < 1 ? 1 : g);     // few, fat blocks: the second-stage reduce is a serial chain over them
 }
 static int ln_fwd_vec_grid(int rows) {
   int g = (rows + 7) / 8;
