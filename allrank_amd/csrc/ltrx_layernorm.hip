@@ -239,18 +239,18 @@ __global__ void __launch_bounds__(256) ltrx_layernorm_bwd_vec_kernel(const float
   }
 }
 
-// One workgroup per 64 columns; its 4 waves split the partial rows, lanes own consecutive columns (coalesced),
-// the 4 wave partials are combined through LDS in a fixed order (deterministic).
-__global__ void __launch_bounds__(256) ltrx_layernorm_bwd_reduce_kernel(const float* __restrict__ partial, int nblk,
-                                                                        int D, float* __restrict__ da,
-                                                                        float* __restrict__ db) {
-  __shared__ float sa[4][64];
-  __shared__ float sb[4][64];
+// One workgroup per 64 columns; its 16 waves split the partial rows, lanes own consecutive columns (coalesced),
+// the wave partials are combined through LDS in a fixed order (deterministic).
+__global__ void __launch_bounds__(1024) ltrx_layernorm_bwd_reduce_kernel(const float* __restrict__ partial, int nblk,
+                                                                         int D, float* __restrict__ da,
+                                                                         float* __restrict__ db) {
+  __shared__ float sa[16][64];
+  __shared__ float sb[16][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   float a = 0.f, b = 0.f;
   if (c < D) {
-    for (int k = w; k < nblk; k += 4) {
+    for (int k = w; k < nblk; k += 16) {
       a += partial[(size_t)k * 2 * D + c];
       b += partial[(size_t)k * 2 * D + D + c];
     }
@@ -259,8 +259,14 @@ __global__ void __launch_bounds__(256) ltrx_layernorm_bwd_reduce_kernel(const fl
   sb[w][lane] = b;
   __syncthreads();
   if (w == 0 && c < D) {
-    da[c] = (sa[0][lane] + sa[1][lane]) + (sa[2][lane] + sa[3][lane]);
-    db[c] = (sb[0][lane] + sb[1][lane]) + (sb[2][lane] + sb[3][lane]);
+    float ta = 0.f, tb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      ta += sa[k][lane];
+      tb += sb[k][lane];
+    }
+    da[c] = ta;
+    db[c] = tb;
   }
 }
 
@@ -271,7 +277,7 @@ static int ln_grid(int rows) {
 // the backward keeps per-block column partials: fewer, fatter blocks (each wave walks many rows)
 static int ln_bwd_grid(int rows) {
   int g = (rows + 15) / 16;
-  return g > 160 ? 160 : (g < 1 ? 1 : g);     // few, fat blocks: the second-stage reduce is a serial chain over them
+  return g > 320 ? 320 : (g < 1 ? 1 : g);
 }
 static int ln_fwd_vec_grid(int rows) {
   int g = (rows + 7) / 8;
@@ -331,7 +337,7 @@ extern "C" int ltrx_layernorm_bwd(const float* dy, const float* xsum, const floa
                        mean, rstd, dres_in, rows, D, eps, dx_out, (float*)ws);
   }
   LTRX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ltrx_layernorm_bwd_reduce_kernel, dim3((D + 63) / 64), dim3(256), 0, s, (const float*)ws, grid, D,
+  hipLaunchKernelGGL(ltrx_layernorm_bwd_reduce_kernel, dim3((D + 63) / 64), dim3(1024), 0, s, (const float*)ws, grid, D,
                      da_out, db_out);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
