@@ -2,7 +2,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from allrank_amd import _lib as LB
 lib = LB.lib()
-m, n, k = 15360, 2048, 512
+m, n, k = int(os.environ.get('GM', '15360')), 2048, 512
 A = torch.randn(m, k, device="cuda"); B = torch.randn(n, k, device="cuda") / k ** 0.5; bias = torch.randn(n, device="cuda")
 C = torch.empty(m, n, device="cuda")
 lib.ltrx_gemm_set_variant(int(os.environ.get("GV", "1")))
