@@ -9,7 +9,8 @@ A "step" is one pass of the hot path (allrank/training/train_utils.py:18-29: mas
 -> backward -> Adam step -> zero_grad) over one batch of synthetic WEB30K-shaped slates that is already resident in
 HBM.  Default workload = BASELINE.json configs[2], the one the north_star target is quoted on:
 F=136, slate_len 240, FCModel[512] -> 2-layer self-attention (d_model 512, h 8, d_ff 2048) -> ApproxNDCG, Adam 1e-3,
-dense slates, 64 slates per GPU (reproducibility/configs/*: batch_size 64, slate_length 240).
+dense slates, 256 slates per GPU by default (the reference's batch_size 64 point is measured too and reported as
+`value_at_64_slates_per_gpu`; reproducibility/configs/*: batch_size 64, slate_length 240).
 `--workload fc_listnet` runs configs[1] (FCModel[96] + ListNet).  Weak scaling: every rank gets its own
 `--slates-per-gpu` slates, losses are normalised by the global batch and gradients summed over RCCL.
 
@@ -32,6 +33,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: v_mfma_f32_32x32x16_bf16, dense (2:1-sparse marketing figure excluded)
 PEAK_HBM_GBPS = 8000.0
 
 WORKLOADS = {
@@ -76,6 +78,7 @@ def time_kernels(w, B, L, device):
 
     def ev(fn, iters=10):
         fn()
+        fn()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -86,6 +89,22 @@ def time_kernels(w, B, L, device):
         return a.elapsed_time(b) * 1e-3 / iters
 
     d, h = w["fc_sizes"][-1], w["h"]
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    if w["N"]:
+        # the dominant kernel of the step: the split-bf16 NT GEMM, timed at the FFN-1 shape [B*L, d] x [d_ff, d]^T
+        Mrows, Nn, Kk = B * L, w["d_ff"], d
+        A_ = torch.randn(Mrows, Kk, device=device)
+        W_ = torch.randn(Nn, Kk, device=device) / Kk ** 0.5
+        b_ = torch.randn(Nn, device=device)
+        C_ = torch.empty(Mrows, Nn, device=device)
+        st = LB.stream_of(A_)
+        t_g = ev(lambda: LB.check(lib.ltrx_gemm_nt(LB.ptr(A_), Kk, LB.ptr(W_), Kk, LB.ptr(C_), Nn, Mrows, Nn, Kk, LB.ptr(b_), 1,
+                                                   None, 0, 0, st), "gemm_nt"))
+        n_nt = 1 + 8 * w["N"] - 1          # fwd: fc + 4/layer; dgrad: 4/layer  (head GEMV is a separate kernel)
+        res["ltrx_gemm_nt_kernel<2,128,32> @FFN1"] = dict(sec=t_g, flops=2.0 * Mrows * Nn * Kk, launches_per_step=n_nt,
+                                                          shape=[Mrows, Nn, Kk])
+        del A_, W_, b_, C_
     y = torch.zeros(B, L, device=device)
     s = torch.randn(B, L, device=device, requires_grad=True)
     lossfn = getattr(E, w["loss"])
@@ -149,7 +168,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="attn_approxndcg", choices=sorted(WORKLOADS))
-    ap.add_argument("--slates-per-gpu", type=int, default=64)
+    ap.add_argument("--slates-per-gpu", type=int, default=256)
     ap.add_argument("--slate-len", type=int, default=240)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm", default="split_bf16", choices=["split_bf16", "split_bf16_strict", "hipblaslt"],
@@ -217,7 +236,21 @@ def main():
         kern = time_kernels(w, B, L, device)
         # dominant hand-written kernel by time per step
         name, k = max(kern.items(), key=lambda kv: kv[1]["sec"] * kv[1]["launches_per_step"])
-        if "flops" in k:
+        if name.startswith("ltrx_gemm"):
+            alg = k["flops"] / k["sec"] / 1e12            # algorithmic: the 2*M*N*K flop of the fp32 GEMM it replaces
+            traffic = None
+            try:                                           # HBM bytes per launch from the committed PMC passes (same shape only)
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
+                if [pm["shape"]["M"], pm["shape"]["N"], pm["shape"]["K"]] == k["shape"]:
+                    traffic = pm["derived"]["nt_hbm_read_bytes_corrected"] + pm["derived"]["nt_hbm_write_bytes"]
+            except Exception:
+                traffic = None
+            roof = dict(kernel=name, bound="mfma", achieved=round(alg, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=round(alg / PEAK_BF16_MFMA_TFLOPS, 4), traffic=traffic, avg_launch_us=round(k["sec"] * 1e6, 1),
+                        algorithmic_flops_per_launch=k["flops"], arithmetic="bf16 MFMA, fp32 accumulate, 3 products per fp32 product (split-bf16)",
+                        executed_mfma_tflops=round(3 * alg, 1), executed_frac=round(3 * alg / PEAK_BF16_MFMA_TFLOPS, 4),
+                        vs_exact_fp32_mfma_peak=round(alg / PEAK_FP32_MFMA_TFLOPS, 3))
+        elif "flops" in k:
             ach = k["flops"] / k["sec"] / 1e12
             roof = dict(kernel=name, bound="mfma", achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
@@ -232,7 +265,7 @@ def main():
             "metric": "slate-items/sec training (WEB30K synth, slate 240)", "value": round(value, 1),
             "unit": "slate-items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32 (dense projections: fp32-accurate split-bf16 on the bf16 MFMA; attention: exact fp32 MFMA)" if (args.engine == "fused" and args.gemm != "hipblaslt") else "f32", "data": "synthetic",
             "config": {"workload": w["desc"], "slates_per_gpu": B, "slate_len": L, "global_batch": B * world,
                        "optimizer": "Adam lr=1e-3", "engine": args.engine, "gemm": args.gemm if args.engine == "fused" else "hipblaslt", "parallelism": "slate-sharded dp%d" % world,
                        "train_flops_per_item": fl_item},
@@ -243,6 +276,20 @@ def main():
             "roofline": roof,
             "kernel_times_us": {n: round(v["sec"] * 1e6, 1) for n, v in kern.items()},
         }
+        if world == 1 and B != 64 and args.engine == "fused":
+            try:
+                m64 = build_model(w, device)
+                t64 = FusedTrainer(m64, w["loss"], {}, 64, L, lr=1e-3, world_size=1, use_graph=True, gemm=args.gemm)
+                for i in range(6):
+                    t64.step(x[:64], y[:64], idx[:64])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(20):
+                    t64.step(x[:64], y[:64], idx[:64])
+                torch.cuda.synchronize()
+                out["value_at_64_slates_per_gpu"] = round(20 * 64 * L / (time.perf_counter() - t0), 1)
+            except Exception as e:      # never let the side measurement break the contract line
+                out["value_at_64_slates_per_gpu"] = "failed: %r" % (e,)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, L)
         else:
