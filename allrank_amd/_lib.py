@@ -25,6 +25,7 @@ SIGNATURES = {
     "ltrx_lambdaloss_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_lambdaloss_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_neuralndcg_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ltrx_neuralndcg_force_general": (None, [_i]),
     "ltrx_neuralndcg_prepare": (_i, [_vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp]),
     "ltrx_neuralndcg_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_ndcg_workspace_bytes": (_sz, [_i, _i]),
@@ -32,6 +33,8 @@ SIGNATURES = {
     "ltrx_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_mha_set_mode": (None, [_i]),
+    "ltrx_mha_get_mode": (_i, []),
     "ltrx_mha_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "ltrx_mha_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltrx_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp, _f, _vp]),

@@ -381,9 +381,365 @@ __global__ void __launch_bounds__(1024) ltrx_neural_backward_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Register-resident fast path (n_valid <= 16 * NR, L <= 64 * NC; L <= 240 -> NR = 15, NC = 4):
+// a 1024-thread workgroup (16 waves) holds the whole n x n Sinkhorn state in VGPRs -- wave w owns rows
+// w, w+16, ..., lane l owns columns l, l+64, ... (60 registers at L = 240; 240^2 fp32 = 230 KB would not fit the
+// 160 KB LDS).  Row sums are lane-local adds + one wave shuffle reduction per row; column sums are per-wave partials
+// exchanged through a 16 KB LDS array and combined in a fixed order.  The backward kernel carries the adjoint the
+// same way (120 state registers).  Normalisers are applied as x * (1/c) (<= 1 ulp from the reference's x / c).
+// Same outputs / workspace contract as the general kernels above (cn, rn, res, S), so pick_iter and the batch-global
+// early-exit replay are shared.
+// ---------------------------------------------------------------------------------------------------------
+template <int NR, int NC>
+struct RegMat {
+  float v[NR][NC];
+};
+
+#define LTRX_FOR_RC for (int ri = 0; ri < NR; ++ri) for (int cj = 0; cj < NC; ++cj)
+
+template <int NR, int NC>
+__global__ void __launch_bounds__(1024) ltrx_neural_forward_reg_kernel(const float* __restrict__ y_pred,
+                                                                       const float* __restrict__ y_true, int L, float pad,
+                                                                       float tau, int max_iter, float* __restrict__ Sws,
+                                                                       float* __restrict__ cnws, float* __restrict__ rnws,
+                                                                       float* __restrict__ resws) {
+  extern __shared__ float lds[];
+  __shared__ float red[LTRX_MAX_WAVES];
+  __shared__ int redi[LTRX_MAX_WAVES];
+  __shared__ float colpart[16][64 * NC];
+  __shared__ float cvec[64 * NC];
+  const SlateLds t = carve_lds(lds, L);
+  const int b = blockIdx.x;
+  const int n = load_slate(t, y_pred + (size_t)b * L, y_true + (size_t)b * L, L, pad, 0, 0, redi);
+  float* S = Sws + (size_t)b * L * L;
+  float* cn = cnws + (size_t)b * max_iter * L;
+  float* rn = rnws + (size_t)b * max_iter * L;
+  float* res = resws + (size_t)b * max_iter;
+  const int lane = lane_id(), w = wave_id();
+  if (n == 0) {
+    for (int it = threadIdx.x; it < max_iter; it += blockDim.x) res[it] = 0.f;
+    return;
+  }
+  RegMat<NR, NC> m;
+  // ---- P0 = row softmax ----
+#pragma unroll
+  for (int ri = 0; ri < NR; ++ri) {
+    const int i = w + 16 * ri;
+    const float sc_i = (i < n) ? t.scal[i] : 0.f;
+    float z[NC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int cj = 0; cj < NC; ++cj) {
+      const int j = lane + 64 * cj;
+      z[cj] = (i < n && j < n) ? (sc_i * t.sc[j] - t.bs[j]) / tau : -INFINITY;
+      mx = fmaxf(mx, z[cj]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int cj = 0; cj < NC; ++cj) {
+      const float e = (z[cj] == -INFINITY) ? 0.f : expf(z[cj] - mx);
+      m.v[ri][cj] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = (sum > 0.f) ? 1.0f / sum : 0.f;
+#pragma unroll
+    for (int cj = 0; cj < NC; ++cj) m.v[ri][cj] = (sum > 0.f) ? m.v[ri][cj] / sum : 0.f;
+    (void)inv;
+    __builtin_amdgcn_sched_barrier(0);     // keep the rows sequential: interleaving all 15 blows the 128-VGPR budget
+  }
+  // ---- Sinkhorn ----
+  float rowres_prev = 0.f;
+  for (int it = 0; it <= max_iter; ++it) {
+    float* cn_it = cn + (size_t)it * L;
+    float* rn_it = rn + (size_t)it * L;
+    // column sums: per-wave partials -> LDS -> fixed-order combine
+#pragma unroll
+    for (int cj = 0; cj < NC; ++cj) {
+      float a = 0.f;
+#pragma unroll
+      for (int ri = 0; ri < NR; ++ri) a += m.v[ri][cj];
+      colpart[w][lane + 64 * cj] = a;
+    }
+    __syncthreads();
+    float cres = 0.f;
+    if (threadIdx.x < 64 * NC) {
+      const int j = threadIdx.x;
+      float c = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 16; ++ww) c += colpart[ww][j];
+      if (j < n) {
+        cres = fabsf(c - 1.0f);
+        if (it < max_iter) {
+          c = fmaxf(c, kSinkEps);
+          cn_it[j] = c;
+        }
+      }
+      cvec[j] = (j < n) ? 1.0f / c : 0.f;
+    }
+    if (it > 0) {
+      cres = block_max(cres, red);
+      if (threadIdx.x == 0) res[it - 1] = fmaxf(cres, rowres_prev);
+    }
+    if (it == max_iter) break;
+    __syncthreads();
+    float rcj[NC];
+#pragma unroll
+    for (int cj = 0; cj < NC; ++cj) rcj[cj] = cvec[lane + 64 * cj];
+    float rres = 0.f;
+#pragma unroll
+    for (int ri = 0; ri < NR; ++ri) {
+      const int i = w + 16 * ri;
+      float r = 0.f;
+#pragma unroll
+      for (int cj = 0; cj < NC; ++cj) {
+        m.v[ri][cj] *= rcj[cj];
+        r += m.v[ri][cj];
+      }
+      r = fmaxf(wave_sum(r), kSinkEps);
+      const float rr = 1.0f / r;
+#pragma unroll
+      for (int cj = 0; cj < NC; ++cj) m.v[ri][cj] *= rr;
+      if (i < n) {
+        if (lane == 0) rn_it[i] = r;
+        rres = fmaxf(rres, fabsf(r * rr - 1.0f));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    rowres_prev = block_max(rres, red);     // (barriers: colpart / cvec may be overwritten next iteration)
+  }
+  // ---- publish the final state for the backward kernel ----
+#pragma unroll
+  for (int ri = 0; ri < NR; ++ri) {
+    const int i = w + 16 * ri;
+#pragma unroll
+    for (int cj = 0; cj < NC; ++cj) {
+      const int j = lane + 64 * cj;
+      if (i < n && j < n) S[(size_t)i * n + j] = m.v[ri][cj];
+    }
+  }
+}
+
+// Backward: state m (NR x NC registers) + adjoint.  NCL of the NC adjoint column slots live in LDS (a_lds[slot][tid],
+// conflict-free: consecutive threads -> consecutive banks) so that the 1024-thread workgroup stays under its
+// 128-VGPR budget: at L = 240 (NR 15, NC 4, NCL 2) that is 60 + 30 registers + 123 KB of the 160 KB LDS.
+template <int NR, int NC, int NCL>
+__global__ void __launch_bounds__(1024) ltrx_neural_backward_reg_kernel(
+    const float* __restrict__ y_pred, const float* __restrict__ y_true, const float* __restrict__ idcg,
+    const float* __restrict__ nonzero_count, int L, float pad, float inv_tau, int gain_powered, int k, int max_iter,
+    const int* __restrict__ titer, const float* __restrict__ Sws, const float* __restrict__ cnws,
+    const float* __restrict__ rnws, float* __restrict__ per_ws, float* __restrict__ per_out, float* __restrict__ grad) {
+  constexpr int NCR = NC - NCL;                         // adjoint column slots kept in registers
+  __shared__ float tables[7 * 64 * NC];
+  __shared__ float red[LTRX_MAX_WAVES];
+  __shared__ int redi[LTRX_MAX_WAVES];
+  __shared__ float colpart[16][64 * NC];
+  __shared__ float cvec[64 * NC];
+  __shared__ float dvec[64 * NC];
+  __shared__ float a_lds[(NCL > 0 ? NR * NCL : 1) * 1024];
+  const SlateLds t = carve_lds(tables, L);
+  const int b = blockIdx.x;
+  const int n = load_slate(t, y_pred + (size_t)b * L, y_true + (size_t)b * L, L, pad, k, gain_powered, redi);
+  const float* S = Sws + (size_t)b * L * L;
+  const float* cn = cnws + (size_t)b * max_iter * L;
+  const float* rn = rnws + (size_t)b * max_iter * L;
+  const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+  const int T = titer[0];
+  float* gp = grad ? grad + (size_t)b * L : nullptr;
+  if (gp)
+    for (int i = tid; i < L; i += blockDim.x) gp[i] = 0.f;
+  const float id = idcg[b];
+  const float cnt = nonzero_count[0];
+  if (n == 0 || id == 0.f) {
+    if (tid == 0) {
+      per_ws[b] = 0.f;
+      if (per_out) per_out[b] = 0.f;
+    }
+    return;
+  }
+  float m[NR][NC];
+  float ar[NR][NCR > 0 ? NCR : 1];
+#define LTRX_A_GET(ri, cj) ((cj) < NCR ? ar[ri][(cj) < NCR ? (cj) : 0] : a_lds[((ri) * NCL + ((cj) - NCR)) * 1024 + tid])
+#define LTRX_A_SET(ri, cj, val)                                        \
+  do {                                                                 \
+    if ((cj) < NCR) ar[ri][(cj) < NCR ? (cj) : 0] = (val);             \
+    else a_lds[((ri) * NCL + ((cj) - NCR)) * 1024 + tid] = (val);      \
+  } while (0)
+#pragma unroll
+  for (int ri = 0; ri < NR; ++ri)
+#pragma unroll
+    for (int cj = 0; cj < NC; ++cj) {
+      const int i = w + 16 * ri, j = lane + 64 * cj;
+      m[ri][cj] = (i < n && j < n) ? S[(size_t)i * n + j] : 0.f;
+    }
+  // ---- rewind the steps max_iter-1 .. T ----
+  for (int it = max_iter - 1; it >= T; --it) {
+    const float* cn_it = cn + (size_t)it * L;
+    const float* rn_it = rn + (size_t)it * L;
+    float cj_[NC];
+#pragma unroll
+    for (int cj = 0; cj < NC; ++cj) cj_[cj] = (lane + 64 * cj < n) ? cn_it[lane + 64 * cj] : 0.f;
+#pragma unroll
+    for (int ri = 0; ri < NR; ++ri) {
+      const int i = w + 16 * ri;
+      const float r = (i < n) ? rn_it[i] : 0.f;
+#pragma unroll
+      for (int cj = 0; cj < NC; ++cj) m[ri][cj] = (m[ri][cj] * r) * cj_[cj];
+    }
+  }
+  // ---- read-out ----
+  float v = 0.f;
+  {
+    float gcj[NC];
+#pragma unroll
+    for (int cj = 0; cj < NC; ++cj) gcj[cj] = (lane + 64 * cj < n) ? t.gc[lane + 64 * cj] : 0.f;
+#pragma unroll
+    for (int ri = 0; ri < NR; ++ri) {
+      const int i = w + 16 * ri;
+      float acc = 0.f;
+#pragma unroll
+      for (int cj = 0; cj < NC; ++cj) acc += m[ri][cj] * gcj[cj];
+      acc = wave_sum(acc);
+      if (lane == 0 && i < n) v += t.dk[i] * acc;
+    }
+    v = block_sum(v, red);
+    const float value = v / (id + kSinkEps);
+    if (tid == 0) {
+      per_ws[b] = value;
+      if (per_out) per_out[b] = value;
+    }
+    if (!gp) return;
+    const float coef = -1.0f / (cnt * (id + kSinkEps));
+#pragma unroll
+    for (int ri = 0; ri < NR; ++ri) {
+      const int i = w + 16 * ri;
+      const float d = (i < n) ? coef * t.dk[i] : 0.f;
+#pragma unroll
+      for (int cj = 0; cj < NC; ++cj) LTRX_A_SET(ri, cj, d * gcj[cj]);
+    }
+  }
+  // ---- reverse Sinkhorn ----
+  for (int it = T - 1; it >= 0; --it) {
+    const float* cn_it = cn + (size_t)it * L;
+    const float* rn_it = rn + (size_t)it * L;
+    // row step:  Y2 = Y1 / r
+#pragma unroll
+    for (int ri = 0; ri < NR; ++ri) {
+      const int i = w + 16 * ri;
+      const float r = (i < n) ? rn_it[i] : 1.0f;
+      float av[NC];
+      float d = 0.f;
+#pragma unroll
+      for (int cj = 0; cj < NC; ++cj) {
+        av[cj] = LTRX_A_GET(ri, cj);
+        d += av[cj] * m[ri][cj];
+      }
+      d = (r > kSinkEps) ? wave_sum(d) : 0.f;
+      const float rr = 1.0f / r;
+#pragma unroll
+      for (int cj = 0; cj < NC; ++cj) {
+        const bool live = (i < n) && (lane + 64 * cj < n);
+        LTRX_A_SET(ri, cj, live ? (av[cj] - d) * rr : 0.f);
+        m[ri][cj] *= r;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // column step:  Y1 = X / c
+#pragma unroll
+    for (int cj = 0; cj < NC; ++cj) {
+      float d = 0.f;
+#pragma unroll
+      for (int ri = 0; ri < NR; ++ri) d += LTRX_A_GET(ri, cj) * m[ri][cj];
+      colpart[w][lane + 64 * cj] = d;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    if (tid < 64 * NC) {
+      float d = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 16; ++ww) d += colpart[ww][tid];
+      const float c = (tid < n) ? cn_it[tid] : 1.0f;
+      dvec[tid] = (c > kSinkEps) ? d : 0.f;
+      cvec[tid] = c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cj = 0; cj < NC; ++cj) {
+      const int j = lane + 64 * cj;
+      const float c = cvec[j], d = dvec[j];
+      const float rc = 1.0f / c;
+#pragma unroll
+      for (int ri = 0; ri < NR; ++ri) {
+        const bool live = (w + 16 * ri < n) && (j < n);
+        LTRX_A_SET(ri, cj, live ? (LTRX_A_GET(ri, cj) - d) * rc : 0.f);
+        m[ri][cj] *= c;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();      // colpart / cvec / dvec are rewritten by the next step
+  }
+  // ---- row softmax backward (m holds P0 again): gz = P0 (g0 - <g0, P0>) / tau ----
+#pragma unroll
+  for (int ri = 0; ri < NR; ++ri) {
+    float av[NC];
+    float d = 0.f;
+#pragma unroll
+    for (int cj = 0; cj < NC; ++cj) {
+      av[cj] = LTRX_A_GET(ri, cj);
+      d += av[cj] * m[ri][cj];
+    }
+    d = wave_sum(d);
+#pragma unroll
+    for (int cj = 0; cj < NC; ++cj) LTRX_A_SET(ri, cj, m[ri][cj] * (av[cj] - d) * inv_tau);
+  }
+  // ---- column sums of gz: weighted by the row scaling (direct term), then plain (Q) ----
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int cj = 0; cj < NC; ++cj) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int ri = 0; ri < NR; ++ri) {
+        const int i = w + 16 * ri;
+        const float g = LTRX_A_GET(ri, cj);
+        s1 += (pass == 0) ? ((i < n) ? g * t.scal[i] : 0.f) : g;
+      }
+      colpart[w][lane + 64 * cj] = s1;
+    }
+    __syncthreads();
+    if (tid < 64 * NC) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 16; ++ww) s1 += colpart[ww][tid];
+      if (pass == 0) cvec[tid] = s1; else dvec[tid] = s1;
+    }
+    __syncthreads();
+  }
+  for (int j = tid; j < n; j += blockDim.x) {
+    const float sj = t.sc[j];
+    float sgn_sum = 0.f, cross = 0.f;
+    for (int mm = 0; mm < n; ++mm) {
+      const float dlt = sj - t.sc[mm];
+      const float sg = (dlt > 0.f) ? 1.0f : ((dlt < 0.f) ? -1.0f : 0.f);
+      sgn_sum += sg;
+      cross -= dvec[mm] * sg;
+    }
+    gp[t.vidx[j]] = cvec[j] - dvec[j] * sgn_sum + cross;
+  }
+#undef LTRX_A_GET
+#undef LTRX_A_SET
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
+// test hook: force the general (L2-streaming) kernels even when the register-resident fast path applies
+static int g_neural_force_general = 0;
+extern "C" void ltrx_neuralndcg_force_general(int on) { g_neural_force_general = on ? 1 : 0; }
+
 extern "C" size_t ltrx_neuralndcg_workspace_bytes(int B, int L, int max_iter) {
   if (B <= 0 || L <= 0 || max_iter < 0) return 0;
   const int mi = max_iter > 0 ? max_iter : 1;
@@ -417,16 +773,40 @@ extern "C" int ltrx_neuralndcg_fwd_bwd(const float* y_pred, const float* y_true,
   // neuralNDCG.py:48-49 vs :118-124: plain uses 2^y-1 or y (padded -> 0 either way); transposed uses y for the
   // non-powered case, whose padded entries meet zero columns -- identical on the valid block.
   (void)transposed;
-  const int threads = L <= 256 ? 256 : (L <= 512 ? 512 : 1024);
+  const int threads = 1024;   // 16 waves per slate
   const size_t lds = LTRX_NEURAL_LDS_FLOATS(L) * sizeof(float);
-  hipLaunchKernelGGL(ltrx_neural_forward_kernel, dim3(B), dim3(threads), lds, s, y_pred, y_true, L, pad_value,
-                     temperature, max_iter, w.S, w.cn, w.rn, w.res);
+  const bool fast = (L <= 240) && !g_neural_force_general;
+#define LTRX_NEURAL_FWD(NR, NC)                                                                                          \
+  hipLaunchKernelGGL((ltrx_neural_forward_reg_kernel<NR, NC>), dim3(B), dim3(1024), lds, s, y_pred, y_true, L, pad_value, \
+                     temperature, max_iter, w.S, w.cn, w.rn, w.res)
+  if (fast) {
+    if (L <= 64) LTRX_NEURAL_FWD(4, 1);
+    else if (L <= 128) LTRX_NEURAL_FWD(8, 2);
+    else if (L <= 192) LTRX_NEURAL_FWD(12, 3);
+    else LTRX_NEURAL_FWD(15, 4);
+  } else {
+    hipLaunchKernelGGL(ltrx_neural_forward_kernel, dim3(B), dim3(threads), lds, s, y_pred, y_true, L, pad_value,
+                       temperature, max_iter, w.S, w.cn, w.rn, w.res);
+  }
+#undef LTRX_NEURAL_FWD
   LTRX_LAUNCH_CHECK();
   hipLaunchKernelGGL(ltrx_neural_pick_iter_kernel, dim3(1), dim3(256), 0, s, w.res, B, max_iter, tol, w.titer, iters_out);
   LTRX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ltrx_neural_backward_kernel, dim3(B), dim3(threads), lds, s, y_pred, y_true, idcg, nonzero_count, L,
-                     pad_value, 1.0f / temperature, powered_relevancies, k, max_iter, w.titer, w.S, w.A, w.cn, w.rn,
-                     w.per, per_slate_out, grad_out);
+#define LTRX_NEURAL_BWD(NR, NC, NCL)                                                                                      \
+  hipLaunchKernelGGL((ltrx_neural_backward_reg_kernel<NR, NC, NCL>), dim3(B), dim3(1024), 0, s, y_pred, y_true, idcg,      \
+                     nonzero_count, L, pad_value, 1.0f / temperature, powered_relevancies, k, max_iter, w.titer, w.S, w.cn, \
+                     w.rn, w.per, per_slate_out, grad_out)
+  if (fast) {
+    if (L <= 64) LTRX_NEURAL_BWD(4, 1, 0);
+    else if (L <= 128) LTRX_NEURAL_BWD(8, 2, 0);
+    else if (L <= 192) LTRX_NEURAL_BWD(12, 3, 0);
+    else LTRX_NEURAL_BWD(15, 4, 2);
+  } else {
+    hipLaunchKernelGGL(ltrx_neural_backward_kernel, dim3(B), dim3(threads), lds, s, y_pred, y_true, idcg, nonzero_count, L,
+                       pad_value, 1.0f / temperature, powered_relevancies, k, max_iter, w.titer, w.S, w.A, w.cn, w.rn,
+                       w.per, per_slate_out, grad_out);
+  }
+#undef LTRX_NEURAL_BWD
   LTRX_LAUNCH_CHECK();
   // loss = -sum_b value_b / nonzero_count  (device scalar) -> two tiny kernels: sum, then scale
   int rc = ltrx_launch_finalize_sum(w.per, B, -1.0f, loss_out, s);

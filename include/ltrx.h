@@ -102,6 +102,8 @@ int ltrx_lambdaloss_fwd_bwd(const float* y_pred, const float* y_true, int B, int
  * powered_relevancies == 0, neuralNDCG.py:126).  k <= 0 means k=None.  The Sinkhorn early exit
  * (loss_utils.py:25) is batch-global as in the reference; iters_out[1] (int32, optional) = iterations used. */
 size_t ltrx_neuralndcg_workspace_bytes(int B, int L, int max_iter);
+/* test hook: 1 = always use the general L2-streaming kernels (default 0: register-resident fast path when L <= 240) */
+void ltrx_neuralndcg_force_general(int on);
 int ltrx_neuralndcg_prepare(const float* y_true, int B, int L, float pad_value, int k, int idcg_powered,
                             float* idcg_out, float* nonzero_count_out, void* ws, ltrx_stream_t stream);
 int ltrx_neuralndcg_fwd_bwd(const float* y_pred, const float* y_true, const float* idcg, const float* nonzero_count,
@@ -140,6 +142,10 @@ int ltrx_layernorm_bwd(const float* dy, const float* xsum, const float* a, const
  * softmax over keys; dropout is not applied (p=0 / eval).  lse_out[B,h,L] = log-sum-exp of the
  * scaled, masked scores (the only tensor saved for backward).  fp32 in/out; contractions on the fp32 MFMA
  * (v_mfma_f32_32x32x2_f32), exact fp32 products.  d_k % 4 == 0, d_k <= 128 (zero-padded to a multiple of 32). */
+/* precision of the attention contractions: 0 (default) = exact fp32 MFMA (bit-exact fp32 products, error ~5e-7),
+ * 1 = split-bf16 on the bf16 MFMA (3 products per fp32 product; error ~1e-5 after the softmax exponential). */
+void ltrx_mha_set_mode(int mode);
+int ltrx_mha_get_mode(void);
 int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L, int h,
                  int d_k, int row_stride, float* o, int o_row_stride, float* lse_out, ltrx_stream_t stream);
 /* backward: dq,dk,dv from do; delta_ws[B,h,L] scratch (rowsum(do*o)). */

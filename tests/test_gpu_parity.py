@@ -223,10 +223,12 @@ def test_layernorm_forward_backward():
         assert np.abs(bt.grad.cpu().numpy() - grads["n.b_2"]).max() < 1e-4 * max(1.0, np.abs(grads["n.b_2"]).max())
 
 
+@pytest.mark.parametrize("mode", [0, 1])      # 0 = exact fp32 MFMA (default), 1 = split-bf16 MFMA
 @pytest.mark.parametrize("B,L,h,dk", [(2, 240, 8, 64), (3, 70, 4, 8), (2, 33, 1, 96), (1, 300, 2, 32), (2, 129, 1, 128),
                                       (2, 64, 2, 72)])
-def test_attention_forward_backward(B, L, h, dk):
-    from allrank_amd import ops
+def test_attention_forward_backward(B, L, h, dk, mode):
+    from allrank_amd import ops, _lib as LB
+    LB.lib().ltrx_mha_set_mode(mode)
     rng = np.random.default_rng(L * 7 + dk)
     d = h * dk
     qkv = rng.standard_normal((B, L, 3 * d)).astype(np.float32)
@@ -255,7 +257,8 @@ def test_attention_forward_backward(B, L, h, dk):
     g = t.grad.cpu().numpy()
     for name, ref, sl in (("dq", gq, slice(0, d)), ("dk", gk, slice(d, 2 * d)), ("dv", gv, slice(2 * d, 3 * d))):
         err[name] = float(np.abs(g[:, :, sl] - unheads(ref)).max() / max(np.abs(ref).max(), 1e-6))
-    _log("attention_%d_%d_%d_%d" % (B, L, h, dk), err)
+    _log("attention_%d_%d_%d_%d_mode%d" % (B, L, h, dk, mode), err)
+    LB.lib().ltrx_mha_set_mode(0)
     assert err["o"] < 2e-5 and err["dq"] < 1e-4 and err["dk"] < 1e-4 and err["dv"] < 1e-4, err
     assert np.all(g[:, :, d:][np.broadcast_to(mask[:, :, None], (B, L, 2 * d))] == 0)   # padded keys get exactly 0
 
@@ -469,3 +472,24 @@ def test_sharded_step_equals_single_rank_step():
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     assert "EQUIV_OK" in out.stdout, out.stdout[-2000:]
+
+
+def test_neuralndcg_register_path_equals_general_path():
+    """the register-resident fast path (L <= 240) and the general L2-streaming kernels agree with each other and the oracle."""
+    from allrank_amd import losses as E, _lib as LB
+    from tests.golden.make_inputs import make_inputs
+    lib = LB.lib()
+    for (B, L, seed) in [(16, 240, 21), (9, 100, 22), (5, 64, 23), (4, 130, 24)]:
+        s, y = make_inputs(B, L, seed)
+        out = {}
+        for force in (0, 1):
+            lib.ltrx_neuralndcg_force_general(force)
+            sp = _t(s, True)
+            l = E.neuralNDCG(sp, _t(y), temperature=0.7, k=20)
+            l.backward()
+            out[force] = (float(l.item()), sp.grad.cpu().numpy())
+        lib.ltrx_neuralndcg_force_general(0)
+        ro, rg = O.neuralndcg(s, y, temperature=0.7, k=20)[:2]
+        for force in (0, 1):
+            assert close(out[force][0], ro, rtol=2e-5) and grad_close(out[force][1], rg, rtol=5e-4), (B, L, force, out[force][0], ro)
+        assert abs(out[0][0] - out[1][0]) < 1e-6
