@@ -58,6 +58,36 @@ __device__ __forceinline__ void stage_tile(float* tile, const float* __restrict_
   }
 }
 
+// Split staging for software prefetch: tile_gload issues the global loads of a [32][dk] slab into registers (DKP/32
+// float4 per thread), tile_sstore writes them to the LDS tile later -- the loads of tile t+1 fly behind the MFMAs of
+// tile t instead of being waited for right after their issue.
+template <int DKP>
+struct TileRegs {
+  float4 v[DKP / 32];
+};
+template <int DKP>
+__device__ __forceinline__ void tile_gload(TileRegs<DKP>& r, const float* __restrict__ base, int row0, int nrows, int dk,
+                                           size_t rs) {
+  constexpr int C4 = DKP / 4;
+#pragma unroll
+  for (int p = 0; p < DKP / 32; ++p) {
+    const int idx = threadIdx.x + 256 * p;
+    const int row = idx / C4, c = (idx % C4) * 4;
+    r.v[p] = (row0 + row < nrows && c < dk) ? *reinterpret_cast<const float4*>(base + (size_t)(row0 + row) * rs + c)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int DKP>
+__device__ __forceinline__ void tile_sstore(float* tile, const TileRegs<DKP>& r) {
+  constexpr int C4 = DKP / 4;
+#pragma unroll
+  for (int p = 0; p < DKP / 32; ++p) {
+    const int idx = threadIdx.x + 256 * p;
+    const int row = idx / C4, c = (idx % C4) * 4;
+    *reinterpret_cast<float4*>(tile + row * Tile<DKP>::LDT + c) = r.v[p];
+  }
+}
+
 // FIXED fragment of the wave: lane keeps FIXED[row0 + (l&31)][half*DKP/2 + t], t = 0..DKP/2-1 (zero beyond nrows/dk).
 template <int DKP>
 __device__ __forceinline__ void load_fixed(float (&frag)[DKP / 2], const float* __restrict__ base, int row0, int nrows,
@@ -128,6 +158,26 @@ __device__ __forceinline__ void store_rows(float* __restrict__ base, int row0, i
   }
 }
 
+// Dropout on the attention probabilities (transformer.py:154-155): a counter-based generator -- the keep decision of
+// element (slate*head, query, key) is a pure function of (seed, index), so the forward and both backward kernels
+// regenerate the same mask without storing it.  murmur3 finaliser over the folded 64-bit element index.
+struct DropCfg {
+  uint32_t seed;
+  uint32_t thresh;     // keep iff (hash >> 8) >= thresh,  thresh = p * 2^24
+  float inv_keep;      // 1 / (1 - p)
+};
+__device__ __forceinline__ float drop_scale(const DropCfg& d, uint32_t bh, int L, int qrow, int key) {
+  if (d.thresh == 0u) return 1.0f;
+  const uint64_t idx = ((uint64_t)bh * (uint64_t)L + (uint64_t)qrow) * (uint64_t)L + (uint64_t)key;
+  uint32_t x = (uint32_t)idx ^ ((uint32_t)(idx >> 32) * 0x9E3779B9u) ^ d.seed;
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return ((x >> 8) >= d.thresh) ? d.inv_keep : 0.f;
+}
+
 template <int DKP>
 __device__ __forceinline__ void zero_acc(f32x16 (&o)[DKP / 32]) {
 #pragma unroll
@@ -146,7 +196,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
                                                               const float* __restrict__ v,
                                                               const uint8_t* __restrict__ kpm, int L, int h, int dk,
                                                               int rs, float* __restrict__ o, int ors,
-                                                              float* __restrict__ lse, float scale) {
+                                                              float* __restrict__ lse, float scale, DropCfg drop) {
   __shared__ __attribute__((aligned(16))) float ktile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float vtile[Tile<DKP>::FLOATS];
   __shared__ float kmask[32];
@@ -165,15 +215,22 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
   float m = -INFINITY, l = 0.f;
 
   const int nkt = (L + 31) / 32;
+  TileRegs<DKP> kr, vr;
+  tile_gload<DKP>(kr, kb, 0, L, dk, rs);
+  tile_gload<DKP>(vr, vb, 0, L, dk, rs);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();   // previous tile fully consumed
-    stage_tile<DKP>(ktile, kb, kt * 32, L, dk, rs);
-    stage_tile<DKP>(vtile, vb, kt * 32, L, dk, rs);
+    tile_sstore<DKP>(ktile, kr);
+    tile_sstore<DKP>(vtile, vr);
     if (threadIdx.x < 32) {
       const int key = kt * 32 + threadIdx.x;
       kmask[threadIdx.x] = (key >= L || kpm[slate + key]) ? 1.f : 0.f;
     }
     __syncthreads();
+    if (kt + 1 < nkt) {   // prefetch: in flight during this tile's MFMAs
+      tile_gload<DKP>(kr, kb, (kt + 1) * 32, L, dk, rs);
+      tile_gload<DKP>(vr, vb, (kt + 1) * 32, L, dk, rs);
+    }
     f32x16 s = rows_x_fixed<DKP>(ktile, qfrag);
     float mt = -INFINITY;
 #pragma unroll
@@ -191,7 +248,12 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
       p[r] = (s[r] == -INFINITY) ? 0.f : expf(s[r] - mn);
       ps += p[r];
     }
-    l = l * alpha + ps;
+    l = l * alpha + ps;                      // the softmax normaliser counts every key (dropout comes after softmax)
+    if (drop.thresh != 0u) {
+      const int qd = q0 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[r] *= drop_scale(drop, blockIdx.y, L, qd, kt * 32 + rowmap(r, half));
+    }
 #pragma unroll
     for (int ct = 0; ct < DKP / 32; ++ct)
 #pragma unroll
@@ -214,7 +276,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ kpm, const float* __restrict__ o, const float* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ delta, int L, int h, int dk, int rs, int ors,
-    float* __restrict__ dq, int drs, float scale) {
+    float* __restrict__ dq, int drs, float scale, DropCfg drop) {
   __shared__ __attribute__((aligned(16))) float ktile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float vtile[Tile<DKP>::FLOATS];
   __shared__ float kmask[32];
@@ -244,22 +306,30 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
   f32x16 dqacc[DKP / 32];
   zero_acc<DKP>(dqacc);
   const int nkt = (L + 31) / 32;
+  TileRegs<DKP> kr, vr;
+  tile_gload<DKP>(kr, kb, 0, L, dk, rs);
+  tile_gload<DKP>(vr, vb, 0, L, dk, rs);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
-    stage_tile<DKP>(ktile, kb, kt * 32, L, dk, rs);
-    stage_tile<DKP>(vtile, vb, kt * 32, L, dk, rs);
+    tile_sstore<DKP>(ktile, kr);
+    tile_sstore<DKP>(vtile, vr);
     if (threadIdx.x < 32) {
       const int key = kt * 32 + threadIdx.x;
       kmask[threadIdx.x] = (key >= L || kpm[slate + key]) ? 1.f : 0.f;
     }
     __syncthreads();
+    if (kt + 1 < nkt) {
+      tile_gload<DKP>(kr, kb, (kt + 1) * 32, L, dk, rs);
+      tile_gload<DKP>(vr, vb, (kt + 1) * 32, L, dk, rs);
+    }
     const f32x16 s = rows_x_fixed<DKP>(ktile, qfrag);
     const f32x16 dp = rows_x_fixed<DKP>(vtile, dofrag);
     f32x16 ds;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float p = (kmask[rowmap(r, half)] != 0.f) ? 0.f : expf(s[r] * scale - lse_q);
-      ds[r] = p * (dp[r] - del_q) * scale;
+      const float dm = (drop.thresh != 0u) ? drop_scale(drop, blockIdx.y, L, qrow, kt * 32 + rowmap(r, half)) : 1.0f;
+      ds[r] = p * (dp[r] * dm - del_q) * scale;
     }
     cols_x_p<DKP>(ktile, ds, dqacc);
   }
@@ -274,7 +344,7 @@ __global__ void __launch_bounds__(256) ltrx_mha_bwd_dkdv_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ kpm, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, int L, int h, int dk, int rs, int ors, float* __restrict__ dkout,
-    float* __restrict__ dvout, int drs, float scale) {
+    float* __restrict__ dvout, int drs, float scale, DropCfg drop) {
   __shared__ __attribute__((aligned(16))) float qtile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float dotile[Tile<DKP>::FLOATS];
   __shared__ float lse_t[32];
@@ -295,25 +365,41 @@ __global__ void __launch_bounds__(256) ltrx_mha_bwd_dkdv_kernel(
   zero_acc<DKP>(dvacc);
   const size_t statb = ((size_t)b * h + head) * L;
   const int nqt = (L + 31) / 32;
+  TileRegs<DKP> qr, dor;
+  tile_gload<DKP>(qr, qb, 0, L, dk, rs);
+  tile_gload<DKP>(dor, dob, 0, L, dk, ors);
   for (int qt = 0; qt < nqt; ++qt) {
     __syncthreads();
-    stage_tile<DKP>(qtile, qb, qt * 32, L, dk, rs);
-    stage_tile<DKP>(dotile, dob, qt * 32, L, dk, ors);
+    tile_sstore<DKP>(qtile, qr);
+    tile_sstore<DKP>(dotile, dor);
     if (threadIdx.x < 32) {
       const int qrow = qt * 32 + threadIdx.x;
       lse_t[threadIdx.x] = (qrow < L) ? lse[statb + qrow] : INFINITY;   // +inf -> P = exp(-inf) = 0 for rows >= L
       del_t[threadIdx.x] = (qrow < L) ? delta[statb + qrow] : 0.f;
     }
     __syncthreads();
+    if (qt + 1 < nqt) {
+      tile_gload<DKP>(qr, qb, (qt + 1) * 32, L, dk, rs);
+      tile_gload<DKP>(dor, dob, (qt + 1) * 32, L, dk, ors);
+    }
     const f32x16 s = rows_x_fixed<DKP>(qtile, kfrag);     // S[q = row(r,half)][key = l&31]
     f32x16 p;
 #pragma unroll
     for (int r = 0; r < 16; ++r) p[r] = key_masked ? 0.f : expf(s[r] * scale - lse_t[rowmap(r, half)]);
-    cols_x_p<DKP>(dotile, p, dvacc);                       // dV^T[c][key] += sum_q dO[q][c] P[q][key]
-    const f32x16 dp = rows_x_fixed<DKP>(dotile, vfrag);    // dP[q][key]
+    f32x16 dm;                                             // dropout keep-scale of (q, key), 1 when dropout is off
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      dm[r] = (drop.thresh != 0u) ? drop_scale(drop, blockIdx.y, L, qt * 32 + rowmap(r, half), key) : 1.0f;
+    {
+      f32x16 pd;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pd[r] = p[r] * dm[r];
+      cols_x_p<DKP>(dotile, pd, dvacc);                    // dV^T[c][key] += sum_q dO[q][c] (P*M)[q][key]
+    }
+    const f32x16 dp = rows_x_fixed<DKP>(dotile, vfrag);    // dP[q][key] (before the dropout mask)
     f32x16 ds;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ds[r] = p[r] * (dp[r] - del_t[rowmap(r, half)]) * scale;
+    for (int r = 0; r < 16; ++r) ds[r] = p[r] * (dp[r] * dm[r] - del_t[rowmap(r, half)]) * scale;
     cols_x_p<DKP>(qtile, ds, dkacc);                       // dK^T[c][key] += sum_q Q[q][c] dS[q][key]
   }
   store_rows<DKP>(dkout + slate * drs + (size_t)head * dk, k0, L, dk, drs, dkacc, 1.0f);
@@ -367,20 +453,29 @@ static int mha_check(int B, int L, int h, int dk, int rs, int ors) {
     else { CALL(128); }             \
   } while (0)
 
+static DropCfg make_drop(float p_drop, uint32_t seed) {
+  DropCfg d;
+  d.seed = seed;
+  d.thresh = (p_drop > 0.f) ? (uint32_t)(p_drop * 16777216.0f) : 0u;
+  d.inv_keep = (p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
+  return d;
+}
+
 extern "C" int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L,
-                            int h, int d_k, int row_stride, float* o, int o_row_stride, float* lse_out,
-                            ltrx_stream_t stream) {
-  if (!q || !k || !v || !key_pad_mask || !o || !lse_out) return LTRX_EINVAL;
+                            int h, int d_k, int row_stride, float* o, int o_row_stride, float* lse_out, float p_drop,
+                            uint32_t seed, ltrx_stream_t stream) {
+  if (!q || !k || !v || !key_pad_mask || !o || !lse_out || !(p_drop >= 0.f) || p_drop >= 1.f) return LTRX_EINVAL;
   int rc = mha_check(B, L, h, d_k, row_stride, o_row_stride);
   if (rc != LTRX_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (g_mha_mode == 1)
+  if (g_mha_mode == 1 && p_drop == 0.f)      // (dropout is implemented in the exact-fp32 kernels only)
     return ltrx_mha_fwd_bf16_launch(q, k, v, key_pad_mask, B, L, h, d_k, row_stride, o, o_row_stride, lse_out, s);
+  const DropCfg drop = make_drop(p_drop, seed);
   const dim3 grid((L + 127) / 128, B * h);
   const float scale = 1.0f / sqrtf((float)d_k);
 #define CALL(DKP)                                                                                                 \
   hipLaunchKernelGGL(ltrx_mha_fwd_kernel<DKP>, grid, dim3(256), 0, s, q, k, v, key_pad_mask, L, h, d_k, row_stride, o, \
-                     o_row_stride, lse_out, scale)
+                     o_row_stride, lse_out, scale, drop)
   LTRX_DKP_DISPATCH(d_k, CALL);
 #undef CALL
   LTRX_LAUNCH_CHECK();
@@ -394,28 +489,30 @@ extern "C" size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h) {
 
 extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, const float* o,
                             const float* dout, const float* lse, int B, int L, int h, int d_k, int row_stride,
-                            int o_row_stride, float* dq, float* dk, float* dv, int d_row_stride, void* ws,
-                            ltrx_stream_t stream) {
+                            int o_row_stride, float* dq, float* dk, float* dv, int d_row_stride, float p_drop,
+                            uint32_t seed, void* ws, ltrx_stream_t stream) {
   if (!q || !k || !v || !key_pad_mask || !o || !dout || !lse || !dq || !dk || !dv || !ws) return LTRX_EINVAL;
+  if (!(p_drop >= 0.f) || p_drop >= 1.f) return LTRX_EINVAL;
   int rc = mha_check(B, L, h, d_k, row_stride, o_row_stride);
   if (rc != LTRX_OK) return rc;
   if (d_row_stride % 4 != 0 || d_row_stride < h * d_k) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* delta = (float*)ws;
-  if (g_mha_mode == 1)
+  if (g_mha_mode == 1 && p_drop == 0.f)
     return ltrx_mha_bwd_bf16_launch(q, k, v, key_pad_mask, o, dout, lse, B, L, h, d_k, row_stride, o_row_stride, dq, dk, dv,
                                     d_row_stride, delta, s);
+  const DropCfg drop = make_drop(p_drop, seed);
   const dim3 grid((L + 127) / 128, B * h);
   const float scale = 1.0f / sqrtf((float)d_k);
 #define CALLQ(DKP)                                                                                                   \
   hipLaunchKernelGGL(ltrx_mha_bwd_dq_kernel<DKP>, grid, dim3(256), 0, s, q, k, v, key_pad_mask, o, dout, lse, delta, L, h, \
-                     d_k, row_stride, o_row_stride, dq, d_row_stride, scale)
+                     d_k, row_stride, o_row_stride, dq, d_row_stride, scale, drop)
   LTRX_DKP_DISPATCH(d_k, CALLQ);
 #undef CALLQ
   LTRX_LAUNCH_CHECK();
 #define CALLK(DKP)                                                                                                     \
   hipLaunchKernelGGL(ltrx_mha_bwd_dkdv_kernel<DKP>, grid, dim3(256), 0, s, q, k, v, key_pad_mask, dout, lse, delta, L, h, \
-                     d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale)
+                     d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale, drop)
   LTRX_DKP_DISPATCH(d_k, CALLK);
 #undef CALLK
   LTRX_LAUNCH_CHECK();

@@ -324,7 +324,7 @@ class FusedTrainer(object):
             self._lin_fwd(st["xn0"], st["wqkv"], st["bqkv"], st["qkv"])
             qkv = st["qkv"]
             self.LB.check(lib.ltrx_mha_fwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(self.mask), B, L, self.h,
-                                           d // self.h, 3 * d, P(st["o"]), d, P(st["lse"]), self._st()), "mha_fwd")
+                                           d // self.h, 3 * d, P(st["o"]), d, P(st["lse"]), 0.0, 0, self._st()), "mha_fwd")
             lo = lay.self_attn.linears[3]
             self._lin_fwd(st["o"], W(lo.weight), W(lo.bias), self.branch)
             self._ln_fwd(x, self.branch, W(n1.a_2), W(n1.b_2), st["x1"], st["xn1"], st["mean1"], st["rstd1"])
@@ -371,7 +371,7 @@ class FusedTrainer(object):
                 qkv, dq = st["qkv"], self.dqkv
                 self.LB.check(lib.ltrx_mha_bwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(self.mask), P(st["o"]),
                                                P(self.d_o), P(st["lse"]), B, L, self.h, d // self.h, 3 * d, d, P(dq),
-                                               dq.data_ptr() + 4 * d, dq.data_ptr() + 8 * d, 3 * d, P(self.ws_mha), self._st()),
+                                               dq.data_ptr() + 4 * d, dq.data_ptr() + 8 * d, 3 * d, 0.0, 0, P(self.ws_mha), self._st()),
                               "mha_bwd")
                 self._lin_wgrad(dq, st["xn0"], st["gwqkv"], st["gbqkv"])
                 self._lin_dgrad(dq, st["wqkv"], st.get("wqkvT"), self.tmp_d)

@@ -11,8 +11,8 @@ Arithmetic: the per-slate self-attention (flash-style, fp32 MFMA) and the custom
 run in hand-written HIP kernels (allrank_amd/ops.py -> libltrx.so).  The dense projections are plain library GEMMs
 (torch.nn.functional.linear -> hipBLASLt), with Q, K and V computed by ONE [3d, d] GEMM so that the attention
 kernel reads q/k/v as strided views of a single buffer.  Dropout follows torch semantics (nn.Dropout on the
-residual branches / activations); the attention-probability dropout of transformer.py:154-155 is only honoured for
-p == 0 or eval() -- with p > 0 in train() it raises, rather than silently training a different model.
+residual branches / activations); the attention-probability dropout of transformer.py:154-155 happens inside the fused
+attention kernel (counter-based mask regenerated in the backward; same distribution, different random stream).
 """
 import copy
 
@@ -96,9 +96,6 @@ class MultiHeadedAttention(nn.Module):
     def forward(self, query, key, value, mask=None):
         if query is not key or key is not value:
             raise NotImplementedError("only self-attention (query is key is value) is on the MI355X hot path")
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("attention-probability dropout > 0 in train() is not implemented in the fused "
-                                      "kernel; configure the transformer with dropout 0 for the attention block")
         B, SL, d = query.shape
         if mask is None:
             mask = torch.zeros((B, SL), dtype=torch.bool, device=query.device)
@@ -106,7 +103,8 @@ class MultiHeadedAttention(nn.Module):
         w = torch.cat([self.linears[i].weight for i in range(3)], dim=0)
         b = torch.cat([self.linears[i].bias for i in range(3)], dim=0)
         qkv = F.linear(query, w, b)                                        # [B, L, 3d]
-        o = ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], mask, self.h)
+        p_drop = self.dropout.p if self.training else 0.0          # transformer.py:154-155, inside the fused kernel
+        o = ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], mask, self.h, p_drop)
         return self.linears[3](o)
 
 
@@ -159,14 +157,59 @@ class Encoder(nn.Module):
         return self.norm(x)
 
 
+class FixedPositionalEncoding(nn.Module):
+    """allrank/models/positional.py:15-50: sin/cos table of max_len rows + one all-zero padding row; the original rank
+    of an item (``indices``) selects the row, padded items and ranks beyond max_len get the zero row;
+    x <- sqrt(d_model) * x + pe[row].  (Plain torch gather: one pass over [B,L,d])"""
+
+    def __init__(self, d_model, max_len=5000):
+        super(FixedPositionalEncoding, self).__init__()
+        import math
+        pos = torch.arange(0.0, max_len).unsqueeze(1)
+        freq = torch.exp(torch.arange(0.0, d_model, 2) * -(math.log(10000.0) / d_model))
+        table = torch.zeros(max_len + 1, d_model)
+        table[:max_len, 0::2] = torch.sin(pos * freq)
+        table[:max_len, 1::2] = torch.cos(pos * freq)
+        self.padding_idx = max_len
+        self.register_buffer("pe", table)
+
+    def forward(self, x, mask, indices):
+        rows = indices.masked_fill(mask, self.padding_idx).clamp(max=self.padding_idx)
+        return (self.pe.shape[1] ** 0.5) * x + self.pe[rows]
+
+
+class LearnedPositionalEncoding(nn.Module):
+    """allrank/models/positional.py:53-77: an Embedding of max_len + 1 rows whose last row is the padding row."""
+
+    def __init__(self, d_model, max_len=5000):
+        super(LearnedPositionalEncoding, self).__init__()
+        self.pe = nn.Embedding(max_len + 1, d_model, padding_idx=-1)
+
+    def forward(self, x, mask, indices):
+        pad = self.pe.padding_idx
+        rows = indices.masked_fill(mask, pad).clamp(max=pad)
+        return (self.pe.embedding_dim ** 0.5) * x + self.pe(rows)
+
+
+def _make_positional_encoding(d_model, positional_encoding):
+    """positional.py:80-94; accepts the reference's attrs PositionalEncoding object or a dict."""
+    if positional_encoding is None:
+        return None
+    get = positional_encoding.get if isinstance(positional_encoding, dict) else lambda k: getattr(positional_encoding, k)
+    strategy, max_indices = get("strategy"), get("max_indices")
+    if strategy == "fixed":
+        return FixedPositionalEncoding(d_model, max_len=max_indices)
+    if strategy == "learned":
+        return LearnedPositionalEncoding(d_model, max_len=max_indices)
+    raise ValueError("Invalid positional encoding type: {}".format(strategy))        # positional.py:94
+
+
 def make_transformer(N=6, d_ff=2048, h=8, dropout=0.1, n_features=136, positional_encoding=None):
-    """transformer.py:230-247"""
-    if positional_encoding is not None:
-        raise NotImplementedError("positional encodings (allrank/models/positional.py) are the next scope row "
-                                  "(SURVEY.md §8f #3); every shipped config uses positional_encoding: null")
+    """transformer.py:230-247 (same construction order: attention, feed-forward, position, encoder -> same RNG draws)"""
     attn = MultiHeadedAttention(h, n_features, dropout)
     ff = PositionwiseFeedForward(n_features, d_ff, dropout)
-    return Encoder(EncoderLayer(n_features, copy.deepcopy(attn), copy.deepcopy(ff), dropout), N, None)
+    position = _make_positional_encoding(n_features, positional_encoding)
+    return Encoder(EncoderLayer(n_features, copy.deepcopy(attn), copy.deepcopy(ff), dropout), N, position)
 
 
 class OutputLayer(nn.Module):

@@ -69,7 +69,7 @@ class _AttentionFn(torch.autograd.Function):
     views of one fused projection).  allrank/models/transformer.py:137-156, :193-203."""
 
     @staticmethod
-    def forward(ctx, q, k, v, key_pad_mask, h):
+    def forward(ctx, q, k, v, key_pad_mask, h, p_drop=0.0, seed=0):
         L.require_device(q, k, v, key_pad_mask)
         B, SL, d = q.shape
         dk = d // h
@@ -83,9 +83,10 @@ class _AttentionFn(torch.autograd.Function):
         o = torch.empty((B, SL, d), dtype=torch.float32, device=q.device)
         lse = torch.empty((B, h, SL), dtype=torch.float32, device=q.device)
         L.check(L.lib().ltrx_mha_fwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), B, SL, h, dk, rs, L.ptr(o), d, L.ptr(lse),
-                                     L.stream_of(q)), "mha_fwd")
+                                     float(p_drop), int(seed) & 0xFFFFFFFF, L.stream_of(q)), "mha_fwd")
         ctx.save_for_backward(q, k, v, mask, o, lse)
         ctx.h = h
+        ctx.p_drop, ctx.seed = float(p_drop), int(seed) & 0xFFFFFFFF
         return o
 
     @staticmethod
@@ -101,13 +102,17 @@ class _AttentionFn(torch.autograd.Function):
         lib = L.lib()
         ws = L.workspace(lib.ltrx_mha_bwd_workspace_bytes(B, SL, h), o)
         L.check(lib.ltrx_mha_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), L.ptr(o), L.ptr(do), L.ptr(lse), B, SL, h, dk_,
-                                 q.stride(1), d, L.ptr(dq), L.ptr(dkk), L.ptr(dv), 3 * d, L.ptr(ws), L.stream_of(o)),
-                "mha_bwd")
-        return dq, dkk, dv, None, None
+                                 q.stride(1), d, L.ptr(dq), L.ptr(dkk), L.ptr(dv), 3 * d, ctx.p_drop, ctx.seed, L.ptr(ws),
+                                 L.stream_of(o)), "mha_bwd")
+        return dq, dkk, dv, None, None, None, None
 
 
-def attention(q, k, v, key_pad_mask, h):
-    return _AttentionFn.apply(q, k, v, key_pad_mask, h)
+def attention(q, k, v, key_pad_mask, h, p_drop=0.0, seed=None):
+    """fused masked self-attention; with p_drop > 0 the softmax probabilities are dropped out inside the kernel (the seed
+    is drawn from torch's CPU generator unless given, so torch.manual_seed controls it)."""
+    if p_drop and seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return _AttentionFn.apply(q, k, v, key_pad_mask, h, float(p_drop or 0.0), int(seed or 0))
 
 
 def mfma_selftest(A, Bm):

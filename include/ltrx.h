@@ -139,7 +139,9 @@ int ltrx_layernorm_bwd(const float* dy, const float* xsum, const float* a, const
 /* transformer.py:137-156 attention() as used by MultiHeadedAttention.forward (:178-203), fused flash-style:
  * q,k,v,o are [B, L, h, d_k] views of the projection outputs (element (b,l,head,c) at ((b*L+l)*h+head)*d_k + c
  * scaled by the given row stride), key_pad_mask u8[B,L] (1 = padded key, filled with -inf, transformer.py:150-151);
- * softmax over keys; dropout is not applied (p=0 / eval).  lse_out[B,h,L] = log-sum-exp of the
+ * softmax over keys; dropout on the probabilities (transformer.py:154-155) with rate p_drop (0 = off) from a counter-
+ * based generator keyed by `seed` (the backward must be given the same p_drop and seed; the stream differs from torch's
+ * Philox, equivalence is statistical).  lse_out[B,h,L] = log-sum-exp of the
  * scaled, masked scores (the only tensor saved for backward).  fp32 in/out; contractions on the fp32 MFMA
  * (v_mfma_f32_32x32x2_f32), exact fp32 products.  d_k % 4 == 0, d_k <= 128 (zero-padded to a multiple of 32). */
 /* precision of the attention contractions: 0 (default) = exact fp32 MFMA (bit-exact fp32 products, error ~5e-7),
@@ -147,12 +149,14 @@ int ltrx_layernorm_bwd(const float* dy, const float* xsum, const float* a, const
 void ltrx_mha_set_mode(int mode);
 int ltrx_mha_get_mode(void);
 int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L, int h,
-                 int d_k, int row_stride, float* o, int o_row_stride, float* lse_out, ltrx_stream_t stream);
+                 int d_k, int row_stride, float* o, int o_row_stride, float* lse_out, float p_drop, uint32_t seed,
+                 ltrx_stream_t stream);
 /* backward: dq,dk,dv from do; delta_ws[B,h,L] scratch (rowsum(do*o)). */
 size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h);
 int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, const float* o,
                  const float* dout, const float* lse, int B, int L, int h, int d_k, int row_stride, int o_row_stride,
-                 float* dq, float* dk, float* dv, int d_row_stride, void* ws, ltrx_stream_t stream);
+                 float* dq, float* dk, float* dv, int d_row_stride, float p_drop, uint32_t seed, void* ws,
+                 ltrx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-step glue (allrank/training/train_utils.py:18-29 around the model): the pieces between the library

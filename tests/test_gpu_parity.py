@@ -493,3 +493,65 @@ def test_neuralndcg_register_path_equals_general_path():
         for force in (0, 1):
             assert close(out[force][0], ro, rtol=2e-5) and grad_close(out[force][1], rg, rtol=5e-4), (B, L, force, out[force][0], ro)
         assert abs(out[0][0] - out[1][0]) < 1e-6
+
+
+def test_attention_dropout_statistics_and_gradient_consistency():
+    """in-kernel dropout on the attention probabilities: (a) p = 0 is the plain kernel; (b) the keep rate is 1 - p and
+    E[out] is the undropped output; (c) forward and backward regenerate the SAME mask: the analytic gradient matches a
+    finite difference of the (fixed-seed) dropped forward."""
+    from allrank_amd import ops
+    rng = np.random.default_rng(0)
+    B, L, h, dk = 2, 96, 2, 32
+    d = h * dk
+    qkv = (rng.standard_normal((B, L, 3 * d)) * 0.5).astype(np.float32)
+    mask = torch.zeros(B, L, dtype=torch.bool, device=DEV)
+    t0 = _t(qkv)
+    base = ops.attention(t0[:, :, :d], t0[:, :, d:2 * d], t0[:, :, 2 * d:], mask, h, 0.0)
+    same = ops.attention(t0[:, :, :d], t0[:, :, d:2 * d], t0[:, :, 2 * d:], mask, h, 0.0, seed=123)
+    assert torch.equal(base, same)
+    # (b) v = ones  =>  out = (1/(1-p)) * sum_j keep_ij P_ij : its mean over rows is ~1 and the kept mass fraction ~ 1-p
+    ones = qkv.copy()
+    ones[:, :, 2 * d:] = 1.0
+    t1 = _t(ones)
+    p = 0.3
+    outs = [ops.attention(t1[:, :, :d], t1[:, :, d:2 * d], t1[:, :, 2 * d:], mask, h, p, seed=s).mean().item() for s in range(8)]
+    assert abs(np.mean(outs) - 1.0) < 0.02, outs
+    o1 = ops.attention(t1[:, :, :d], t1[:, :, d:2 * d], t1[:, :, 2 * d:], mask, h, p, seed=7)
+    o2 = ops.attention(t1[:, :, :d], t1[:, :, d:2 * d], t1[:, :, 2 * d:], mask, h, p, seed=7)
+    o3 = ops.attention(t1[:, :, :d], t1[:, :, d:2 * d], t1[:, :, 2 * d:], mask, h, p, seed=8)
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)
+    # (c) directional derivative check with a fixed seed (float64 reference is not available: use central differences)
+    tq = _t(qkv, True)
+    go = _t(rng.standard_normal((B, L, d)).astype(np.float32))
+    o = ops.attention(tq[:, :, :d], tq[:, :, d:2 * d], tq[:, :, 2 * d:], mask, h, p, seed=99)
+    (o * go).sum().backward()
+    direction = rng.standard_normal(qkv.shape).astype(np.float32)
+    eps = 1e-2
+
+    def f(x):
+        t = _t(x)
+        return float((ops.attention(t[:, :, :d], t[:, :, d:2 * d], t[:, :, 2 * d:], mask, h, p, seed=99) * go).sum().item())
+
+    fd = (f(qkv + eps * direction) - f(qkv - eps * direction)) / (2 * eps)
+    an = float((tq.grad.cpu().numpy() * direction).sum())
+    assert abs(fd - an) <= 2e-2 * max(1.0, abs(an)), (fd, an)
+
+
+def test_model_trains_with_reference_dropout_config():
+    """the reference's WEB30K ranker (fc 96, N=2, h=1, d_ff=384, dropout 0.1 -- approxndcg.json) runs train() steps through
+    the plugin surface and reduces the loss on a fixed batch."""
+    from allrank_amd import losses as E
+    from allrank_amd.model import make_model
+    from allrank_amd.engine import Trainer
+    torch.manual_seed(0)
+    model = make_model(dict(sizes=[96], input_norm=False, activation=None, dropout=0.0),
+                       dict(N=2, d_ff=384, h=1, positional_encoding=dict(strategy="fixed", max_indices=240), dropout=0.1),
+                       dict(d_output=1, output_activation=None), 136).to(DEV)
+    model.train()
+    rng = np.random.default_rng(1)
+    x = _t(rng.standard_normal((16, 60, 136)).astype(np.float32))
+    y = _t(rng.integers(0, 5, (16, 60)).astype(np.float32))
+    idx = torch.arange(60, device=DEV).expand(16, 60).contiguous()
+    tr = Trainer(model, E.approxNDCGLoss, torch.optim.Adam(model.parameters(), lr=1e-3))
+    losses = [tr.step(x, y, idx).item() for _ in range(30)]
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.02, losses

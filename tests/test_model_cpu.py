@@ -11,9 +11,9 @@ def _engine(cfgkw):
     return make_model(**cfgkw)
 
 
-def _kw(N=2, h=8, d_ff=2048, sizes=(512,), nf=136, act=None, norm=False, oact=None):
+def _kw(N=2, h=8, d_ff=2048, sizes=(512,), nf=136, act=None, norm=False, oact=None, pos=None):
     return dict(fc_model=dict(sizes=list(sizes), input_norm=norm, activation=act, dropout=0.0),
-                transformer=dict(N=N, d_ff=d_ff, h=h, positional_encoding=None, dropout=0.0) if N else None,
+                transformer=dict(N=N, d_ff=d_ff, h=h, positional_encoding=pos, dropout=0.0) if N else None,
                 post_model=dict(d_output=1, output_activation=oact), n_features=nf)
 
 
@@ -38,7 +38,9 @@ def test_make_model_mutates_sizes_like_reference():
 
 @pytest.mark.skipif(not reference_available(), reason="reference tree only exists in the build container")
 @pytest.mark.parametrize("kw", [_kw(N=2, h=4, d_ff=64, sizes=(32,), nf=20), _kw(N=0, sizes=(24, 16), nf=20, act="ReLU", norm=True),
-                                _kw(N=1, h=1, d_ff=48, sizes=(24,), nf=12, oact="Sigmoid")])
+                                _kw(N=1, h=1, d_ff=48, sizes=(24,), nf=12, oact="Sigmoid"),
+                                _kw(N=1, h=2, d_ff=48, sizes=(24,), nf=12, pos=dict(strategy="learned", max_indices=30)),
+                                _kw(N=1, h=2, d_ff=48, sizes=(24,), nf=12, pos=dict(strategy="fixed", max_indices=30))])
 def test_same_seed_gives_reference_initial_weights(kw):
     import copy
     from oracle.ref_loader import load_reference
@@ -47,6 +49,9 @@ def test_same_seed_gives_reference_initial_weights(kw):
     from allrank.config import TransformerConfig
     k1, k2 = copy.deepcopy(kw), copy.deepcopy(kw)
     if k1["transformer"]:
+        from allrank.config import PositionalEncoding
+        if k1["transformer"]["positional_encoding"]:
+            k1["transformer"]["positional_encoding"] = PositionalEncoding(**k1["transformer"]["positional_encoding"])
         k1["transformer"] = TransformerConfig(**k1["transformer"])
     torch.manual_seed(42)
     ref = ref_make(**k1)
@@ -57,3 +62,8 @@ def test_same_seed_gives_reference_initial_weights(kw):
     for k in rs:
         assert torch.equal(rs[k], es[k]), k
     assert [n for n, _ in ref.named_parameters()] == [n for n, _ in eng.named_parameters()]
+    if kw["transformer"] and kw["transformer"]["positional_encoding"]:      # the position module computes the same thing
+        x = torch.randn(3, 7, kw["fc_model"]["sizes"][-1])
+        idx = torch.tensor([[0, 1, 2, 3, 4, 5, 6], [5, 40, 2, -1, -1, -1, -1], [29, 30, 31, 0, 1, -1, -1]])
+        mask = idx == -1
+        assert torch.equal(ref.encoder.position(x, mask, idx.clone()), eng.encoder.position(x, mask, idx.clone()))
