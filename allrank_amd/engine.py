@@ -433,3 +433,53 @@ class _null(object):
 
     def __exit__(self, *a):
         return False
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# epoch loop on device-resident data  (the body of fit(), allrank/training/train_utils.py:78-147, without its host work)
+# ------------------------------------------------------------------------------------------------------------------
+def fit_device(model, loss_name, loss_args, train_ds, val_ds, epochs, batch_size, slate_length, metrics=None, lr=1e-3,
+               val_metric=None, early_stopping_patience=None, generator=None, use_fused=True, log=None):
+    """Train ``model`` on a DeviceSlates dataset; returns {"epochs", "train_loss", "val_metrics", "history"}.
+
+    Per epoch: shuffled batches produced on the device (DeviceSlates.batches), one training step each (FusedTrainer when
+    the model family / dropout allow it, else the autograd Trainer), the running loss is accumulated ON THE DEVICE (one
+    host sync per epoch instead of the reference's ``loss.item()`` per step, train_utils.py:29), then one no-grad
+    metrics pass over the validation set (train_utils.py:101-107).  The reference's second full pass over the TRAIN set
+    for train metrics (train_utils.py:99, dropout active) is not reproduced."""
+    from . import losses as E
+    from .data import evaluate
+    metrics = metrics or {"ndcg": [5]}
+    trainer, fused = None, False
+    if use_fused:
+        try:
+            trainer = FusedTrainer(model, loss_name, loss_args, batch_size, slate_length, lr=lr, use_graph=True)
+            fused = True
+        except NotImplementedError:
+            trainer = None
+    if trainer is None:
+        lossfn = (lambda s, t: getattr(E, loss_name)(s, t, **(loss_args or {})))
+        trainer = Trainer(model, lossfn, torch.optim.Adam(model.parameters(), lr=lr))
+    history, best, best_epoch = [], -1.0, 0
+    for epoch in range(epochs):
+        model.train()
+        tot = torch.zeros(1, device=train_ds.device)
+        nb = 0
+        for xb, yb, idx in train_ds.batches(batch_size, slate_length, shuffle=True, generator=generator, drop_last=fused):
+            loss = trainer.step(xb, yb, idx)
+            tot += loss.detach().view(1) * xb.shape[0]
+            nb += xb.shape[0]
+        train_loss = float(tot.item()) / max(nb, 1)
+        val = evaluate(model, val_ds, metrics)
+        history.append(dict(epoch=epoch, train_loss=train_loss, **val))
+        if log:
+            log(history[-1])
+        if val_metric is not None and early_stopping_patience is not None:
+            cur = val[val_metric]
+            if cur > best:
+                best, best_epoch = cur, epoch
+            if epoch - best_epoch > early_stopping_patience:       # early_stop.py:17-19
+                break
+    return dict(epochs=epoch, train_loss=history[-1]["train_loss"], val_metrics={k: v for k, v in history[-1].items()
+                                                                                 if k not in ("epoch", "train_loss")},
+                history=history, fused=fused)
