@@ -41,6 +41,14 @@ WORKLOADS = {
                             n_features=136, fc_sizes=[512], N=2, h=8, d_ff=2048, loss="approxNDCGLoss"),
     "fc_listnet": dict(desc="WEB30K-synth F=136 L=240, FCModel[96] + ListNet (BASELINE configs[1])",
                        n_features=136, fc_sizes=[96], N=0, h=1, d_ff=0, loss="listNet"),
+    "attn_neuralndcg": dict(desc="WEB30K-synth F=136 L=240, fc[512] + 2x self-attention(d512,h8,d_ff2048) + NeuralNDCG tau=1 (BASELINE configs[3])",
+                            n_features=136, fc_sizes=[512], N=2, h=8, d_ff=2048, loss="neuralNDCG",
+                            loss_args=dict(temperature=1.0, powered_relevancies=True, k=None, stochastic=False)),
+    "attn_lambdarank": dict(desc="WEB30K-synth F=136 L=240, fc[512] + 2x self-attention(d512,h8,d_ff2048) + lambdaLoss(lambdaRank_scheme) (BASELINE configs[3])",
+                            n_features=136, fc_sizes=[512], N=2, h=8, d_ff=2048, loss="lambdaLoss",
+                            loss_args=dict(weighing_scheme="lambdaRank_scheme", k=None, mu=10.0, sigma=1.0)),
+    "attn1024_listmle": dict(desc="synthetic F=1024 L=1024, fc[512] + 2x self-attention(d512,h8,d_ff2048) + ListMLE (BASELINE configs[4])",
+                             n_features=1024, fc_sizes=[512], N=2, h=8, d_ff=2048, loss="listMLE", slate_len=1024, slates=16),
 }
 
 
@@ -108,7 +116,8 @@ def time_kernels(w, B, L, device):
     y = torch.zeros(B, L, device=device)
     s = torch.randn(B, L, device=device, requires_grad=True)
     lossfn = getattr(E, w["loss"])
-    res["loss_fwd_bwd"] = dict(sec=ev(lambda: lossfn(s, y)), launches_per_step=1)
+    largs = w.get("loss_args", {})
+    res["loss_fwd_bwd"] = dict(sec=ev(lambda: lossfn(s, y, **largs)), launches_per_step=1)
     if w["N"]:
         dk = d // h
         qkv = torch.randn(B, L, 3 * d, device=device)
@@ -147,7 +156,11 @@ def cpu_baseline(w, L, seconds_budget=20.0):
     y = rng.choice(5, size=(Bs, L), p=[0.52, 0.32, 0.13, 0.02, 0.01]).astype(np.float32)
     params = M.init_params(cfg, seed=0)
     opt = M.Adam(params, lr=1e-3)
-    lossfn = (lambda s, t: O.approxndcg(s, t)) if w["loss"] == "approxNDCGLoss" else (lambda s, t: O.listnet(s, t))
+    la = dict(w.get("loss_args", {}))
+    la.pop("stochastic", None)
+    lossfn = {"approxNDCGLoss": lambda s, t: O.approxndcg(s, t), "listNet": lambda s, t: O.listnet(s, t),
+              "neuralNDCG": lambda s, t: O.neuralndcg(s, t, **la), "lambdaLoss": lambda s, t: O.lambdaloss(s, t, **la),
+              "listMLE": lambda s, t: O.listmle(s, t, np.arange(L))}[w["loss"]]
     M.train_step(params, cfg, opt, x, y, lossfn)        # warm-up
     t0 = time.perf_counter()
     n = 0
@@ -198,12 +211,17 @@ def main():
     from allrank_amd.engine import Trainer, FusedTrainer
     w = WORKLOADS[args.workload]
     B, L = args.slates_per_gpu, args.slate_len
+    if "slate_len" in w and args.slate_len == 240:
+        L = w["slate_len"]
+    if "slates" in w and args.slates_per_gpu == 256:
+        B = w["slates"]
     model = build_model(w, device)
     if args.engine == "fused":
-        trainer = FusedTrainer(model, w["loss"], {}, B, L, lr=1e-3, world_size=world, use_graph=True, gemm=args.gemm)   # Adam 1e-3: approxndcg.json:28-33
+        trainer = FusedTrainer(model, w["loss"], w.get("loss_args", {}), B, L, lr=1e-3, world_size=world, use_graph=True, gemm=args.gemm)   # Adam 1e-3: approxndcg.json:28-33
     else:
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-        trainer = Trainer(model, getattr(E, w["loss"]), opt, None, world, None)
+        _lf, _la = getattr(E, w["loss"]), w.get("loss_args", {})
+        trainer = Trainer(model, (lambda sc, yt: _lf(sc, yt, **_la)), opt, None, world, None)
     n_batches = 8
     x, y, idx = synth_batch(n_batches * B, L, w["n_features"], 42 + rank, device)
 
@@ -279,7 +297,7 @@ def main():
         if world == 1 and B != 64 and args.engine == "fused":
             try:
                 m64 = build_model(w, device)
-                t64 = FusedTrainer(m64, w["loss"], {}, 64, L, lr=1e-3, world_size=1, use_graph=True, gemm=args.gemm)
+                t64 = FusedTrainer(m64, w["loss"], w.get("loss_args", {}), 64, L, lr=1e-3, world_size=1, use_graph=True, gemm=args.gemm)
                 for i in range(6):
                     t64.step(x[:64], y[:64], idx[:64])
                 torch.cuda.synchronize()
