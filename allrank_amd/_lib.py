@@ -30,27 +30,29 @@ SIGNATURES = {
     "ltrx_neuralndcg_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_ndcg_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_ndcg_at": (_i, [_vp, _vp, _i, _i, ctypes.POINTER(ctypes.c_int), _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
-    "ltrx_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, ctypes.c_uint32, _vp, _vp]),
     "ltrx_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_mha_set_mode": (None, [_i]),
     "ltrx_mha_get_mode": (_i, []),
-    "ltrx_mha_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _f, ctypes.c_uint32, _vp]),
+    "ltrx_mha_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _f, ctypes.c_uint32, _vp, _vp]),
     "ltrx_mha_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltrx_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp, _f, _vp]),
     "ltrx_colsum_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_colsum": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
-    "ltrx_relu_bwd": (_i, [_vp, _vp, _sz, _vp]),
+    "ltrx_relu_bwd": (_i, [_vp, _vp, _sz, _f, _vp]),
+    "ltrx_dropout_apply": (_i, [_vp, _vp, _sz, _f, ctypes.c_uint32, _vp, _vp]),
+    "ltrx_bump_u32": (_i, [_vp, _vp]),
     "ltrx_bias_act": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ltrx_score_head_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ltrx_score_head_bwd_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_score_head_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "ltrx_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "ltrx_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _f, ctypes.c_uint32, _vp, _i, _vp]),
     "ltrx_gemm_set_variant": (None, [_i]),
     "ltrx_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltrx_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ltrx_selftest_mfma32x32x2": (_i, [_vp, _vp, _vp, _vp]),
-    "ltrx_mha_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, ctypes.c_uint32, _vp, _vp]),
+    "ltrx_mha_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, ctypes.c_uint32, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -102,6 +102,34 @@ __device__ __forceinline__ void block_inclusive_scan(float* a, int n, float* red
 
 __device__ __forceinline__ float sigmoidf_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Counter-based dropout: the keep decision of element `idx` of a tensor is a pure function of (seed, idx), so forward and
+// backward kernels regenerate the same mask without storing it (murmur3 finaliser over the folded 64-bit index).
+// `seed` = per-site constant XOR a per-step word read from device memory (so a captured hipGraph draws a fresh mask at
+// every replay).  Returns 1/(1-p) for kept elements, 0 for dropped ones.
+struct DropSpec {
+  uint32_t seed;
+  uint32_t thresh;     // drop iff (hash >> 8) < thresh,  thresh = p * 2^24  (0 = dropout off)
+  float inv_keep;
+};
+__device__ __forceinline__ float drop_keep_scale(const DropSpec& d, uint64_t idx) {
+  uint32_t x = (uint32_t)idx ^ ((uint32_t)(idx >> 32) * 0x9E3779B9u) ^ d.seed;
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return ((x >> 8) >= d.thresh) ? d.inv_keep : 0.f;
+}
+
+}  // namespace ltrx
+inline ltrx::DropSpec ltrx_make_drop(float p, uint32_t seed) {
+  ltrx::DropSpec d;
+  d.seed = seed;
+  d.thresh = (p > 0.f) ? (uint32_t)(p * 16777216.0f) : 0u;
+  d.inv_keep = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f;
+  return d;
+}
+namespace ltrx {
 }  // namespace ltrx
 
 // Final cross-slate reduction: out[0] = scale * sum_b per[b]  (fixed order -> deterministic).  One block.

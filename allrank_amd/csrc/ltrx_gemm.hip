@@ -117,7 +117,8 @@ __global__ void __launch_bounds__(BM_ * 2) __attribute__((amdgpu_waves_per_eu(2,
                                                                   const float* __restrict__ B, int ldb,
                                                                   float* __restrict__ C, int ldc, int M, int N, int K,
                                                                   const float* __restrict__ bias, int act,
-                                                                  const float* __restrict__ aux, int ldaux, int tiles_n) {
+                                                                  const float* __restrict__ aux, int ldaux, int tiles_n,
+                                                                  ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step) {
   constexpr int T = BM_ * 2;                    // threads
   constexpr int C4 = BK_ / 4;                   // float4 per tile row
   constexpr int PA = BM_ * C4 / T;              // float4 per thread for the A tile
@@ -186,6 +187,8 @@ __global__ void __launch_bounds__(BM_ * 2) __attribute__((amdgpu_waves_per_eu(2,
 
   // epilogue: lane owns column n0 + wc*64 + j*32 + (lane&31); register r is row rowmap(r, half)
   const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+  ltrx::DropSpec dsp = drop;
+  if (drop_step) dsp.seed ^= drop_step[0] * 0x9E3779B9u;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wc * 64 + j * 32 + l31;
@@ -199,7 +202,8 @@ __global__ void __launch_bounds__(BM_ * 2) __attribute__((amdgpu_waves_per_eu(2,
         if (row < M) {
           float v = acc[i][j][r] + bv;
           if (act == 1) v = fmaxf(v, 0.f);
-          if (act == 2) v = (aux[(size_t)row * ldaux + col] > 0.f) ? v : 0.f;    // ReLU backward fused into the dgrad
+          if (act == 2) v = (aux[(size_t)row * ldaux + col] > 0.f) ? v * drop.inv_keep : 0.f;   // ReLU(+dropout) backward
+          else if (drop.thresh != 0u) v *= ltrx::drop_keep_scale(dsp, (uint64_t)row * (uint64_t)N + (uint64_t)col);
           C[(size_t)row * ldc + col] = v;
         }
       }
@@ -218,7 +222,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                                                                    const float* __restrict__ B, int ldb,
                                                                    float* __restrict__ C, int ldc, int M, int N, int K,
                                                                    const float* __restrict__ bias, int act,
-                                                                   const float* __restrict__ aux, int ldaux, int tiles_n) {
+                                                                   const float* __restrict__ aux, int ldaux, int tiles_n,
+                                                                  ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step) {
   constexpr int BM_ = 128, BK_ = 32;
   __shared__ __attribute__((aligned(16))) Smem<NTERMS, BM_, BK_> s[2];
   const int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -282,6 +287,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 
   const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+  ltrx::DropSpec dsp = drop;
+  if (drop_step) dsp.seed ^= drop_step[0] * 0x9E3779B9u;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wc * 64 + j * 32 + l31;
@@ -295,7 +302,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (row < M) {
           float v = acc[i][j][r] + bv;
           if (act == 1) v = fmaxf(v, 0.f);
-          if (act == 2) v = (aux[(size_t)row * ldaux + col] > 0.f) ? v : 0.f;
+          if (act == 2) v = (aux[(size_t)row * ldaux + col] > 0.f) ? v * drop.inv_keep : 0.f;
+          else if (drop.thresh != 0u) v *= ltrx::drop_keep_scale(dsp, (uint64_t)row * (uint64_t)N + (uint64_t)col);
           C[(size_t)row * ldc + col] = v;
         }
       }
@@ -425,15 +433,19 @@ extern "C" void ltrx_gemm_set_variant(int v) { g_nt_variant = v; }
 
 template <int NTERMS, int BM_, int BK_>
 static void launch_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
-                      const float* bias, int act, const float* aux, int ldaux, hipStream_t s) {
+                      const float* bias, int act, const float* aux, int ldaux, ltrx::DropSpec drop, const uint32_t* drop_step,
+                      hipStream_t s) {
   const int tiles_m = (M + BM_ - 1) / BM_, tiles_n = (N + BN - 1) / BN;
   hipLaunchKernelGGL((ltrx_gemm_nt_kernel<NTERMS, BM_, BK_>), dim3(tiles_m * tiles_n), dim3(BM_ * 2), 0, s, A, lda, B, ldb, C,
-                     ldc, M, N, K, bias, act, aux, ldaux, tiles_n);
+                     ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step);
 }
 
 extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
-                            const float* bias, int act, const float* aux, int ldaux, int strict, ltrx_stream_t stream) {
+                            const float* bias, int act, const float* aux, int ldaux, float drop_p, uint32_t drop_seed,
+                            const uint32_t* drop_step, int strict, ltrx_stream_t stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return LTRX_EINVAL;
+  if (!(drop_p >= 0.f) || drop_p >= 1.f) return LTRX_EINVAL;
+  const ltrx::DropSpec drop = ltrx_make_drop(drop_p, drop_seed);
   if (act == 2 && (!aux || ldaux < N)) return LTRX_EINVAL;
   if ((K & 3) || (lda & 3) || (ldb & 3) || lda < K || ldb < K || ldc < N) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
@@ -445,19 +457,19 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
   }
   if (v == 0) v = 1;
   if (strict) {
-    launch_nt<3, 128, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s);
+    launch_nt<3, 128, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, drop, drop_step, s);
   } else {
     switch (v) {
-      case 2: launch_nt<2, 128, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s); break;
-      case 3: launch_nt<2, 256, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s); break;
-      case 4: launch_nt<2, 256, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s); break;
+      case 2: launch_nt<2, 128, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, drop, drop_step, s); break;
+      case 3: launch_nt<2, 256, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, drop, drop_step, s); break;
+      case 4: launch_nt<2, 256, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, drop, drop_step, s); break;
       case 5: {
         const int tiles_m = (M + 127) / 128, tiles_n = (N + BN - 1) / BN;
         hipLaunchKernelGGL(ltrx_gemm_nt_pipe_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N,
-                           K, bias, act, aux, ldaux, tiles_n);
+                           K, bias, act, aux, ldaux, tiles_n, drop, drop_step);
         break;
       }
-      default: launch_nt<2, 128, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, s); break;
+      default: launch_nt<2, 128, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, drop, drop_step, s); break;
     }
   }
   LTRX_LAUNCH_CHECK();

@@ -19,9 +19,11 @@ __global__ void __launch_bounds__(256) ltrx_layernorm_fwd_kernel(const float* __
                                                                  const float* __restrict__ b, int rows, int D, float eps,
                                                                  float* __restrict__ xsum_out, float* __restrict__ y,
                                                                  float* __restrict__ mean_out,
-                                                                 float* __restrict__ rstd_out) {
+                                                                 float* __restrict__ rstd_out, DropSpec drop,
+                                                                 const uint32_t* __restrict__ drop_step) {
   const int lane = lane_id();
   const int wpb = blockDim.x >> 6;
+  if (drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   for (int row = blockIdx.x * wpb + wave_id(); row < rows; row += gridDim.x * wpb) {
     const float* xr = x + (size_t)row * D;
     const float* rr = res ? res + (size_t)row * D : nullptr;
@@ -29,15 +31,14 @@ __global__ void __launch_bounds__(256) ltrx_layernorm_fwd_kernel(const float* __
     float sum = 0.f;
     for (int c = lane; c < D; c += 64) {
       float v = xr[c];
-      if (rr) v += rr[c];
+      if (rr) v += (drop.thresh != 0u) ? rr[c] * drop_keep_scale(drop, (uint64_t)row * D + c) : rr[c];
       if (xs) xs[c] = v;
       sum += v;
     }
     const float mean = wave_sum(sum) / (float)D;
     float sq = 0.f;
     for (int c = lane; c < D; c += 64) {
-      float v = xr[c];
-      if (rr) v += rr[c];
+      float v = xs ? xs[c] : xr[c];
       const float d = v - mean;
       sq += d * d;
     }
@@ -45,8 +46,7 @@ __global__ void __launch_bounds__(256) ltrx_layernorm_fwd_kernel(const float* __
     const float r = 1.0f / (stdv + eps);
     float* yr = y + (size_t)row * D;
     for (int c = lane; c < D; c += 64) {
-      float v = xr[c];
-      if (rr) v += rr[c];
+      float v = xs ? xs[c] : xr[c];
       yr[c] = a[c] * ((v - mean) * r) + b[c];
     }
     if (lane == 0) {
@@ -126,9 +126,11 @@ __global__ void __launch_bounds__(256) ltrx_layernorm_fwd_vec_kernel(const float
                                                                      const float* __restrict__ a, const float* __restrict__ b,
                                                                      int rows, float eps, float* __restrict__ xsum_out,
                                                                      float* __restrict__ y, float* __restrict__ mean_out,
-                                                                     float* __restrict__ rstd_out) {
+                                                                     float* __restrict__ rstd_out, DropSpec drop,
+                                                                     const uint32_t* __restrict__ drop_step) {
   constexpr int D = 256 * NV;
   const int lane = lane_id(), wpb = blockDim.x >> 6;
+  if (drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   float4 av[NV], bv[NV];
 #pragma unroll
   for (int t = 0; t < NV; ++t) {
@@ -143,7 +145,12 @@ __global__ void __launch_bounds__(256) ltrx_layernorm_fwd_vec_kernel(const float
     for (int t = 0; t < NV; ++t) {
       v[t] = xr[lane + 64 * t];
       if (res) {
-        const float4 r = reinterpret_cast<const float4*>(res + (size_t)row * D)[lane + 64 * t];
+        float4 r = reinterpret_cast<const float4*>(res + (size_t)row * D)[lane + 64 * t];
+        if (drop.thresh != 0u) {
+          const uint64_t e0 = (uint64_t)row * D + 4 * (lane + 64 * t);
+          r.x *= drop_keep_scale(drop, e0); r.y *= drop_keep_scale(drop, e0 + 1);
+          r.z *= drop_keep_scale(drop, e0 + 2); r.w *= drop_keep_scale(drop, e0 + 3);
+        }
         v[t].x += r.x; v[t].y += r.y; v[t].z += r.z; v[t].w += r.w;
       }
       sum += (v[t].x + v[t].y) + (v[t].z + v[t].w);
@@ -289,13 +296,15 @@ static bool ln_vec_ok(int D, const void* p0, const void* p1, const void* p2) {
 
 extern "C" int ltrx_layernorm_fwd(const float* x, const float* res, const float* a, const float* b, int rows, int D,
                                   float eps, float* xsum_out, float* y_out, float* mean_out, float* rstd_out,
-                                  ltrx_stream_t stream) {
+                                  float res_drop_p, uint32_t drop_seed, const uint32_t* drop_step, ltrx_stream_t stream) {
   if (!x || !a || !b || !y_out || !mean_out || !rstd_out || rows <= 0 || D < 2) return LTRX_EINVAL;
   if (res && !xsum_out) return LTRX_EINVAL;
+  if (!(res_drop_p >= 0.f) || res_drop_p >= 1.f) return LTRX_EINVAL;
+  const DropSpec drop = ltrx_make_drop(res ? res_drop_p : 0.f, drop_seed);
   hipStream_t s = (hipStream_t)stream;
   if (ln_vec_ok(D, x, y_out, res) && ln_vec_ok(D, a, b, xsum_out)) {
     const dim3 g(ln_fwd_vec_grid(rows));
-#define LTRX_LN_FWD(NV) hipLaunchKernelGGL(ltrx_layernorm_fwd_vec_kernel<NV>, g, dim3(256), 0, s, x, res, a, b, rows, eps, xsum_out, y_out, mean_out, rstd_out)
+#define LTRX_LN_FWD(NV) hipLaunchKernelGGL(ltrx_layernorm_fwd_vec_kernel<NV>, g, dim3(256), 0, s, x, res, a, b, rows, eps, xsum_out, y_out, mean_out, rstd_out, drop, drop_step)
     switch (D / 256) {
       case 1: LTRX_LN_FWD(1); break;
       case 2: LTRX_LN_FWD(2); break;
@@ -305,7 +314,7 @@ extern "C" int ltrx_layernorm_fwd(const float* x, const float* res, const float*
 #undef LTRX_LN_FWD
   } else {
     hipLaunchKernelGGL(ltrx_layernorm_fwd_kernel, dim3(ln_grid(rows)), dim3(256), 0, s, x, res, a, b, rows, D, eps, xsum_out,
-                       y_out, mean_out, rstd_out);
+                       y_out, mean_out, rstd_out, drop, drop_step);
   }
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;

@@ -158,24 +158,12 @@ __device__ __forceinline__ void store_rows(float* __restrict__ base, int row0, i
   }
 }
 
-// Dropout on the attention probabilities (transformer.py:154-155): a counter-based generator -- the keep decision of
-// element (slate*head, query, key) is a pure function of (seed, index), so the forward and both backward kernels
-// regenerate the same mask without storing it.  murmur3 finaliser over the folded 64-bit element index.
-struct DropCfg {
-  uint32_t seed;
-  uint32_t thresh;     // keep iff (hash >> 8) >= thresh,  thresh = p * 2^24
-  float inv_keep;      // 1 / (1 - p)
-};
+// Dropout on the attention probabilities (transformer.py:154-155): the counter-based generator of ltrx_device.h keyed by
+// the element index ((slate*head) * L + query) * L + key: forward and both backward kernels regenerate the same mask.
+typedef DropSpec DropCfg;
 __device__ __forceinline__ float drop_scale(const DropCfg& d, uint32_t bh, int L, int qrow, int key) {
   if (d.thresh == 0u) return 1.0f;
-  const uint64_t idx = ((uint64_t)bh * (uint64_t)L + (uint64_t)qrow) * (uint64_t)L + (uint64_t)key;
-  uint32_t x = (uint32_t)idx ^ ((uint32_t)(idx >> 32) * 0x9E3779B9u) ^ d.seed;
-  x ^= x >> 16;
-  x *= 0x85EBCA6Bu;
-  x ^= x >> 13;
-  x *= 0xC2B2AE35u;
-  x ^= x >> 16;
-  return ((x >> 8) >= d.thresh) ? d.inv_keep : 0.f;
+  return drop_keep_scale(d, ((uint64_t)bh * (uint64_t)L + (uint64_t)qrow) * (uint64_t)L + (uint64_t)key);
 }
 
 template <int DKP>
@@ -196,7 +184,9 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
                                                               const float* __restrict__ v,
                                                               const uint8_t* __restrict__ kpm, int L, int h, int dk,
                                                               int rs, float* __restrict__ o, int ors,
-                                                              float* __restrict__ lse, float scale, DropCfg drop) {
+                                                              float* __restrict__ lse, float scale, DropCfg drop,
+                                                              const uint32_t* __restrict__ drop_step) {
+  if (drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   __shared__ __attribute__((aligned(16))) float ktile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float vtile[Tile<DKP>::FLOATS];
   __shared__ float kmask[32];
@@ -276,7 +266,8 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ kpm, const float* __restrict__ o, const float* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ delta, int L, int h, int dk, int rs, int ors,
-    float* __restrict__ dq, int drs, float scale, DropCfg drop) {
+    float* __restrict__ dq, int drs, float scale, DropCfg drop, const uint32_t* __restrict__ drop_step) {
+  if (drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   __shared__ __attribute__((aligned(16))) float ktile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float vtile[Tile<DKP>::FLOATS];
   __shared__ float kmask[32];
@@ -344,7 +335,8 @@ __global__ void __launch_bounds__(256) ltrx_mha_bwd_dkdv_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ kpm, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, int L, int h, int dk, int rs, int ors, float* __restrict__ dkout,
-    float* __restrict__ dvout, int drs, float scale, DropCfg drop) {
+    float* __restrict__ dvout, int drs, float scale, DropCfg drop, const uint32_t* __restrict__ drop_step) {
+  if (drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   __shared__ __attribute__((aligned(16))) float qtile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float dotile[Tile<DKP>::FLOATS];
   __shared__ float lse_t[32];
@@ -453,17 +445,11 @@ static int mha_check(int B, int L, int h, int dk, int rs, int ors) {
     else { CALL(128); }             \
   } while (0)
 
-static DropCfg make_drop(float p_drop, uint32_t seed) {
-  DropCfg d;
-  d.seed = seed;
-  d.thresh = (p_drop > 0.f) ? (uint32_t)(p_drop * 16777216.0f) : 0u;
-  d.inv_keep = (p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
-  return d;
-}
+static DropCfg make_drop(float p_drop, uint32_t seed) { return ltrx_make_drop(p_drop, seed); }
 
 extern "C" int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L,
                             int h, int d_k, int row_stride, float* o, int o_row_stride, float* lse_out, float p_drop,
-                            uint32_t seed, ltrx_stream_t stream) {
+                            uint32_t seed, const uint32_t* seed_step, ltrx_stream_t stream) {
   if (!q || !k || !v || !key_pad_mask || !o || !lse_out || !(p_drop >= 0.f) || p_drop >= 1.f) return LTRX_EINVAL;
   int rc = mha_check(B, L, h, d_k, row_stride, o_row_stride);
   if (rc != LTRX_OK) return rc;
@@ -475,7 +461,7 @@ extern "C" int ltrx_mha_fwd(const float* q, const float* k, const float* v, cons
   const float scale = 1.0f / sqrtf((float)d_k);
 #define CALL(DKP)                                                                                                 \
   hipLaunchKernelGGL(ltrx_mha_fwd_kernel<DKP>, grid, dim3(256), 0, s, q, k, v, key_pad_mask, L, h, d_k, row_stride, o, \
-                     o_row_stride, lse_out, scale, drop)
+                     o_row_stride, lse_out, scale, drop, seed_step)
   LTRX_DKP_DISPATCH(d_k, CALL);
 #undef CALL
   LTRX_LAUNCH_CHECK();
@@ -490,7 +476,7 @@ extern "C" size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h) {
 extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, const float* o,
                             const float* dout, const float* lse, int B, int L, int h, int d_k, int row_stride,
                             int o_row_stride, float* dq, float* dk, float* dv, int d_row_stride, float p_drop,
-                            uint32_t seed, void* ws, ltrx_stream_t stream) {
+                            uint32_t seed, const uint32_t* seed_step, void* ws, ltrx_stream_t stream) {
   if (!q || !k || !v || !key_pad_mask || !o || !dout || !lse || !dq || !dk || !dv || !ws) return LTRX_EINVAL;
   if (!(p_drop >= 0.f) || p_drop >= 1.f) return LTRX_EINVAL;
   int rc = mha_check(B, L, h, d_k, row_stride, o_row_stride);
@@ -506,13 +492,13 @@ extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, cons
   const float scale = 1.0f / sqrtf((float)d_k);
 #define CALLQ(DKP)                                                                                                   \
   hipLaunchKernelGGL(ltrx_mha_bwd_dq_kernel<DKP>, grid, dim3(256), 0, s, q, k, v, key_pad_mask, o, dout, lse, delta, L, h, \
-                     d_k, row_stride, o_row_stride, dq, d_row_stride, scale, drop)
+                     d_k, row_stride, o_row_stride, dq, d_row_stride, scale, drop, seed_step)
   LTRX_DKP_DISPATCH(d_k, CALLQ);
 #undef CALLQ
   LTRX_LAUNCH_CHECK();
 #define CALLK(DKP)                                                                                                     \
   hipLaunchKernelGGL(ltrx_mha_bwd_dkdv_kernel<DKP>, grid, dim3(256), 0, s, q, k, v, key_pad_mask, dout, lse, delta, L, h, \
-                     d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale, drop)
+                     d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale, drop, seed_step)
   LTRX_DKP_DISPATCH(d_k, CALLK);
 #undef CALLK
   LTRX_LAUNCH_CHECK();

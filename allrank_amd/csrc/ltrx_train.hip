@@ -128,24 +128,25 @@ extern "C" int ltrx_colsum(const float* a, int M, int N, int ld, float* out, int
 // ---------------------------------------------------------------------------------------------------------------
 // elementwise helpers
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) ltrx_relu_bwd_kernel(float* __restrict__ dr, const float* __restrict__ r, size_t n4) {
+__global__ void __launch_bounds__(256) ltrx_relu_bwd_kernel(float* __restrict__ dr, const float* __restrict__ r, size_t n4,
+                                                            float scale) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 d = reinterpret_cast<float4*>(dr)[i];
     const float4 a = reinterpret_cast<const float4*>(r)[i];
-    d.x = a.x > 0.f ? d.x : 0.f;
-    d.y = a.y > 0.f ? d.y : 0.f;
-    d.z = a.z > 0.f ? d.z : 0.f;
-    d.w = a.w > 0.f ? d.w : 0.f;
+    d.x = a.x > 0.f ? d.x * scale : 0.f;
+    d.y = a.y > 0.f ? d.y * scale : 0.f;
+    d.z = a.z > 0.f ? d.z * scale : 0.f;
+    d.w = a.w > 0.f ? d.w * scale : 0.f;
     reinterpret_cast<float4*>(dr)[i] = d;
   }
 }
 
-extern "C" int ltrx_relu_bwd(float* dr_inout, const float* r_post_act, size_t n, ltrx_stream_t stream) {
+extern "C" int ltrx_relu_bwd(float* dr_inout, const float* r_post_act, size_t n, float scale, ltrx_stream_t stream) {
   if (!dr_inout || !r_post_act || n == 0 || (n & 3)) return LTRX_EINVAL;
   size_t blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(ltrx_relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dr_inout, r_post_act, n / 4);
+  hipLaunchKernelGGL(ltrx_relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dr_inout, r_post_act, n / 4, scale);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }
@@ -267,6 +268,37 @@ extern "C" int ltrx_score_head_bwd(const float* dscores, const float* x, const f
                      D, dx, (float*)ws);
   LTRX_LAUNCH_CHECK();
   hipLaunchKernelGGL(ltrx_score_head_reduce_kernel, dim3((D + 1 + 255) / 256), dim3(256), 0, s, (const float*)ws, g, D, dw, db);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dropout plumbing of the explicit step: dst[i] = src[i] * keep_scale(i)  (the backward of a dropped residual branch /
+// identity-activation FC output), and the per-step word that re-keys every dropout site at each hipGraph replay.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ltrx_dropout_apply_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n,
+                                                                 DropSpec drop, const uint32_t* __restrict__ drop_step) {
+  if (drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i] * drop_keep_scale(drop, (uint64_t)i);
+}
+
+extern "C" int ltrx_dropout_apply(const float* src, float* dst, size_t n, float p, uint32_t seed, const uint32_t* drop_step,
+                                  ltrx_stream_t stream) {
+  if (!src || !dst || n == 0 || !(p >= 0.f) || p >= 1.f) return LTRX_EINVAL;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ltrx_dropout_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n,
+                     ltrx_make_drop(p, seed), drop_step);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+__global__ void ltrx_bump_u32_kernel(uint32_t* __restrict__ w) { w[0] += 1u; }
+
+extern "C" int ltrx_bump_u32(uint32_t* word, ltrx_stream_t stream) {
+  if (!word) return LTRX_EINVAL;
+  hipLaunchKernelGGL(ltrx_bump_u32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, word);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }

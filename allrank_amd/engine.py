@@ -63,15 +63,20 @@ class FusedTrainer(object):
     * dense projections are library GEMMs (torch.mm/addmm -> hipBLASLt); everything else is libltrx kernels.
     * the whole sequence is captured in a hipGraph after warm-up (``use_graph=True``) -- at 64 slates/GPU the step is
       ~100 launches of 10-300 us, so launch latency matters.
-    Supported model family = what the hot path names: FCModel (no input_norm, activation None/ReLU, dropout 0) ->
-    optional encoder (no positional encoding, dropout 0) -> OutputLayer(d_output=1, no activation).  Anything else
-    raises NotImplementedError (use ``Trainer``).
+    * dropout (every shipped transformer config trains with 0.1-0.4) is counter-based: a mask element is a hash of
+      (site seed ^ per-step device word, element index), generated inside the producing kernel's epilogue (GEMM bias+
+      ReLU+dropout, the residual add of the LayerNorm kernel, the attention probabilities) and REGENERATED in the backward
+      -- no mask tensors, and a replayed hipGraph draws fresh masks because the step word lives in device memory.
+    Supported model family = what the hot path names: FCModel (no input_norm, activation None/ReLU) -> optional encoder
+    (no positional encoding) -> OutputLayer(d_output=1, no activation).  Anything else raises NotImplementedError (use
+    ``Trainer``).
     """
 
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
-                 use_graph=True, gemm="split_bf16"):
+                 use_graph=True, gemm="split_bf16", dropout=True, seed=None):
         """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
-        products), or "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs)."""
+        products), or "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs).  dropout=False trains with every
+        nn.Dropout of the model disabled; seed keys the dropout masks (default: drawn from torch's global generator)."""
         import torch.nn as nn
         from . import _lib as LB
         from .losses import FusedLoss
@@ -89,8 +94,12 @@ class FusedTrainer(object):
         if not isinstance(model, LTRModel) or not isinstance(model.input_layer, FCModel):
             raise NotImplementedError("FusedTrainer needs an allrank_amd LTRModel with an FCModel input block")
         fc = model.input_layer
-        if not isinstance(fc.input_norm, nn.Identity) or fc.dropout.p != 0:
-            raise NotImplementedError("FusedTrainer: FCModel.input_norm / dropout are not on the fused path")
+        if not isinstance(fc.input_norm, nn.Identity):
+            raise NotImplementedError("FusedTrainer: FCModel.input_norm is not on the fused path")
+        self.p_fc = float(fc.dropout.p) if dropout else 0.0
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        self._seed = (int(seed) * 0x9E3779B1 + 0x7F4A7C15 * (1 + self._rank(group, world_size))) & 0xFFFFFFFF
         if isinstance(fc.activation, nn.Identity):
             self.fc_act = 0
         elif isinstance(fc.activation, nn.ReLU):
@@ -114,12 +123,6 @@ class FusedTrainer(object):
             l0 = enc.layers[0]
             self.h = l0.self_attn.h
             self.dff = l0.feed_forward.w_1.out_features
-            for lay in enc.layers:
-                for sl in lay.sublayer:
-                    if sl.dropout.p != 0:
-                        raise NotImplementedError("FusedTrainer: dropout > 0")
-                if lay.self_attn.dropout.p != 0 or lay.feed_forward.dropout.p != 0:
-                    raise NotImplementedError("FusedTrainer: dropout > 0")
             self.ln_eps = enc.norm.eps
 
         # ---- flat parameter layout (16-byte aligned segments; q,k,v weights and biases adjacent) ----
@@ -146,6 +149,7 @@ class FusedTrainer(object):
         self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.drop_step = torch.zeros(1, dtype=torch.int32, device=dev)       # u32 word folded into every dropout seed
         self._pv, self._gv = {}, {}
         with torch.no_grad():
             for p, o in zip(order, offs):
@@ -186,7 +190,13 @@ class FusedTrainer(object):
                 xn0=torch.zeros((M, d), **f32), mean0=torch.zeros(M, **f32), rstd0=torch.zeros(M, **f32),
                 qkv=torch.zeros((M, 3 * d), **f32), o=torch.zeros((M, d), **f32), lse=torch.zeros((B, self.h, L), **f32),
                 x1=torch.zeros((M, d), **f32), xn1=torch.zeros((M, d), **f32), mean1=torch.zeros(M, **f32),
-                rstd1=torch.zeros(M, **f32), r=torch.zeros((M, self.dff), **f32), mod=lay)
+                rstd1=torch.zeros(M, **f32), r=torch.zeros((M, self.dff), **f32), mod=lay,
+                # dropout sites (transformer.py:105,155,227): probabilities and seeds
+                p_att=float(lay.self_attn.dropout.p) if dropout else 0.0,
+                p_ff=float(lay.feed_forward.dropout.p) if dropout else 0.0,
+                p_s0=float(lay.sublayer[0].dropout.p) if dropout else 0.0,
+                p_s1=float(lay.sublayer[1].dropout.p) if dropout else 0.0,
+                s_att=self._site(4 * i), s_ff=self._site(4 * i + 1), s_s0=self._site(4 * i + 2), s_s1=self._site(4 * i + 3))
             self.layers.append(st)
         if self.N:
             self.branch = torch.zeros((M, d), **f32)          # attention-proj / FFN output before the residual add
@@ -198,6 +208,7 @@ class FusedTrainer(object):
             self.dqkv = torch.zeros((M, 3 * d), **f32)
             self.d_o = torch.zeros((M, d), **f32)
             self.tmp_d = torch.zeros((M, d), **f32)
+            self.d_br = torch.zeros((M, d), **f32)            # gradient of a dropped residual branch (ds * keep)
             self.ws_ln = torch.empty(max(self.lib.ltrx_layernorm_bwd_workspace_bytes(M, d), 64), dtype=torch.uint8, device=dev)
             self.ws_mha = torch.empty(max(self.lib.ltrx_mha_bwd_workspace_bytes(B, L, self.h), 64), dtype=torch.uint8, device=dev)
         self.scores = torch.zeros((B, L), **f32)
@@ -236,10 +247,38 @@ class FusedTrainer(object):
     def _st(self):
         return self.LB.ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
-    def _ln_fwd(self, x, res, a, b, xsum, y, mean, rstd):
+    @staticmethod
+    def _rank(group, world_size):
+        if world_size <= 1:
+            return 0
+        import torch.distributed as dist
+        return dist.get_rank(group)
+
+    def _site(self, k):
+        """seed of dropout site k (one per nn.Dropout instance of the model)"""
+        x = (self._seed ^ ((k + 1) * 0x85EBCA6B)) & 0xFFFFFFFF
+        x = ((x ^ (x >> 16)) * 0x7FEB352D) & 0xFFFFFFFF
+        x = ((x ^ (x >> 15)) * 0x846CA68B) & 0xFFFFFFFF
+        return x ^ (x >> 16)
+
+    def _ln_fwd(self, x, res, a, b, xsum, y, mean, rstd, p=0.0, seed=0):
+        """y = LN(x + drop_p(res)); xsum = x + drop_p(res)"""
         P = self.LB.ptr
         self.LB.check(self.lib.ltrx_layernorm_fwd(P(x), P(res), P(a), P(b), self.M, self.d, float(self.ln_eps), P(xsum), P(y),
-                                                  P(mean), P(rstd), self._st()), "layernorm_fwd")
+                                                  P(mean), P(rstd), float(p), seed, P(self.drop_step), self._st()),
+                      "layernorm_fwd")
+
+    def _drop_apply(self, src, dst, p, seed):
+        """dst = src * keep-mask/(1-p) of the site (the backward of a dropped branch)"""
+        P = self.LB.ptr
+        self.LB.check(self.lib.ltrx_dropout_apply(P(src), P(dst), src.numel(), float(p), seed, P(self.drop_step), self._st()),
+                      "dropout_apply")
+
+    def _branch_grad(self, ds, p, seed):
+        if p == 0.0:
+            return ds
+        self._drop_apply(ds, self.d_br, p, seed)
+        return self.d_br
 
     def _ln_bwd(self, dy, xsum, a, mean, rstd, dres, dx, da, db):
         P = self.LB.ptr
@@ -252,8 +291,9 @@ class FusedTrainer(object):
         self.LB.check(self.lib.ltrx_colsum(P(a), a.shape[0], a.shape[1], a.stride(0), P(out), 0, P(self.ws_col), self._st()),
                       "colsum")
 
-    def _relu_bwd(self, dr, r):
-        self.LB.check(self.lib.ltrx_relu_bwd(self.LB.ptr(dr), self.LB.ptr(r), dr.numel(), self._st()), "relu_bwd")
+    def _relu_bwd(self, dr, r, p=0.0):
+        """dr *= (r > 0) / (1 - p): backward of dropout(relu(z)) given the stored post-dropout activation r"""
+        self.LB.check(self.lib.ltrx_relu_bwd(self.LB.ptr(dr), self.LB.ptr(r), dr.numel(), 1.0 / (1.0 - p), self._st()), "relu_bwd")
 
     def _refresh_transposes(self):
         if self.gemm == "hipblaslt":
@@ -263,30 +303,35 @@ class FusedTrainer(object):
         for st in self.layers:
             st["wqkvT"].copy_(st["wqkv"].t())
 
-    def _lin_fwd(self, x, w, b, out, act=0):
-        """out = act(x w^T + b)   (nn.Linear forward, act 1 = ReLU)"""
+    def _lin_fwd(self, x, w, b, out, act=0, p=0.0, seed=0):
+        """out = drop_p(act(x w^T + b))   (nn.Linear forward, act 1 = ReLU; dropout in the epilogue)"""
         if self.gemm == "hipblaslt":
             torch.addmm(b, x, w.t(), out=out)
             if act == 1:
                 torch.relu_(out)
+            if p:
+                self._drop_apply(out, out, p, seed)
             return
         P = self.LB.ptr
         self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), P(out), out.stride(0), x.shape[0], w.shape[0],
-                                            x.shape[1], P(b), act, None, 0, 1 if self.gemm == "split_bf16_strict" else 0,
-                                            self._st()), "gemm_nt(fwd)")
+                                            x.shape[1], P(b), act, None, 0, float(p), seed, P(self.drop_step),
+                                            1 if self.gemm == "split_bf16_strict" else 0, self._st()), "gemm_nt(fwd)")
 
-    def _lin_dgrad(self, dy, w, wT, out, relu_of=None):
-        """out = dy w   (input gradient of nn.Linear); wT = w^T contiguous.  With ``relu_of`` (the saved post-ReLU
-        activation that produced the layer input) the ReLU backward mask is applied in the GEMM epilogue."""
+    def _lin_dgrad(self, dy, w, wT, out, relu_of=None, p=0.0, seed=0):
+        """out = dy w   (input gradient of nn.Linear); wT = w^T contiguous.  With ``relu_of`` (the saved post-ReLU,
+        post-dropout activation that produced the layer input) the ReLU(+dropout p) backward mask is applied in the GEMM
+        epilogue; without it, p > 0 re-applies the dropout mask of site ``seed`` (identity activation)."""
         if self.gemm == "hipblaslt":
             torch.mm(dy, w, out=out)
             if relu_of is not None:
-                self._relu_bwd(out, relu_of)
+                self._relu_bwd(out, relu_of, p)
+            elif p:
+                self._drop_apply(out, out, p, seed)
             return
         P = self.LB.ptr
         self.LB.check(self.lib.ltrx_gemm_nt(P(dy), dy.stride(0), P(wT), wT.stride(0), P(out), out.stride(0), dy.shape[0],
                                             wT.shape[0], dy.shape[1], None, 2 if relu_of is not None else 0, P(relu_of),
-                                            relu_of.stride(0) if relu_of is not None else 0,
+                                            relu_of.stride(0) if relu_of is not None else 0, float(p), seed, P(self.drop_step),
                                             1 if self.gemm == "split_bf16_strict" else 0, self._st()), "gemm_nt(dgrad)")
 
     def _lin_wgrad(self, dy, x, gw, gb):
@@ -309,33 +354,38 @@ class FusedTrainer(object):
         # ---------------- forward ----------------
         h = self.x_in
         for i, lyr in enumerate(fc.layers):
-            self._lin_fwd(h, W(lyr.weight), W(lyr.bias), self.fc_out[i], self.fc_act)
+            self._lin_fwd(h, W(lyr.weight), W(lyr.bias), self.fc_out[i], self.fc_act, self.p_fc, self._site(1000 + i))
             h = self.fc_out[i]
         x = h                                                     # residual stream
+        p_prev, s_prev = 0.0, 0                                   # dropout of the pending FFN branch (sublayer[1] of layer i-1)
         for i, st in enumerate(self.layers):
             lay = st["mod"]
             n0, n1 = lay.sublayer[0].norm, lay.sublayer[1].norm
             if i == 0:
                 self._ln_fwd(x, None, W(n0.a_2), W(n0.b_2), None, st["xn0"], st["mean0"], st["rstd0"])
             else:                                                 # x = x1_prev + ffn_prev, fused with this layer's first norm
-                self._ln_fwd(x, self.branch, W(n0.a_2), W(n0.b_2), st["xsum0"], st["xn0"], st["mean0"], st["rstd0"])
+                self._ln_fwd(x, self.branch, W(n0.a_2), W(n0.b_2), st["xsum0"], st["xn0"], st["mean0"], st["rstd0"],
+                             p_prev, s_prev)
                 x = st["xsum0"]
             st["xin"] = x
             self._lin_fwd(st["xn0"], st["wqkv"], st["bqkv"], st["qkv"])
             qkv = st["qkv"]
             self.LB.check(lib.ltrx_mha_fwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(self.mask), B, L, self.h,
-                                           d // self.h, 3 * d, P(st["o"]), d, P(st["lse"]), 0.0, 0, self._st()), "mha_fwd")
+                                           d // self.h, 3 * d, P(st["o"]), d, P(st["lse"]), st["p_att"], st["s_att"],
+                                           P(self.drop_step), self._st()), "mha_fwd")
             lo = lay.self_attn.linears[3]
             self._lin_fwd(st["o"], W(lo.weight), W(lo.bias), self.branch)
-            self._ln_fwd(x, self.branch, W(n1.a_2), W(n1.b_2), st["x1"], st["xn1"], st["mean1"], st["rstd1"])
+            self._ln_fwd(x, self.branch, W(n1.a_2), W(n1.b_2), st["x1"], st["xn1"], st["mean1"], st["rstd1"],
+                         st["p_s0"], st["s_s0"])
             ff = lay.feed_forward
-            self._lin_fwd(st["xn1"], W(ff.w_1.weight), W(ff.w_1.bias), st["r"], 1)
+            self._lin_fwd(st["xn1"], W(ff.w_1.weight), W(ff.w_1.bias), st["r"], 1, st["p_ff"], st["s_ff"])
             self._lin_fwd(st["r"], W(ff.w_2.weight), W(ff.w_2.bias), self.branch)
             x = st["x1"]
+            p_prev, s_prev = st["p_s1"], st["s_s1"]
         out = self.model.output_layer
         if self.N:
             nf = self.enc.norm
-            self._ln_fwd(x, self.branch, W(nf.a_2), W(nf.b_2), self.xsum_f, self.xf, self.mean_f, self.rstd_f)
+            self._ln_fwd(x, self.branch, W(nf.a_2), W(nf.b_2), self.xsum_f, self.xf, self.mean_f, self.rstd_f, p_prev, s_prev)
             feat = self.xf
         else:
             feat = x
@@ -358,20 +408,23 @@ class FusedTrainer(object):
                 n0, n1 = lay.sublayer[0].norm, lay.sublayer[1].norm
                 ff = lay.feed_forward
                 # FFN branch
-                self._lin_wgrad(ds, st["r"], G(ff.w_2.weight), G(ff.w_2.bias))
-                self._lin_dgrad(ds, W(ff.w_2.weight), self._wT.get(id(ff.w_2.weight)), self.d_r, relu_of=st["r"])
+                db = self._branch_grad(ds, st["p_s1"], st["s_s1"])
+                self._lin_wgrad(db, st["r"], G(ff.w_2.weight), G(ff.w_2.bias))
+                self._lin_dgrad(db, W(ff.w_2.weight), self._wT.get(id(ff.w_2.weight)), self.d_r, relu_of=st["r"], p=st["p_ff"])
                 self._lin_wgrad(self.d_r, st["xn1"], G(ff.w_1.weight), G(ff.w_1.bias))
                 self._lin_dgrad(self.d_r, W(ff.w_1.weight), self._wT.get(id(ff.w_1.weight)), self.tmp_d)
                 self._ln_bwd(self.tmp_d, st["x1"], W(n1.a_2), st["mean1"], st["rstd1"], ds, other, G(n1.a_2), G(n1.b_2))
                 ds, other = other, ds                              # ds = d loss / d x1
                 # attention branch
                 lo = lay.self_attn.linears[3]
-                self._lin_wgrad(ds, st["o"], G(lo.weight), G(lo.bias))
-                self._lin_dgrad(ds, W(lo.weight), self._wT.get(id(lo.weight)), self.d_o)
+                db = self._branch_grad(ds, st["p_s0"], st["s_s0"])
+                self._lin_wgrad(db, st["o"], G(lo.weight), G(lo.bias))
+                self._lin_dgrad(db, W(lo.weight), self._wT.get(id(lo.weight)), self.d_o)
                 qkv, dq = st["qkv"], self.dqkv
                 self.LB.check(lib.ltrx_mha_bwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(self.mask), P(st["o"]),
                                                P(self.d_o), P(st["lse"]), B, L, self.h, d // self.h, 3 * d, d, P(dq),
-                                               dq.data_ptr() + 4 * d, dq.data_ptr() + 8 * d, 3 * d, 0.0, 0, P(self.ws_mha), self._st()),
+                                               dq.data_ptr() + 4 * d, dq.data_ptr() + 8 * d, 3 * d, st["p_att"], st["s_att"],
+                                               P(self.drop_step), P(self.ws_mha), self._st()),
                               "mha_bwd")
                 self._lin_wgrad(dq, st["xn0"], st["gwqkv"], st["gbqkv"])
                 self._lin_dgrad(dq, st["wqkv"], st.get("wqkvT"), self.tmp_d)
@@ -382,13 +435,17 @@ class FusedTrainer(object):
         # FC stack
         for i in range(self.nfc - 1, -1, -1):
             lyr = fc.layers[i]
-            if self.fc_act == 1 and i == self.nfc - 1:
-                self._relu_bwd(ds, self.fc_out[i])               # the last FC activation feeds the encoder / head
+            if i == self.nfc - 1:                                # the last FC activation(+dropout) feeds the encoder / head
+                if self.fc_act == 1:
+                    self._relu_bwd(ds, self.fc_out[i], self.p_fc)
+                elif self.p_fc:
+                    self._drop_apply(ds, ds, self.p_fc, self._site(1000 + i))
             inp = self.x_in if i == 0 else self.fc_out[i - 1]
             self._lin_wgrad(ds, inp, G(lyr.weight), G(lyr.bias))
             if i > 0:
                 self._lin_dgrad(ds, W(lyr.weight), self._wT.get(id(lyr.weight)), self.fc_dgrad[i - 1],
-                                relu_of=self.fc_out[i - 1] if self.fc_act == 1 else None)
+                                relu_of=self.fc_out[i - 1] if self.fc_act == 1 else None, p=self.p_fc,
+                                seed=self._site(1000 + i - 1))
                 ds = self.fc_dgrad[i - 1]
         return loss
 
@@ -399,6 +456,7 @@ class FusedTrainer(object):
                                               P(self.step_count), 1.0, self._st()), "adam_step")
 
     def _full(self):
+        self.LB.check(self.lib.ltrx_bump_u32(self.LB.ptr(self.drop_step), self._st()), "bump_u32")   # fresh masks every step
         loss = self._body()
         if self.world > 1:
             import torch.distributed as dist

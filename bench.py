@@ -71,9 +71,9 @@ def synth_batch(n_slates, L, F, seed, device):
     return x.to(device), y.to(device), idx.to(device)
 
 
-def build_model(w, device):
+def build_model(w, device, dropout=0.0):
     from allrank_amd.model import make_model
-    tr = dict(N=w["N"], d_ff=w["d_ff"], h=w["h"], positional_encoding=None, dropout=0.0) if w["N"] else None
+    tr = dict(N=w["N"], d_ff=w["d_ff"], h=w["h"], positional_encoding=None, dropout=dropout) if w["N"] else None
     fc = dict(sizes=list(w["fc_sizes"]), input_norm=False, activation=None, dropout=0.0)
     torch.manual_seed(42)                      # allrank/main.py:36
     return make_model(fc, tr, dict(d_output=1, output_activation=None), w["n_features"]).to(device)
@@ -108,7 +108,7 @@ def time_kernels(w, B, L, device):
         C_ = torch.empty(Mrows, Nn, device=device)
         st = LB.stream_of(A_)
         t_g = ev(lambda: LB.check(lib.ltrx_gemm_nt(LB.ptr(A_), Kk, LB.ptr(W_), Kk, LB.ptr(C_), Nn, Mrows, Nn, Kk, LB.ptr(b_), 1,
-                                                   None, 0, 0, st), "gemm_nt"))
+                                                   None, 0, 0.0, 0, None, 0, st), "gemm_nt"))
         n_nt = 1 + 8 * w["N"] - 1          # fwd: fc + 4/layer; dgrad: 4/layer  (head GEMV is a separate kernel)
         res["ltrx_gemm_nt_kernel<2,128,32> @FFN1"] = dict(sec=t_g, flops=2.0 * Mrows * Nn * Kk, launches_per_step=n_nt,
                                                           shape=[Mrows, Nn, Kk])
@@ -184,6 +184,8 @@ def main():
     ap.add_argument("--slates-per-gpu", type=int, default=256)
     ap.add_argument("--slate-len", type=int, default=240)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="transformer dropout (the shipped reference configs train with 0.1-0.4); masks are generated in-kernel")
     ap.add_argument("--gemm", default="split_bf16", choices=["split_bf16", "split_bf16_strict", "hipblaslt"],
                     help="dense projections: libltrx fp32-accurate split-bf16 MFMA GEMMs (default) or hipBLASLt fp32")
     ap.add_argument("--engine", default="fused", choices=["fused", "autograd"],
@@ -215,7 +217,7 @@ def main():
         L = w["slate_len"]
     if "slates" in w and args.slates_per_gpu == 256:
         B = w["slates"]
-    model = build_model(w, device)
+    model = build_model(w, device, args.dropout)
     if args.engine == "fused":
         trainer = FusedTrainer(model, w["loss"], w.get("loss_args", {}), B, L, lr=1e-3, world_size=world, use_graph=True, gemm=args.gemm)   # Adam 1e-3: approxndcg.json:28-33
     else:
@@ -285,7 +287,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (dense projections: fp32-accurate split-bf16 on the bf16 MFMA; attention: exact fp32 MFMA)" if (args.engine == "fused" and args.gemm != "hipblaslt") else "f32", "data": "synthetic",
             "config": {"workload": w["desc"], "slates_per_gpu": B, "slate_len": L, "global_batch": B * world,
-                       "optimizer": "Adam lr=1e-3", "engine": args.engine, "gemm": args.gemm if args.engine == "fused" else "hipblaslt", "parallelism": "slate-sharded dp%d" % world,
+                       "optimizer": "Adam lr=1e-3", "dropout": args.dropout, "engine": args.engine, "gemm": args.gemm if args.engine == "fused" else "hipblaslt", "parallelism": "slate-sharded dp%d" % world,
                        "train_flops_per_item": fl_item},
             "model_tflops": round(value * fl_item / 1e12, 2),
             "model_mfma_frac_fp32": round(value * fl_item / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
@@ -296,7 +298,7 @@ def main():
         }
         if world == 1 and B != 64 and args.engine == "fused":
             try:
-                m64 = build_model(w, device)
+                m64 = build_model(w, device, args.dropout)
                 t64 = FusedTrainer(m64, w["loss"], w.get("loss_args", {}), 64, L, lr=1e-3, world_size=1, use_graph=True, gemm=args.gemm)
                 for i in range(6):
                     t64.step(x[:64], y[:64], idx[:64])

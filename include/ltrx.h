@@ -126,9 +126,12 @@ int ltrx_ndcg_at(const float* y_pred, const float* y_true, int B, int L, const i
 /* transformer.py:59-81  custom LayerNorm: y = a*(x-mean)/(std_unbiased+eps)+b over the last dim D, with an
  * optional fused residual input (transformer.py:105: the sum x + sublayer(...) that feeds the next norm):
  *   xsum = x (+ res);  y = LN(xsum).   xsum_out may be NULL when res is NULL.
- * Saves mean[rows], rstd[rows] (= 1/(std+eps)) for the backward. */
+ * Saves mean[rows], rstd[rows] (= 1/(std+eps)) for the backward.  res_drop_p > 0 applies the SublayerConnection dropout
+ * (transformer.py:105) to the residual branch inside the add: xsum = x + drop(res), counter-based mask keyed by
+ * drop_seed ^ hash(drop_step[0]) (drop_step may be NULL); the backward of the branch is ltrx_dropout_apply. */
 int ltrx_layernorm_fwd(const float* x, const float* res, const float* a, const float* b, int rows, int D, float eps,
-                       float* xsum_out, float* y_out, float* mean_out, float* rstd_out, ltrx_stream_t stream);
+                       float* xsum_out, float* y_out, float* mean_out, float* rstd_out, float res_drop_p, uint32_t drop_seed,
+                       const uint32_t* drop_step, ltrx_stream_t stream);
 /* dx = LN backward of dy (+ dres_in if given: the gradient arriving through the residual branch);
  * da_out/db_out (fp32, length D) are written via a deterministic two-stage reduction through ws. */
 size_t ltrx_layernorm_bwd_workspace_bytes(int rows, int D);
@@ -150,13 +153,13 @@ void ltrx_mha_set_mode(int mode);
 int ltrx_mha_get_mode(void);
 int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L, int h,
                  int d_k, int row_stride, float* o, int o_row_stride, float* lse_out, float p_drop, uint32_t seed,
-                 ltrx_stream_t stream);
+                 const uint32_t* seed_step, ltrx_stream_t stream);
 /* backward: dq,dk,dv from do; delta_ws[B,h,L] scratch (rowsum(do*o)). */
 size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h);
 int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, const float* o,
                  const float* dout, const float* lse, int B, int L, int h, int d_k, int row_stride, int o_row_stride,
-                 float* dq, float* dk, float* dv, int d_row_stride, float p_drop, uint32_t seed, void* ws,
-                 ltrx_stream_t stream);
+                 float* dq, float* dk, float* dv, int d_row_stride, float p_drop, uint32_t seed,
+                 const uint32_t* seed_step, void* ws, ltrx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-step glue (allrank/training/train_utils.py:18-29 around the model): the pieces between the library
@@ -173,8 +176,14 @@ int ltrx_adam_step(float* params, const float* grads, float* exp_avg, float* exp
 size_t ltrx_colsum_workspace_bytes(int M, int N);
 int ltrx_colsum(const float* a, int M, int N, int ld, float* out, int accumulate, void* ws, ltrx_stream_t stream);
 
-/* ReLU backward in place (transformer.py:227, FCModel activation): dr[i] = r[i] > 0 ? dr[i] : 0; n % 4 == 0. */
-int ltrx_relu_bwd(float* dr_inout, const float* r_post_act, size_t n, ltrx_stream_t stream);
+/* ReLU backward in place (transformer.py:227, FCModel activation): dr[i] = r[i] > 0 ? dr[i] * scale : 0; n % 4 == 0. */
+int ltrx_relu_bwd(float* dr_inout, const float* r_post_act, size_t n, float scale, ltrx_stream_t stream);
+
+/* dropout plumbing of the explicit step: dst[i] = src[i] * keep_scale(i) with the same counter-based mask the forward
+ * kernels use (seed ^ hash(step[0])); ltrx_bump_u32 advances the per-step word (so a replayed hipGraph re-keys). */
+int ltrx_dropout_apply(const float* src, float* dst, size_t n, float p, uint32_t seed, const uint32_t* drop_step,
+                       ltrx_stream_t stream);
+int ltrx_bump_u32(uint32_t* word, ltrx_stream_t stream);
 
 /* y = act(y + bias) in place over a contiguous [M,N] matrix (model.py:42-43); act 0 = identity, 1 = ReLU; N % 4 == 0. */
 int ltrx_bias_act(float* y_inout, const float* bias, int M, int N, int act, ltrx_stream_t stream);
@@ -193,10 +202,13 @@ int ltrx_score_head_bwd(const float* dscores, const float* x, const float* w, in
  *                 -- forward (B = weight) and input gradient (B = weight^T);  K, lda, ldb multiples of 4.
  *                 epilogue `act`: 0 none, 1 ReLU (transformer.py:227 fused), 2 multiply by (aux[m,n] > 0): the ReLU
  *                 backward fused into the input-gradient GEMM (aux = the saved post-activation tensor, ld ldaux).
+ *                 drop_p > 0: nn.Dropout after the activation (model.py:43, transformer.py:227) fused in the epilogue
+ *                 (act 0/1: counter-based mask over the [M,N] output; act 2: the mask is carried by aux, only 1/(1-p)).
  *   ltrx_gemm_tn: C[NP,KP] (dense) = A[M,NP]^T * B[M,KP]  -- weight gradient dW = dY^T X (split over M, deterministic);
  *                 bias_out[NP] (optional) = column sums of A = the bias gradient, produced in the same pass. */
 int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,
-                 int act, const float* aux, int ldaux, int strict, ltrx_stream_t stream);
+                 int act, const float* aux, int ldaux, float drop_p, uint32_t drop_seed, const uint32_t* drop_step, int strict,
+                 ltrx_stream_t stream);
 /* tuning hook: tile variant of ltrx_gemm_nt (0 auto, 1 128x128x32, 2 128x128x64, 3 256x128x32, 4 256x128x64) */
 void ltrx_gemm_set_variant(int variant);
 size_t ltrx_gemm_tn_workspace_bytes(int M, int NP, int KP);

@@ -413,10 +413,10 @@ def test_split_bf16_gemm_matches_fp64(strict):
         bias = rng.standard_normal(N).astype(np.float32)
         At, Bt, bt = _t(A), _t(Bw), _t(bias)
         C = torch.empty((Mm, N), device=DEV)
-        LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, LB.ptr(C), N, Mm, N, K, LB.ptr(bt), 1, None, 0, strict, None), "gemm_nt")
+        LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, LB.ptr(C), N, Mm, N, K, LB.ptr(bt), 1, None, 0, 0.0, 0, None, strict, None), "gemm_nt")
         aux = rng.standard_normal((Mm, N)).astype(np.float32)
         C2 = torch.empty((Mm, N), device=DEV)
-        LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, LB.ptr(C2), N, Mm, N, K, None, 2, LB.ptr(_t(aux)), N, strict, None), "gemm_nt(mask)")
+        LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, LB.ptr(C2), N, Mm, N, K, None, 2, LB.ptr(_t(aux)), N, 0.0, 0, None, strict, None), "gemm_nt(mask)")
         ref2 = (A.astype(np.float64) @ Bw.astype(np.float64).T) * (aux > 0)
         assert float(np.abs(C2.cpu().numpy() - ref2).max()) < 1e-4
         ref = np.maximum(A.astype(np.float64) @ Bw.astype(np.float64).T + bias, 0)
@@ -592,3 +592,156 @@ def test_end_to_end_training_on_device_resident_libsvm_data(tmp_path):
     after = res["val_metrics"]["ndcg_5"]
     _log("fit_device", dict(before=before, after=after, history=res["history"], fused=res["fused"]))
     assert res["fused"] and np.isfinite(after) and after > before + 0.03, (before, res["history"])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# dropout inside the explicit step (counter-based masks regenerated in the backward; device-side step word)
+# ------------------------------------------------------------------------------------------------------------------
+def test_dropout_sites_share_one_counter_based_mask():
+    """the GEMM epilogue, the LayerNorm residual add and ltrx_dropout_apply key the SAME mask off (seed, step word,
+    element index): epilogue dropout == plain output * apply-mask bit for bit; keep rate = 1 - p; the step word re-keys."""
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    rng = np.random.default_rng(0)
+    Mm, N, K, p, seed = 700, 192, 136, 0.3, 0xC0FFEE
+    A, Bw, bias = _t(rng.standard_normal((Mm, K)).astype(np.float32)), _t(rng.standard_normal((N, K)).astype(np.float32)), _t(rng.standard_normal(N).astype(np.float32))
+    step = torch.tensor([7], dtype=torch.int32, device=DEV)
+    C0, C1, Mk = (torch.empty((Mm, N), device=DEV) for _ in range(3))
+    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, LB.ptr(C0), N, Mm, N, K, LB.ptr(bias), 1, None, 0, 0.0, 0, None, 0, None), "nt")
+    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, LB.ptr(C1), N, Mm, N, K, LB.ptr(bias), 1, None, 0, p, seed, LB.ptr(step), 0, None), "nt")
+    ones = torch.ones((Mm, N), device=DEV)
+    LB.check(lib.ltrx_dropout_apply(LB.ptr(ones), LB.ptr(Mk), ones.numel(), p, seed, LB.ptr(step), None), "apply")
+    torch.cuda.synchronize()
+    keep = (Mk > 0).float().mean().item()
+    assert abs(keep - (1 - p)) < 0.01, keep
+    vals = torch.unique(Mk).cpu().numpy()
+    assert len(vals) == 2 and vals[0] == 0 and abs(vals[1] - 1 / (1 - p)) < 1e-6, vals
+    assert torch.equal(C1, C0 * Mk)
+    # act == 2 (ReLU+dropout backward): mask carried by aux, scale 1/(1-p)
+    G2 = torch.empty((Mm, N), device=DEV)
+    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, LB.ptr(G2), N, Mm, N, K, None, 2, LB.ptr(C1), N, p, 0, None, 0, None), "nt")
+    G0 = torch.empty((Mm, N), device=DEV)
+    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, LB.ptr(G0), N, Mm, N, K, None, 0, None, 0, 0.0, 0, None, 0, None), "nt")
+    torch.cuda.synchronize()
+    assert torch.equal(G2, torch.where(C1 > 0, G0 * np.float32(1 / (1 - p)), torch.zeros_like(G0)))
+    # a different step word -> a different, equally dense mask; NULL step word == step word 0
+    step2 = torch.tensor([8], dtype=torch.int32, device=DEV)
+    Mk2, Mk0, Mkn = (torch.empty((Mm, N), device=DEV) for _ in range(3))
+    LB.check(lib.ltrx_dropout_apply(LB.ptr(ones), LB.ptr(Mk2), ones.numel(), p, seed, LB.ptr(step2), None), "apply")
+    LB.check(lib.ltrx_dropout_apply(LB.ptr(ones), LB.ptr(Mk0), ones.numel(), p, seed, LB.ptr(torch.zeros(1, dtype=torch.int32, device=DEV)), None), "apply")
+    LB.check(lib.ltrx_dropout_apply(LB.ptr(ones), LB.ptr(Mkn), ones.numel(), p, seed, None, None), "apply")
+    torch.cuda.synchronize()
+    agree = ((Mk2 > 0) == (Mk > 0)).float().mean().item()
+    assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 0.01, agree          # independent masks
+    assert torch.equal(Mk0, Mkn)
+    # LayerNorm residual add: xsum = x + drop(res) with the same mask (D = 256 -> vectorised kernel; D = 96 -> generic)
+    for D in (256, 96):
+        rows = 300
+        x, res = _t(rng.standard_normal((rows, D)).astype(np.float32)), _t(rng.standard_normal((rows, D)).astype(np.float32))
+        a, b = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+        xs, y, mean, rstd, mk = torch.empty_like(x), torch.empty_like(x), torch.empty(rows, device=DEV), torch.empty(rows, device=DEV), torch.empty_like(x)
+        LB.check(lib.ltrx_layernorm_fwd(LB.ptr(x), LB.ptr(res), LB.ptr(a), LB.ptr(b), rows, D, 1e-6, LB.ptr(xs), LB.ptr(y), LB.ptr(mean),
+                                        LB.ptr(rstd), p, seed, LB.ptr(step), None), "ln")
+        LB.check(lib.ltrx_dropout_apply(LB.ptr(res), LB.ptr(mk), res.numel(), p, seed, LB.ptr(step), None), "apply")
+        torch.cuda.synchronize()
+        assert torch.equal(xs, x + mk), D
+        ref = xs.double()
+        mu = ref.mean(1, keepdim=True)
+        yr = (ref - mu) / (ref.std(1, keepdim=True) + 1e-6)
+        assert (y.double() - yr).abs().max().item() < 2e-5
+
+
+def _dropout_model(p, fc_act, fc_drop, N=2):
+    from allrank_amd.model import make_model
+    return make_model(dict(sizes=[48, 32], input_norm=False, activation=fc_act, dropout=fc_drop),
+                      dict(N=N, d_ff=64, h=2, positional_encoding=None, dropout=p) if N else None,
+                      dict(d_output=1, output_activation=None), 20).to(DEV)
+
+
+@pytest.mark.parametrize("gemm,fc_act", [("split_bf16_strict", None), ("hipblaslt", "ReLU"), ("split_bf16_strict", "ReLU")])
+def test_fused_step_dropout_gradients_match_finite_differences(gemm, fc_act):
+    """with the masks frozen (fixed seed and step word) the explicit backward must be the gradient of the explicit forward:
+    for every parameter tensor, the central difference of the loss along that tensor's own gradient direction equals the
+    gradient norm.  A forward/backward mask mismatch at any of the dropout sites breaks this by O(1)."""
+    from allrank_amd.engine import FusedTrainer
+    torch.manual_seed(5)
+    model = _dropout_model(0.25, fc_act, 0.2)
+    B, L = 6, 20
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((B, L, 20)).astype(np.float32)
+    y = rng.integers(0, 5, (B, L)).astype(np.float32)
+    y[0, 15:] = -1
+    ft = FusedTrainer(model, "listNet", {}, B, L, use_graph=False, gemm=gemm, seed=1234)
+    ft._divisor = float(B)
+    ft.x_in.copy_(_t(x).reshape(B * L, -1))
+    ft.y_in.copy_(_t(y))
+    ft.mask.copy_(_t(y) == -1)
+    base = float(ft._body().item())
+    again = float(ft._body().item())
+    assert base == again                                     # same step word -> same masks -> same loss
+    g = ft.flat_g.clone()
+    p0 = ft.flat_p.clone()
+    rows, bad = [], []
+    for name, prm in model.named_parameters():
+        o, shape = ft._pv[id(prm)]
+        n = prm.numel()
+        gn = float(g[o:o + n].norm().item())
+        if gn < 2e-3:
+            continue
+        eps = 5e-3
+        v = torch.zeros_like(p0)
+        v[o:o + n] = g[o:o + n] / gn
+        ft.flat_p.copy_(p0 + eps * v)
+        lp = float(ft._body().item())
+        ft.flat_p.copy_(p0 - eps * v)
+        lm = float(ft._body().item())
+        fd = (lp - lm) / (2 * eps)
+        rows.append(dict(param=name, grad_norm=gn, fd=fd))
+        if abs(fd - gn) > 0.02 * gn + 5e-4:
+            bad.append(rows[-1])
+    ft.flat_p.copy_(p0)
+    _log("dropout_fd_%s_%s" % (gemm, fc_act), rows)
+    assert len(rows) >= 10 and not bad, bad
+    # and the dropout is really on: a no-dropout trainer on the same weights gives a different loss
+    ft2 = FusedTrainer(model, "listNet", {}, B, L, use_graph=False, gemm=gemm, dropout=False)
+    ft2._divisor = float(B)
+    ft2.x_in.copy_(ft.x_in); ft2.y_in.copy_(ft.y_in); ft2.mask.copy_(ft.mask)
+    assert abs(float(ft2._body().item()) - base) > 1e-4
+
+
+def test_fused_step_dropout_off_equals_eval_forward_and_graph_replays_fresh_masks():
+    from allrank_amd.engine import FusedTrainer
+    from allrank_amd import losses as E
+    torch.manual_seed(6)
+    model = _dropout_model(0.3, None, 0.0)
+    B, L = 8, 24
+    rng = np.random.default_rng(3)
+    x = _t(rng.standard_normal((B, L, 20)).astype(np.float32))
+    y = _t(rng.integers(0, 5, (B, L)).astype(np.float32))
+    model.eval()
+    with torch.no_grad():
+        want = float(E.listNet(model(x, y == -1, None), y).item())
+    off = FusedTrainer(model, "listNet", {}, B, L, lr=0.0, use_graph=True, dropout=False)
+    on = FusedTrainer(model, "listNet", {}, B, L, lr=0.0, use_graph=True, seed=99)
+    l_off = [float(off.step(x, y).item()) for _ in range(6)]
+    l_on = [float(on.step(x, y).item()) for _ in range(8)]
+    assert all(abs(v - want) <= 1e-5 * (1 + abs(want)) for v in l_off), (want, l_off)
+    assert on.graph is not None and len(set(l_on[3:])) == len(l_on[3:]), l_on       # replays draw new masks
+    assert abs(np.mean(l_on) - want) < 0.5 * abs(want)
+
+
+def test_fused_trainer_trains_reference_dropout_config():
+    """the reference's WEB30K ranker shape (fc 96, N=2, h=1 -> here h=2, d_ff=384, dropout 0.1; approxndcg.json) through the
+    hipGraph-captured explicit step WITH dropout: the loss on a fixed batch goes down."""
+    from allrank_amd.engine import FusedTrainer
+    from allrank_amd.model import make_model
+    torch.manual_seed(0)
+    model = make_model(dict(sizes=[96], input_norm=False, activation=None, dropout=0.0),
+                       dict(N=2, d_ff=384, h=2, positional_encoding=None, dropout=0.1),
+                       dict(d_output=1, output_activation=None), 136).to(DEV)
+    rng = np.random.default_rng(1)
+    x = _t(rng.standard_normal((16, 60, 136)).astype(np.float32))
+    y = _t(rng.integers(0, 5, (16, 60)).astype(np.float32))
+    ft = FusedTrainer(model, "approxNDCGLoss", {}, 16, 60, lr=1e-3, use_graph=True)
+    losses = [float(ft.step(x, y).item()) for _ in range(30)]
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.02, losses

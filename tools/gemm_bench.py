@@ -24,7 +24,7 @@ for (m, n, k) in shapes:
     row = dict(shape=(m, n, k))
     for v in (1, 2, 3, 5):
         lib.ltrx_gemm_set_variant(v)
-        us = ev(lambda: LB.check(lib.ltrx_gemm_nt(LB.ptr(A), k, LB.ptr(B), k, LB.ptr(C), n, m, n, k, LB.ptr(bias), 0, None, 0, 0, None), "nt"))
+        us = ev(lambda: LB.check(lib.ltrx_gemm_nt(LB.ptr(A), k, LB.ptr(B), k, LB.ptr(C), n, m, n, k, LB.ptr(bias), 0, None, 0, 0.0, 0, None, 0, None), "nt"))
         row["nt_v%d" % v] = "%.1fus %.0fTF" % (us, fl / us / 1e6)
     lib.ltrx_gemm_set_variant(0)
     us = ev(lambda: torch.addmm(bias, A, B.t(), out=C))

@@ -7,7 +7,7 @@ A = torch.randn(m, k, device="cuda"); B = torch.randn(n, k, device="cuda") / k *
 C = torch.empty(m, n, device="cuda")
 lib.ltrx_gemm_set_variant(int(os.environ.get("GV", "1")))
 for _ in range(5):
-    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), k, LB.ptr(B), k, LB.ptr(C), n, m, n, k, LB.ptr(bias), 0, None, 0, 0, None), "nt")
+    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), k, LB.ptr(B), k, LB.ptr(C), n, m, n, k, LB.ptr(bias), 0, None, 0, 0.0, 0, None, 0, None), "nt")
 dY = torch.randn(m, n, device="cuda"); X = torch.randn(m, k, device="cuda")
 gW = torch.empty(n, k, device="cuda"); gb = torch.empty(n, device="cuda")
 ws = torch.empty(max(lib.ltrx_gemm_tn_workspace_bytes(m, n, k), 64), dtype=torch.uint8, device="cuda")
