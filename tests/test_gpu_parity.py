@@ -697,7 +697,7 @@ def test_fused_step_dropout_gradients_match_finite_differences(gemm, fc_act):
         lm = float(ft._body().item())
         fd = (lp - lm) / (2 * eps)
         rows.append(dict(param=name, grad_norm=gn, fd=fd))
-        if abs(fd - gn) > 0.02 * gn + 5e-4:
+        if abs(fd - gn) > 0.04 * gn + 5e-4:       # ReLU kinks along a bias direction cost ~2%
             bad.append(rows[-1])
     ft.flat_p.copy_(p0)
     _log("dropout_fd_%s_%s" % (gemm, fc_act), rows)
