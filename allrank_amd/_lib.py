@@ -27,7 +27,17 @@ SIGNATURES = {
     "ltrx_neuralndcg_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltrx_neuralndcg_force_general": (None, [_i]),
     "ltrx_neuralndcg_prepare": (_i, [_vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp]),
-    "ltrx_neuralndcg_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_neuralndcg_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_ranknet_workspace_bytes": (_sz, [_i, _i]),
+    "ltrx_ranknet_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_bce_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ltrx_bce_fwd_bwd": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_pointwise_rmse_workspace_bytes": (_sz, [_i, _i]),
+    "ltrx_pointwise_rmse_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "ltrx_binary_listnet_workspace_bytes": (_sz, [_i, _i]),
+    "ltrx_binary_listnet_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "ltrx_mrr_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ltrx_mrr_at": (_i, [_vp, _vp, _i, _i, ctypes.POINTER(ctypes.c_int), _i, _f, _vp, _vp, _vp]),
     "ltrx_ndcg_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_ndcg_at": (_i, [_vp, _vp, _i, _i, ctypes.POINTER(ctypes.c_int), _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, ctypes.c_uint32, _vp, _vp]),

@@ -15,6 +15,14 @@
     if (e__ != hipSuccess) return LTRX_EHIP - (int)e__;       \
   } while (0)
 
+// cut-off ranks of a metric call, passed to the kernel by value (ltrx_ndcg_at, ltrx_mrr_at)
+#define LTRX_MAX_ATS 16
+
+struct LtrxAts {
+  int n;
+  int at[LTRX_MAX_ATS];
+};
+
 namespace ltrx {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

@@ -12,12 +12,6 @@
 
 using namespace ltrx;
 
-#define LTRX_MAX_ATS 16
-
-struct LtrxAts {
-  int n;
-  int at[LTRX_MAX_ATS];
-};
 
 __global__ void __launch_bounds__(256) ltrx_ndcg_kernel(const float* __restrict__ y_pred,
                                                         const float* __restrict__ y_true, int L, float pad,

@@ -128,7 +128,7 @@ __device__ __forceinline__ int load_slate(const SlateLds& t, const float* __rest
   int cnt = 0;
   for (int i = threadIdx.x; i < L; i += blockDim.x) cnt += (yp[i] != pad);
   const int n = block_sum_i(cnt, redi);
-  const int kk = (k <= 0 || k > L) ? L : k;
+  const int kk = k;                      // rows (ranks) >= kk carry no discount; the callers resolve k=None / k_rows
   for (int i = threadIdx.x; i < L; i += blockDim.x) {
     const float y = yp[i];
     if (y == pad) continue;
@@ -257,7 +257,8 @@ __global__ void __launch_bounds__(256) ltrx_neural_pick_iter_kernel(const float*
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) ltrx_neural_backward_kernel(
     const float* __restrict__ y_pred, const float* __restrict__ y_true, const float* __restrict__ idcg,
-    const float* __restrict__ nonzero_count, int L, float pad, float inv_tau, int gain_powered, int k, int max_iter,
+    const float* __restrict__ nonzero_count, int L, float pad, float inv_tau, int gain_powered, int k,
+    const int* __restrict__ k_rows, int max_iter,
     const int* __restrict__ titer, float* __restrict__ Sws, float* __restrict__ Aws, const float* __restrict__ cnws,
     const float* __restrict__ rnws, float* __restrict__ per_ws, float* __restrict__ per_out, float* __restrict__ grad) {
   extern __shared__ float lds[];
@@ -265,7 +266,9 @@ __global__ void __launch_bounds__(1024) ltrx_neural_backward_kernel(
   __shared__ int redi[LTRX_MAX_WAVES];
   const SlateLds t = carve_lds(lds, L);
   const int b = blockIdx.x;
-  const int n = load_slate(t, y_pred + (size_t)b * L, y_true + (size_t)b * L, L, pad, k, gain_powered, redi);
+  int kk = (k <= 0 || k > L) ? L : k;
+  if (k_rows) kk = min(kk, k_rows[b]);
+  const int n = load_slate(t, y_pred + (size_t)b * L, y_true + (size_t)b * L, L, pad, kk, gain_powered, redi);
   float* S = Sws + (size_t)b * L * L;
   float* A = Aws + (size_t)b * L * L;
   const float* cn = cnws + (size_t)b * max_iter * L;
@@ -529,7 +532,8 @@ __global__ void __launch_bounds__(1024) ltrx_neural_forward_reg_kernel(const flo
 template <int NR, int NC, int NCL>
 __global__ void __launch_bounds__(1024) ltrx_neural_backward_reg_kernel(
     const float* __restrict__ y_pred, const float* __restrict__ y_true, const float* __restrict__ idcg,
-    const float* __restrict__ nonzero_count, int L, float pad, float inv_tau, int gain_powered, int k, int max_iter,
+    const float* __restrict__ nonzero_count, int L, float pad, float inv_tau, int gain_powered, int k,
+    const int* __restrict__ k_rows, int max_iter,
     const int* __restrict__ titer, const float* __restrict__ Sws, const float* __restrict__ cnws,
     const float* __restrict__ rnws, float* __restrict__ per_ws, float* __restrict__ per_out, float* __restrict__ grad) {
   constexpr int NCR = NC - NCL;                         // adjoint column slots kept in registers
@@ -542,7 +546,9 @@ __global__ void __launch_bounds__(1024) ltrx_neural_backward_reg_kernel(
   __shared__ float a_lds[(NCL > 0 ? NR * NCL : 1) * 1024];
   const SlateLds t = carve_lds(tables, L);
   const int b = blockIdx.x;
-  const int n = load_slate(t, y_pred + (size_t)b * L, y_true + (size_t)b * L, L, pad, k, gain_powered, redi);
+  int kk = (k <= 0 || k > L) ? L : k;
+  if (k_rows) kk = min(kk, k_rows[b]);
+  const int n = load_slate(t, y_pred + (size_t)b * L, y_true + (size_t)b * L, L, pad, kk, gain_powered, redi);
   const float* S = Sws + (size_t)b * L * L;
   const float* cn = cnws + (size_t)b * max_iter * L;
   const float* rn = rnws + (size_t)b * max_iter * L;
@@ -761,8 +767,8 @@ extern "C" int ltrx_neuralndcg_prepare(const float* y_true, int B, int L, float 
 
 extern "C" int ltrx_neuralndcg_fwd_bwd(const float* y_pred, const float* y_true, const float* idcg,
                                        const float* nonzero_count, int B, int L, float pad_value, float temperature,
-                                       int powered_relevancies, int k, int transposed, int max_iter, float tol,
-                                       float* loss_out, float* per_slate_out, float* grad_out, int32_t* iters_out,
+                                       int powered_relevancies, int k, const int32_t* k_rows, int transposed,
+                                       int max_iter, float tol, float* loss_out, float* per_slate_out, float* grad_out, int32_t* iters_out,
                                        void* ws, ltrx_stream_t stream) {
   if (!y_pred || !y_true || !idcg || !nonzero_count || !loss_out || !ws || B <= 0 || L <= 0) return LTRX_EINVAL;
   if (!(temperature > 0.f) || max_iter < 0) return LTRX_EINVAL;
@@ -794,7 +800,7 @@ extern "C" int ltrx_neuralndcg_fwd_bwd(const float* y_pred, const float* y_true,
   LTRX_LAUNCH_CHECK();
 #define LTRX_NEURAL_BWD(NR, NC, NCL)                                                                                      \
   hipLaunchKernelGGL((ltrx_neural_backward_reg_kernel<NR, NC, NCL>), dim3(B), dim3(1024), 0, s, y_pred, y_true, idcg,      \
-                     nonzero_count, L, pad_value, 1.0f / temperature, powered_relevancies, k, max_iter, w.titer, w.S, w.cn, \
+                     nonzero_count, L, pad_value, 1.0f / temperature, powered_relevancies, k, k_rows, max_iter, w.titer, w.S, w.cn, \
                      w.rn, w.per, per_slate_out, grad_out)
   if (fast) {
     if (L <= 64) LTRX_NEURAL_BWD(4, 1, 0);
@@ -803,7 +809,7 @@ extern "C" int ltrx_neuralndcg_fwd_bwd(const float* y_pred, const float* y_true,
     else LTRX_NEURAL_BWD(15, 4, 2);
   } else {
     hipLaunchKernelGGL(ltrx_neural_backward_kernel, dim3(B), dim3(threads), lds, s, y_pred, y_true, idcg, nonzero_count, L,
-                       pad_value, 1.0f / temperature, powered_relevancies, k, max_iter, w.titer, w.S, w.A, w.cn, w.rn,
+                       pad_value, 1.0f / temperature, powered_relevancies, k, k_rows, max_iter, w.titer, w.S, w.A, w.cn, w.rn,
                        w.per, per_slate_out, grad_out);
   }
 #undef LTRX_NEURAL_BWD

@@ -12,8 +12,10 @@ allRank resolves its plugins by name at run time (SURVEY.md §5 "Config / flags"
 import importlib
 import sys
 
-_HOT_LOSSES = ("listNet", "listMLE", "approxNDCGLoss", "lambdaLoss", "neuralNDCG", "neuralNDCG_transposed")
-_HOT_METRICS = ("ndcg", "dcg")
+_HOT_LOSSES = ("listNet", "listMLE", "approxNDCGLoss", "lambdaLoss", "neuralNDCG", "neuralNDCG_transposed",
+               "rankNet", "rankNet_weightByGTDiff", "rankNet_weightByGTDiff_pow", "bce", "ordinal", "pointwise_rmse",
+               "binary_listNet")
+_HOT_METRICS = ("ndcg", "dcg", "mrr")
 _saved = {}
 
 

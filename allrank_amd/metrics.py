@@ -1,5 +1,5 @@
 """MI355X-native ranking metrics with the signatures of ``allrank.models.metrics`` (metrics.py:7-77; looked up by
-name at allrank/training/train_utils.py:50).  ``ndcg``/``dcg`` run as one HIP kernel per call (libltrx.so)."""
+name at allrank/training/train_utils.py:50).  ``ndcg``/``dcg``/``mrr`` run as one HIP kernel per call (libltrx.so)."""
 import ctypes
 
 import torch
@@ -44,3 +44,25 @@ def dcg(y_pred, y_true, ats=None, gain_function=None, padding_indicator=PADDED_Y
     if gain_function is not None:
         raise NotImplementedError("custom gain_function: only the default 2**x - 1 is implemented on the device")
     return _run(y_pred, y_true, ats, padding_indicator, 1.0, False)[1]
+
+
+def mrr(y_pred, y_true, ats=None, padding_indicator=PADDED_Y_VALUE):
+    """MRR@ats (metrics.py:80-113): [batch, len(ats)] -- 1 / (1 + rank of the first item carrying the slate's maximum
+    label) when that rank is below the cut-off, else 0; the reference's batch-level zeroing (all maxima 0) is kept."""
+    if y_pred.dim() != 2 or y_pred.shape != y_true.shape:
+        raise ValueError("y_pred and y_true must both be [batch_size, slate_length]")
+    L.require_device(y_pred, y_true)
+    yp = L.f32c(y_pred.detach())
+    yt = L.f32c(y_true.detach())
+    B, SL = yp.shape
+    if ats is None:
+        ats = [SL]
+    ats = [int(a) for a in ats]
+    n = len(ats)
+    out = torch.empty((B, n), dtype=torch.float32, device=yp.device)
+    lib = L.lib()
+    ws = L.workspace(lib.ltrx_mrr_workspace_bytes(B, SL, n), yp)
+    arr = (ctypes.c_int * n)(*ats)
+    L.check(lib.ltrx_mrr_at(L.ptr(yp), L.ptr(yt), B, SL, arr, n, float(padding_indicator), L.ptr(out), L.ptr(ws),
+                            L.stream_of(yp)), "mrr_at")
+    return out

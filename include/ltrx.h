@@ -100,7 +100,10 @@ int ltrx_lambdaloss_fwd_bwd(const float* y_pred, const float* y_true, int B, int
  *   step 2  ltrx_neuralndcg_fwd_bwd: loss and gradient; `nonzero_count` is read from DEVICE memory.
  * transposed != 0 selects the neuralNDCG_transposed conventions (same value; idcg stays "powered" when
  * powered_relevancies == 0, neuralNDCG.py:126).  k <= 0 means k=None.  The Sinkhorn early exit
- * (loss_utils.py:25) is batch-global as in the reference; iters_out[1] (int32, optional) = iterations used. */
+ * (loss_utils.py:25) is batch-global as in the reference; iters_out[1] (int32, optional) = iterations used.
+ * k_rows[B] (int32, device, optional): a per-slate cap on the ranks that carry a discount (min(k, k_rows[b])) -- the
+ * stochastic variant (loss_utils.py:84-112) masks the permutation rows by the TRUE slate's padding (neuralNDCG.py:44)
+ * while sorting each perturbed copy under another slate's mask (mask.repeat_interleave, :36/:41). */
 size_t ltrx_neuralndcg_workspace_bytes(int B, int L, int max_iter);
 /* test hook: 1 = always use the general L2-streaming kernels (default 0: register-resident fast path when L <= 240) */
 void ltrx_neuralndcg_force_general(int on);
@@ -108,7 +111,7 @@ int ltrx_neuralndcg_prepare(const float* y_true, int B, int L, float pad_value, 
                             float* idcg_out, float* nonzero_count_out, void* ws, ltrx_stream_t stream);
 int ltrx_neuralndcg_fwd_bwd(const float* y_pred, const float* y_true, const float* idcg, const float* nonzero_count,
                             int B, int L, float pad_value, float temperature, int powered_relevancies, int k,
-                            int transposed, int max_iter, float tol, float* loss_out, float* per_slate_out,
+                            const int32_t* k_rows, int transposed, int max_iter, float tol, float* loss_out, float* per_slate_out,
                             float* grad_out, int32_t* iters_out, void* ws, ltrx_stream_t stream);
 
 /* allrank/models/metrics.py:7-77   ndcg(y_pred, y_true, ats, gain=2^x-1, padding_indicator, filler_value)
@@ -118,6 +121,43 @@ size_t ltrx_ndcg_workspace_bytes(int B, int L);
 int ltrx_ndcg_at(const float* y_pred, const float* y_true, int B, int L, const int* ats, int n_ats,
                  float pad_value, float filler_value, float* ndcg_out, float* dcg_out, int64_t* order_out,
                  void* ws, ltrx_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pointwise / pairwise members of allrank.models.losses and MRR.
+ * Count-normalised losses follow the lambdaLoss protocol: *_count_out[1] (optional) receives this call's
+ * count, ext_*count (device, optional) replaces it as the divisor (global count under slate sharding).
+ * ------------------------------------------------------------------------------------------- */
+
+/* allrank/models/losses/rankNet.py:8-79  rankNet / rankNet_weightByGTDiff / rankNet_weightByGTDiff_pow:
+ * BCEWithLogits(target 1) over the pairs y_i > y_j of valid items, mean over ALL pairs of the batch.
+ * weight_mode 0: unweighted, 1: |y_i - y_j|, 2: |y_i^2 - y_j^2|.  No pair at all -> loss NaN, gradient 0 (torch). */
+size_t ltrx_ranknet_workspace_bytes(int B, int L);
+int ltrx_ranknet_fwd_bwd(const float* y_pred, const float* y_true, int B, int L, float pad_value, int weight_mode,
+                         const float* ext_pair_count, float* loss_out, float* pair_count_out, float* grad_out, void* ws,
+                         ltrx_stream_t stream);
+
+/* allrank/models/losses/bce.py:8-32 (n == 0: y_pred[B,L] probabilities, divisor = slates with a valid item) and
+ * ordinal.py:8-50 (n >= 1: y_pred[B,L,n], targets [y_true >= k+1], divisor = valid items); torch.nn.BCELoss arithmetic.
+ * grad_out has the shape of y_pred. */
+size_t ltrx_bce_workspace_bytes(int B, int L, int n);
+int ltrx_bce_fwd_bwd(const float* y_pred, const float* y_true, int B, int L, int n, float pad_value, const float* ext_count,
+                     float* loss_out, float* count_out, float* grad_out, void* ws, ltrx_stream_t stream);
+
+/* allrank/models/losses/pointwise.py:6-32  pointwise_rmse(y_pred, y_true, no_of_levels) */
+size_t ltrx_pointwise_rmse_workspace_bytes(int B, int L);
+int ltrx_pointwise_rmse_fwd_bwd(const float* y_pred, const float* y_true, int B, int L, float no_of_levels, float pad_value,
+                                float batch_divisor, float* loss_out, float* grad_out, void* ws, ltrx_stream_t stream);
+
+/* allrank/models/losses/binary_listNet.py:8-33 */
+size_t ltrx_binary_listnet_workspace_bytes(int B, int L);
+int ltrx_binary_listnet_fwd_bwd(const float* y_pred, const float* y_true, int B, int L, float eps, float pad_value,
+                                float batch_divisor, float* loss_out, float* grad_out, void* ws, ltrx_stream_t stream);
+
+/* allrank/models/metrics.py:80-113  mrr(y_pred, y_true, ats, padding_indicator): mrr_out[B,n_ats]; ats is a HOST array.
+ * Ties in the predictions are ranked by the stable descending order (padded slots last). */
+size_t ltrx_mrr_workspace_bytes(int B, int L, int n_ats);
+int ltrx_mrr_at(const float* y_pred, const float* y_true, int B, int L, const int* ats, int n_ats, float pad_value,
+                float* mrr_out, void* ws, ltrx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Scoring model kernels (allrank/models/transformer.py).

@@ -364,49 +364,43 @@ def _sinkhorn_backward(P0, norms, gbar, dtype):
     return g.astype(dtype)
 
 
-def neuralndcg(y_pred, y_true, pad=PADDED_Y_VALUE, temperature=1.0, powered_relevancies=True, k=None,
-               transposed=False, max_iter=50, tol=1e-6, dtype=np.float32):
-    """Deterministic NeuralNDCG / NeuralNDCG-transposed.  returns (loss, dloss/dy_pred, n_iter_run).
-
-    neuralNDCG.py:10-70 (plain) and :73-136 (transposed).  The two variants compute the same number
-    (sum_i disc_i sum_j P_ij g_j); they differ in (a) the transposed variant exposes max_iter/tol, and
-    (b) with powered_relevancies=False the transposed variant STILL normalises by the powered idcg
-    (neuralNDCG.py:126, reference quirk, kept).
-    """
-    s = _f(y_pred, dtype)
-    t = _f(y_true, dtype)
-    B, L = s.shape
-    if k is None:
-        k = L                                                              # :29-30
-    mask = t == pad                                                        # :32
-    P_hat = deterministic_neural_sort(s, temperature, mask, dtype)         # :38
-    P_s, norms = sinkhorn_scaling(P_hat, mask, tol=tol, max_iter=max_iter, dtype=dtype, return_norms=True)   # :41-42
-    either = mask[:, :, None] | mask[:, None, :]
-    P_s = np.where(either, 0, P_s).astype(dtype)                           # :46
-    tm = np.where(mask, 0, t)                                              # :47
-    g = (np.power(dtype(2), tm) - 1) if powered_relevancies else tm       # :48-49
-    if transposed and not powered_relevancies:
-        g = t.copy()                                                       # :124 (padded gain -1 meets a zero discount)
+def _neural_core(s, t, sort_mask, true_mask, temperature, powered_relevancies, k, transposed, max_iter, tol, idcg, cnt,
+                 dtype):
+    """shared body of neuralndcg / neuralndcg_stochastic over a batch of (possibly perturbed) slates.
+    ``sort_mask`` pads NeuralSort + Sinkhorn (neuralNDCG.py:36-42), ``true_mask`` pads the read-out (:46-47); they differ
+    only in the stochastic variant (mask.repeat_interleave vs the sample-major view, loss_utils.py:107-108).
+    returns (ndcg values [N], d loss / d s [N, L], iterations run), loss = -sum(values)/cnt."""
+    N, L = s.shape
+    P_hat = deterministic_neural_sort(s, temperature, sort_mask, dtype)    # :38
+    P_s, norms = sinkhorn_scaling(P_hat, sort_mask, tol=tol, max_iter=max_iter, dtype=dtype, return_norms=True)   # :41-42
+    either_s = sort_mask[:, :, None] | sort_mask[:, None, :]
+    if transposed:
+        # :102-124: no read-out mask at all -- the gains are the RAW labels (padding -1 -> 2^-1 - 1 or -1), which meet the zero
+        # columns Sinkhorn's own mask leaves (identical to the plain variant unless sort_mask != true_mask)
+        either_t = np.zeros_like(either_s)
+        g = (np.power(dtype(2), t) - 1) if powered_relevancies else t.copy()
+    else:
+        either_t = true_mask[:, :, None] | true_mask[:, None, :]
+        P_s = np.where(either_t, 0, P_s).astype(dtype)                     # :46
+        tm = np.where(true_mask, 0, t)                                     # :47
+        g = (np.power(dtype(2), tm) - 1) if powered_relevancies else tm   # :48-49
     disc = (dtype(1) / np.log2(np.arange(L, dtype=dtype) + dtype(2.0))).astype(dtype)   # :52 / :108
     disc_k = disc.copy()
     disc_k[k:] = 0                                                         # :55 / :111
     gt = np.einsum("bij,bj->bi", P_s, g).astype(dtype)                     # :51
     dgain = np.sum(gt * disc_k[None, :], axis=1, dtype=dtype)              # :53,:60-61
-    idcg_powered = powered_relevancies or transposed                       # :55-58 vs :118-126
-    idcg, _ = dcg(t, t, [k], idcg_powered, pad, dtype)
-    idcg = idcg[:, 0]
     nd = dgain / (idcg + dtype(DEFAULT_EPS))                               # :61
     zero = idcg == 0                                                       # :62
     nd = np.where(zero, 0, nd)                                             # :63
     n_iter = len(norms)
-    if zero.all():
-        return dtype(0.0), np.zeros_like(s), n_iter                        # :66-67
-    cnt = dtype((~zero).sum())
-    loss = -np.sum(nd, dtype=dtype) / cnt                                  # :69-70
+    if cnt == 0:
+        return nd, np.zeros_like(s), n_iter
     # ---- backward ----
     coef = np.where(zero, 0, -1.0 / (cnt * (idcg + dtype(DEFAULT_EPS)))).astype(dtype)    # dloss/d dgain_b
     gbar = coef[:, None, None] * disc_k[None, :, None] * g[:, None, :]     # adjoint of P_s[b,i,j]
-    gbar = np.where(either, 0, gbar).astype(dtype)                         # final masks (:46 and loss_utils.py:28-29)
+    gbar = np.where(either_t | either_s, 0, gbar).astype(dtype)            # final masks (:46 and loss_utils.py:28-29)
+    either = either_s
+    mask = sort_mask
     P0 = np.where(either, 0, P_hat)
     P0 = np.where(mask[:, :, None] & mask[:, None, :], 1, P0).astype(dtype)
     g0 = _sinkhorn_backward(P0, norms, gbar, dtype)
@@ -426,4 +420,184 @@ def neuralndcg(y_pred, y_true, pad=PADDED_Y_VALUE, temperature=1.0, powered_rele
     sgn = np.where(either, 0, sgn)
     grad = grad - Q * sgn.sum(axis=2) + np.einsum("bj,bjm->bm", Q, sgn)
     grad = np.where(mask, 0, grad)
+    return nd, grad.astype(dtype), n_iter
+
+
+def neuralndcg(y_pred, y_true, pad=PADDED_Y_VALUE, temperature=1.0, powered_relevancies=True, k=None,
+               transposed=False, max_iter=50, tol=1e-6, dtype=np.float32):
+    """Deterministic NeuralNDCG / NeuralNDCG-transposed.  returns (loss, dloss/dy_pred, n_iter_run).
+
+    neuralNDCG.py:10-70 (plain) and :73-136 (transposed).  The two variants compute the same number
+    (sum_i disc_i sum_j P_ij g_j); they differ in (a) the transposed variant exposes max_iter/tol, and
+    (b) with powered_relevancies=False the transposed variant STILL normalises by the powered idcg
+    (neuralNDCG.py:126, reference quirk, kept).
+    """
+    s = _f(y_pred, dtype)
+    t = _f(y_true, dtype)
+    B, L = s.shape
+    if k is None:
+        k = L                                                              # :29-30
+    mask = t == pad                                                        # :32
+    idcg_powered = powered_relevancies or transposed                       # :55-58 vs :118-126
+    idcg, _ = dcg(t, t, [k], idcg_powered, pad, dtype)
+    idcg = idcg[:, 0]
+    zero = idcg == 0
+    cnt = dtype((~zero).sum())
+    nd, grad, n_iter = _neural_core(s, t, mask, mask, temperature, powered_relevancies, k, transposed, max_iter, tol, idcg, cnt,
+                                    dtype)
+    if zero.all():
+        return dtype(0.0), np.zeros_like(s), n_iter                        # :66-67
+    loss = -np.sum(nd, dtype=dtype) / cnt                                  # :69-70
     return dtype(loss), grad.astype(dtype), n_iter
+
+
+def neuralndcg_stochastic(y_pred, y_true, gumbel, pad=PADDED_Y_VALUE, temperature=1.0, powered_relevancies=True, k=None,
+                          transposed=False, beta=0.1, log_scores=True, max_iter=50, tol=1e-6, dtype=np.float32):
+    """Stochastic NeuralNDCG (neuralNDCG.py:35-37 + loss_utils.py:84-112) for a GIVEN Gumbel draw ``gumbel``
+    [n_samples, B, L] (the reference: sample_gumbel -> torch.rand, loss_utils.py:80).  returns (loss, dloss/dy_pred).
+    Reference quirk kept: the perturbed copy i = sample*B + b is sorted under the padding mask of slate i // n_samples
+    (mask.repeat_interleave, loss_utils.py:108, neuralNDCG.py:41) and read out under the mask of slate b (:44-47)."""
+    s = _f(y_pred, dtype)
+    t = _f(y_true, dtype)
+    G = _f(gumbel, dtype)
+    S, B, L = G.shape
+    if k is None:
+        k = L
+    mask = t == pad
+    smin = s.min()
+    s_pos = s + np.abs(smin)                                               # loss_utils.py:102
+    w = np.ones_like(s)
+    if log_scores:
+        w = (dtype(1) / (s_pos + dtype(1e-10))).astype(dtype)
+        s_pos = np.log(s_pos + dtype(1e-10))                               # :104-105
+    sp = (s_pos[None] + dtype(beta) * G).reshape(S * B, L).astype(dtype)   # :103,:107
+    idx = np.arange(S * B)
+    sort_mask = mask[idx // S]                                             # :108
+    true_mask = np.tile(mask, (S, 1))                                      # neuralNDCG.py:46 (mask[None] broadcast)
+    tt = np.tile(t, (S, 1))
+    idcg_powered = powered_relevancies or transposed
+    idcg, _ = dcg(t, t, [k], idcg_powered, pad, dtype)
+    idcg = idcg[:, 0]
+    zero = idcg == 0
+    if zero.all():
+        return dtype(0.0), np.zeros_like(s)
+    cnt = dtype((~zero).sum() * S)                                         # :69
+    nd, gp, _ = _neural_core(sp, tt, sort_mask, true_mask, temperature, powered_relevancies, k, transposed, max_iter, tol,
+                             np.tile(idcg, S), cnt, dtype)
+    loss = -np.sum(nd, dtype=dtype) / cnt
+    gs = gp.reshape(S, B, L).sum(axis=0) * w                               # d loss / d s_pos . d s_pos / d s (elementwise part)
+    grad = gs.copy()
+    ties = s == smin                                                       # through |min(s)| (:102); torch's min() backward
+    grad[ties] += np.sign(smin) * gs.sum(dtype=dtype) / ties.sum()         # spreads the gradient evenly over tied minima
+    return dtype(loss), grad.astype(dtype)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# pointwise / pairwise losses and MRR (SURVEY.md section 8f row 4)
+# ------------------------------------------------------------------------------------------------------------------
+def ranknet(y_pred, y_true, pad=PADDED_Y_VALUE, weight_by_diff=False, weight_by_diff_powed=False, dtype=np.float32):
+    """rankNet.py:31-79.  returns (loss, grad): BCEWithLogits(target 1, weight) over pairs y_i > y_j, mean over all pairs."""
+    s = _f(y_pred, dtype)
+    t = _f(y_true, dtype)
+    valid = t != pad
+    pair = valid[:, :, None] & valid[:, None, :] & (t[:, :, None] > t[:, None, :])        # :57-61
+    d = (s[:, :, None] - s[:, None, :]).astype(dtype)
+    if weight_by_diff:
+        w = np.abs(t[:, :, None] - t[:, None, :])                                          # :64-66
+    elif weight_by_diff_powed:
+        w = np.abs(t[:, :, None] ** 2 - t[:, None, :] ** 2)                                # :67-70
+    else:
+        w = np.ones_like(d)
+    n = pair.sum()
+    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+        l = np.where(pair, w * (np.maximum(-d, 0) + np.log1p(np.exp(-np.abs(d)))), 0).astype(dtype)
+        loss = dtype(l.sum(dtype=np.float64) / n) if n else dtype(np.nan)                  # :79 (mean of an empty selection)
+        gpair = np.where(pair, -w / (1 + np.exp(d)), 0)                                    # d l_ij / d d_ij
+    grad = (gpair.sum(axis=2) - gpair.sum(axis=1)) / max(int(n), 1)
+    return loss, grad.astype(dtype)
+
+
+def _bce_terms(p, tgt, dtype):
+    with np.errstate(divide="ignore"):
+        l = -(tgt * np.maximum(np.log(p), -100) + (1 - tgt) * np.maximum(np.log(1 - p), -100))     # torch BCELoss
+    g = (p - tgt) / np.maximum((1 - p) * p, 1e-12)
+    return l.astype(dtype), g.astype(dtype)
+
+
+def bce(y_pred, y_true, pad=PADDED_Y_VALUE, dtype=np.float32):
+    """bce.py:8-32: y_pred are probabilities.  returns (loss, grad)."""
+    p = _f(y_pred, dtype)
+    t = _f(y_true, dtype)
+    valid = t != pad
+    l, g = _bce_terms(p, t, dtype)
+    l = np.where(valid, l, 0)                                                              # :24-25
+    cnt = (valid.sum(axis=1) > 0).sum()                                                    # :28
+    loss = dtype(l.sum(dtype=np.float64) / cnt)
+    return loss, (np.where(valid, g, 0) / cnt).astype(dtype)
+
+
+def ordinal(y_pred, y_true, n, pad=PADDED_Y_VALUE, dtype=np.float32):
+    """ordinal.py:25-50: y_pred [B, L, n] probabilities.  returns (loss, grad [B, L, n])."""
+    p = _f(y_pred, dtype)
+    t = _f(y_true, dtype)
+    valid = t != pad
+    tgt = (t[:, :, None] >= np.arange(1, n + 1, dtype=dtype)[None, None, :]).astype(dtype)  # :17-20
+    l, g = _bce_terms(p, tgt, dtype)
+    l = np.where(valid[:, :, None], l, 0)
+    cnt = valid.sum()                                                                      # :46 (documents with a valid ordinal)
+    loss = dtype(l.sum(dtype=np.float64) / cnt)
+    return loss, (np.where(valid[:, :, None], g, 0) / cnt).astype(dtype)
+
+
+def pointwise_rmse(y_pred, y_true, no_of_levels, pad=PADDED_Y_VALUE, dtype=np.float32):
+    """pointwise.py:6-32.  returns (loss, grad)."""
+    p = _f(y_pred, dtype)
+    t = _f(y_true, dtype)
+    valid = t != pad
+    e = np.where(valid, t - dtype(no_of_levels) * p, 0).astype(dtype)                      # :23-26
+    nv = valid.sum(axis=1).astype(dtype)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rm = np.sqrt((e * e).sum(axis=1, dtype=dtype) / nv)                                # :28-30
+        loss = dtype(rm.mean(dtype=np.float64))
+        grad = -dtype(no_of_levels) * e / (nv * rm)[:, None] / dtype(len(t))
+    return loss, np.where(valid, grad, 0).astype(dtype)
+
+
+def binary_listnet(y_pred, y_true, eps=DEFAULT_EPS, pad=PADDED_Y_VALUE, dtype=np.float32):
+    """binary_listNet.py:8-33.  returns (loss, grad)."""
+    s = _f(y_pred, dtype)
+    t = _f(y_true, dtype)
+    mask = t == pad
+    s = np.where(mask, -np.inf, s)
+    t = np.where(mask, 0, t)
+    norm = t.sum(axis=1, keepdims=True)
+    norm = np.where(norm == 0, 1, norm)                                                    # :24
+    T = (t / norm).astype(dtype)
+    P = _softmax_rows(s).astype(dtype)
+    loss = dtype(np.mean(-np.sum(T * np.log(P + dtype(eps)), axis=1, dtype=dtype), dtype=np.float64))
+    r = P / (P + dtype(eps))
+    grad = (P * np.sum(T * r, axis=1, keepdims=True) - T * r) / dtype(len(s))
+    return loss, np.where(mask, 0, grad).astype(dtype)
+
+
+def mrr(y_pred, y_true, ats=None, pad=PADDED_Y_VALUE, dtype=np.float32):
+    """metrics.py:80-113.  returns [B, len(ats)]."""
+    s = _f(y_pred, dtype)
+    t = _f(y_true, dtype)
+    B, L = s.shape
+    if ats is None:
+        ats = [L]
+    mask = t == pad
+    s = np.where(mask, -np.inf, s)
+    t = np.where(mask, 0, t)
+    order = np.stack([stable_argsort_desc(r) for r in s])
+    ts = np.take_along_axis(t, order, axis=1)
+    vals = ts.max(axis=1)
+    idx = ts.argmax(axis=1).astype(dtype)                                                  # first maximum (:100)
+    res = (dtype(1) / (idx + dtype(1)))[:, None].repeat(len(ats), axis=1)
+    if vals.sum() == 0:                                                                    # :108-109 (0-dim mask)
+        res[:] = 0
+    within = (idx[:, None] < np.asarray(ats, dtype=dtype)[None, :]).astype(dtype)
+    return (res * within).astype(dtype)
+
+

@@ -46,3 +46,37 @@ def iter_loss_cases(gold):
                         k = pre + "neural.t%d.tau%g.k%s.p%d" % (int(tr), tau, kk, int(pw))
                         yield (k, "neuralndcg", dict(transposed=tr, temperature=tau, k=kk, powered_relevancies=pw),
                                s, y, gold[k + ".loss"], gold[k + ".grad"])
+
+
+# ---- SURVEY.md section 8f row 4 fixtures (tests/golden/extra_golden.npz, made by make_golden_extra.py) ----
+STOCH = [dict(tr=False, tau=1.0, k=None, pw=True, log=True, beta=0.1), dict(tr=False, tau=0.5, k=5, pw=False, log=False, beta=0.3),
+         dict(tr=True, tau=1.0, k=None, pw=True, log=True, beta=0.1), dict(tr=True, tau=2.0, k=7, pw=False, log=True, beta=1.0)]
+N_ORD = 4
+
+
+def iter_extra_cases(gold):
+    """yields (name, kind, kwargs, y_pred, y_true, ref_loss, ref_grad) for the pointwise / pairwise losses"""
+    for ci in range(int(gold["n_cases"])):
+        pre = "c%d." % ci
+        s, y = gold[pre + "s"], gold[pre + "y"]
+        for m, kw in enumerate((dict(), dict(weight_by_diff=True), dict(weight_by_diff_powed=True))):
+            yield (pre + "ranknet.m%d" % m, "ranknet", kw, s, y, gold[pre + "ranknet.m%d.loss" % m], gold[pre + "ranknet.m%d.grad" % m])
+        yield (pre + "bce.nopad", "bce", {}, gold[pre + "pe"], gold[pre + "ybnp"], gold[pre + "bce.nopad.loss"], gold[pre + "bce.nopad.grad"])
+        yield (pre + "bce.pad", "bce", {}, gold[pre + "p"], gold[pre + "yb"], gold[pre + "bce.pad.loss"], gold[pre + "bce.pad.grad"])
+        yield (pre + "ordinal.nopad", "ordinal", dict(n=N_ORD), gold[pre + "p3e"], gold[pre + "ynp"],
+               gold[pre + "ordinal.nopad.loss"], gold[pre + "ordinal.nopad.grad"])
+        yield (pre + "ordinal.pad", "ordinal", dict(n=N_ORD), gold[pre + "p3"], y, gold[pre + "ordinal.pad.loss"], gold[pre + "ordinal.pad.grad"])
+        yield (pre + "rmse", "pointwise_rmse", dict(no_of_levels=4), gold[pre + "p"], y, gold[pre + "rmse.loss"], gold[pre + "rmse.grad"])
+        yield (pre + "blistnet", "binary_listnet", {}, s, gold[pre + "yb"], gold[pre + "blistnet.loss"], gold[pre + "blistnet.grad"])
+
+
+def iter_stochastic_cases(gold):
+    """yields (name, cfg, s, y, gumbel[S,B,L], ref_loss, ref_grad, strict_mask): ``strict_mask`` excludes the batch-minimum
+    score(s) when log_scores is on -- there d log(s - min + 1e-10)/ds = 1e10 amplifies fp32 round-off in the reference too."""
+    for ci in range(int(gold["n_cases"])):
+        pre = "c%d." % ci
+        s, y = gold[pre + "s"], gold[pre + "y"]
+        for si, c in enumerate(STOCH):
+            strict = (s != s.min()) if c["log"] else (s == s)
+            yield (pre + "stoch%d" % si, c, s, y, gold[pre + "gumbel"][..., 0], gold[pre + "stoch%d.loss" % si],
+                   gold[pre + "stoch%d.grad" % si], strict)

@@ -22,3 +22,9 @@ def losses_golden():
 def model_golden():
     import numpy as np
     return dict(np.load(os.path.join(ROOT, "tests", "golden", "model_golden.npz"), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def extra_golden():
+    import numpy as np
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "extra_golden.npz"), allow_pickle=False))

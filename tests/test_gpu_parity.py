@@ -745,3 +745,136 @@ def test_fused_trainer_trains_reference_dropout_config():
     ft = FusedTrainer(model, "approxNDCGLoss", {}, 16, 60, lr=1e-3, use_graph=True)
     losses = [float(ft.step(x, y).item()) for _ in range(30)]
     assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(losses[:5]) - 0.02, losses
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# pointwise / pairwise losses, MRR, stochastic NeuralSort
+# ------------------------------------------------------------------------------------------------------------------
+def _extra_engine(kind, kw, yp, yt):
+    from allrank_amd import losses as E
+    fn = dict(ranknet=E.rankNet, bce=E.bce, ordinal=E.ordinal, pointwise_rmse=E.pointwise_rmse, binary_listnet=E.binary_listNet)[kind]
+    p = _t(yp, True)
+    l = fn(p, _t(yt), **kw)
+    l.backward()
+    return float(l.item()), p.grad.cpu().numpy()
+
+
+_EXTRA_ORACLE = dict(ranknet=O.ranknet, bce=O.bce, ordinal=O.ordinal, pointwise_rmse=O.pointwise_rmse, binary_listnet=O.binary_listnet)
+
+
+def test_extra_losses_match_reference_golden(extra_golden):
+    from tests.cases import iter_extra_cases
+    rows, bad = [], []
+    for name, kind, kw, yp, yt, rl, rg in iter_extra_cases(extra_golden):
+        l, g = _extra_engine(kind, kw, yp, yt)
+        ok = close(l, rl) and grad_close(g, rg)
+        rows.append(dict(case=name, loss=l, ref=float(rl), grad_err=float(np.abs(g - rg).max()), ok=ok))
+        if not ok:
+            bad.append(rows[-1])
+    _log("extra_losses_golden", rows)
+    assert len(rows) == 36 and not bad, bad
+
+
+@pytest.mark.parametrize("B,L", [(9, 37), (64, 240), (3, 700)])
+def test_extra_losses_match_oracle_on_random_inputs(B, L):
+    rng = np.random.default_rng(B * 1000 + L)
+    s = rng.standard_normal((B, L)).astype(np.float32) * 2
+    y = rng.integers(0, 5, (B, L)).astype(np.float32)
+    for b in range(B):
+        y[b, L - (b * 7) % L:] = -1 if b % 3 else y[b, L - (b * 7) % L:]
+    y[0] = 0                                                      # a slate without any pair / relevant item
+    p = (1 / (1 + np.exp(-s))).astype(np.float32)
+    p3 = (1 / (1 + np.exp(-rng.standard_normal((B, L, 3))))).astype(np.float32)
+    yb = np.where(y == -1, -1, (y >= 3)).astype(np.float32)
+    cases = [("ranknet", dict(), s, y), ("ranknet", dict(weight_by_diff=True), s, y), ("ranknet", dict(weight_by_diff_powed=True), s, y),
+             ("bce", {}, p, yb), ("ordinal", dict(n=3), p3, y), ("pointwise_rmse", dict(no_of_levels=4), p, y),
+             ("binary_listnet", {}, s, yb)]
+    for kind, kw, yp, yt in cases:
+        l, g = _extra_engine(kind, kw, yp, yt)
+        lo, go = _EXTRA_ORACLE[kind](yp, yt, **kw)
+        assert close(l, lo), (kind, kw, l, lo)
+        assert grad_close(g, go), (kind, kw, float(np.abs(g - go).max()))
+        assert not np.any(g[yt == -1] != 0), kind           # exactly 0 at padded slots
+
+
+def test_ranknet_without_pairs_is_nan_with_zero_gradient():
+    from allrank_amd import losses as E
+    p = _t(np.asarray([[0.3, 0.1, 0.2]], np.float32), True)
+    l = E.rankNet(p, _t(np.asarray([[1.0, 1.0, -1.0]], np.float32)))
+    l.backward()
+    assert np.isnan(l.item()) and not np.any(p.grad.cpu().numpy() != 0)
+
+
+def test_mrr_matches_reference_golden_and_oracle(extra_golden):
+    from allrank_amd import metrics as EM
+    g = extra_golden
+    for ci in range(int(g["n_cases"])):
+        pre = "c%d." % ci
+        s, y = g[pre + "s"], g[pre + "y"]
+        ats = [int(a) for a in g[pre + "mrr.ats"]]
+        assert np.array_equal(EM.mrr(_t(s), _t(y), ats=ats).cpu().numpy(), g[pre + "mrr.val"])
+        assert np.array_equal(EM.mrr(_t(s), _t(y)).cpu().numpy(), g[pre + "mrr.none"])
+        yz = np.where(y == -1, -1, 0).astype(np.float32)
+        assert np.array_equal(EM.mrr(_t(s), _t(yz), ats=ats).cpu().numpy(), g[pre + "mrr.zero"])
+    rng = np.random.default_rng(5)
+    s = np.round(rng.standard_normal((200, 240)), 1).astype(np.float32)            # tie-heavy predictions
+    y = rng.integers(0, 5, (200, 240)).astype(np.float32)
+    y[::3, 100:] = -1
+    assert np.array_equal(EM.mrr(_t(s), _t(y), ats=[1, 5, 10, 240]).cpu().numpy(), O.mrr(s, y, [1, 5, 10, 240]))
+
+
+def test_stochastic_neuralndcg_matches_reference_golden(extra_golden):
+    """n_samples Gumbel-perturbed copies per slate through the fused NeuralSort/Sinkhorn kernels, same draw as the reference
+    run that made the fixture (including its sort-mask / read-out-mask mismatch on ragged batches)."""
+    from allrank_amd import losses as E
+    from tests.cases import iter_stochastic_cases
+    rows, bad = [], []
+    for name, c, s, y, gum, rl, rg, strict in iter_stochastic_cases(extra_golden):
+        fn = E.neuralNDCG_transposed if c["tr"] else E.neuralNDCG
+        p = _t(s, True)
+        l = fn(p, _t(y), temperature=c["tau"], k=c["k"], powered_relevancies=c["pw"], stochastic=True, n_samples=gum.shape[0],
+               beta=c["beta"], log_scores=c["log"], gumbel=_t(gum[..., None]))
+        l.backward()
+        g = p.grad.cpu().numpy()
+        ok = close(l.item(), rl) and grad_close(np.where(strict, g, 0), np.where(strict, rg, 0)) and bool(np.isfinite(g).all())
+        rows.append(dict(case=name, loss=float(l.item()), ref=float(rl), ok=ok,
+                         grad_err=float(np.abs(np.where(strict, g - rg, 0)).max()), grad_scale=float(np.abs(rg).max())))
+        if not ok:
+            bad.append(rows[-1])
+    _log("stochastic_neuralndcg_golden", rows)
+    assert len(rows) == 16 and not bad, bad
+
+
+def test_stochastic_neuralndcg_draws_its_own_noise():
+    from allrank_amd import losses as E
+    rng = np.random.default_rng(0)
+    s, y = _t(rng.standard_normal((8, 60)).astype(np.float32), True), _t(rng.integers(0, 5, (8, 60)).astype(np.float32))
+    torch.manual_seed(1)
+    a = E.neuralNDCG(s, y, stochastic=True, n_samples=4)
+    b = E.neuralNDCG(s, y, stochastic=True, n_samples=4)
+    det = E.neuralNDCG(s, y)
+    a.backward()
+    assert a.item() != b.item() and abs(a.item() - det.item()) < 0.2 and np.isfinite(s.grad.cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("loss_name,loss_args", [("rankNet_weightByGTDiff", {}), ("binary_listNet", {}), ("pointwise_rmse", dict(no_of_levels=4))])
+def test_fused_trainer_runs_the_row4_losses(loss_name, loss_args):
+    """the explicit step with a pointwise / pairwise loss == the autograd path with the same loss function."""
+    import copy
+    from allrank_amd import losses as E
+    from allrank_amd.engine import FusedTrainer, Trainer
+    torch.manual_seed(3)
+    m1 = _dropout_model(0.0, None, 0.0, N=1)
+    m2 = copy.deepcopy(m1)
+    rng = np.random.default_rng(8)
+    B, L = 6, 30
+    x = _t(rng.standard_normal((B, L, 20)).astype(np.float32))
+    y = rng.integers(0, 2, (B, L)).astype(np.float32)
+    y[1, 20:] = -1
+    y = _t(y)
+    ft = FusedTrainer(m1, loss_name, loss_args, B, L, lr=1e-3, use_graph=False, gemm="split_bf16_strict")
+    from functools import partial
+    tr = Trainer(m2, partial(getattr(E, loss_name), **loss_args), torch.optim.Adam(m2.parameters(), lr=1e-3))
+    for step in range(3):
+        lf, la = float(ft.step(x, y).item()), float(tr.step(x, y, None).item())
+        assert abs(lf - la) <= (2e-5 if step == 0 else 1e-3) * (1 + abs(la)), (loss_name, step, lf, la)

@@ -20,9 +20,10 @@ def test_install_rebinds_hot_path_names_and_uninstall_restores():
         assert RL.approxNDCGLoss is E.approxNDCGLoss and RL.listNet is E.listNet and RL.lambdaLoss is E.lambdaLoss
         assert RL.neuralNDCG is E.neuralNDCG and RL.listMLE is E.listMLE
         assert RM.ndcg is EM.ndcg and RMod.make_model is EMod.make_model
-        assert RL.rankNet is orig[3]                     # not on the hot path: untouched
+        assert RL.rankNet is E.rankNet and RL.ordinal is E.ordinal and RL.bce is E.bce and RM.mrr is EM.mrr     # §8f row 4
+        assert RL.with_ordinals is not None
         assert getattr(RL, "approxNDCGLoss") is E.approxNDCGLoss      # what main.py:83 does
         assert len(done) >= 9
     finally:
         allrank_amd.uninstall()
-    assert (RL.approxNDCGLoss, RM.ndcg, RMod.make_model) == orig[:3]
+    assert (RL.approxNDCGLoss, RM.ndcg, RMod.make_model, RL.rankNet) == orig

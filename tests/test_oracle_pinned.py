@@ -147,3 +147,52 @@ def test_model_forward_backward_match_reference_golden(model_golden):
         scale = np.abs(allg).max()
         for k in params:
             assert np.abs(grads[k] - g[pre + "grad." + k]).max() <= 2e-4 * scale + 1e-8, k
+
+
+# ---- pointwise / pairwise losses, mrr, stochastic NeuralSort ------------------
+_EXTRA = dict(ranknet=O.ranknet, bce=O.bce, ordinal=O.ordinal, pointwise_rmse=O.pointwise_rmse, binary_listnet=O.binary_listnet)
+
+
+def test_extra_losses_match_reference_golden(extra_golden):
+    from tests.cases import iter_extra_cases
+    n = 0
+    for name, kind, kw, yp, yt, rl, rg in iter_extra_cases(extra_golden):
+        loss, grad = _EXTRA[kind](yp, yt, **kw)
+        assert close(loss, rl), (name, loss, rl)
+        assert grad_close(grad, rg), (name, float(np.abs(grad - rg).max()))
+        n += 1
+    assert n == 36
+
+
+def test_mrr_matches_reference_golden(extra_golden):
+    g = extra_golden
+    for ci in range(int(g["n_cases"])):
+        pre = "c%d." % ci
+        s, y = g[pre + "s"], g[pre + "y"]
+        ats = [int(a) for a in g[pre + "mrr.ats"]]
+        assert np.array_equal(O.mrr(s, y, ats), g[pre + "mrr.val"])
+        assert np.array_equal(O.mrr(s, y), g[pre + "mrr.none"])
+        assert np.array_equal(O.mrr(s, np.where(y == -1, -1, 0).astype(np.float32), ats), g[pre + "mrr.zero"])
+
+
+def test_kat_mrr_and_ranknet():
+    # metrics.py:80-113 by hand: best label at predicted rank 1 -> 1/2; cut-off 1 -> 0
+    r = O.mrr(_a([0.9, 0.5, 0.7]), _a([0.0, 0.0, 1.0]), ats=[1, 2, 3])
+    assert np.allclose(r, [[0.0, 0.5, 0.5]])
+    # rankNet on one pair: log(1 + exp(-(s_i - s_j)))
+    l, g_ = O.ranknet(_a([0.2, 1.0]), _a([1.0, 0.0]))
+    assert l == pytest.approx(math.log(1 + math.exp(0.8)), rel=1e-6)
+    assert g_[0, 0] == pytest.approx(-1 / (1 + math.exp(-0.8)), rel=1e-6) and g_[0, 1] == pytest.approx(-g_[0, 0])
+
+
+def test_stochastic_neuralndcg_matches_reference_golden(extra_golden):
+    from tests.cases import iter_stochastic_cases
+    n = 0
+    for name, c, s, y, gum, rl, rg, strict in iter_stochastic_cases(extra_golden):
+        loss, grad = O.neuralndcg_stochastic(s, y, gum, temperature=c["tau"], k=c["k"], powered_relevancies=c["pw"],
+                                             transposed=c["tr"], beta=c["beta"], log_scores=c["log"])
+        assert close(loss, rl), (name, loss, rl)
+        assert grad_close(np.where(strict, grad, 0), np.where(strict, rg, 0)), (name,)
+        assert np.isfinite(grad).all()
+        n += 1
+    assert n == 16
