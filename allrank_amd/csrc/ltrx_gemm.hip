@@ -311,6 +311,137 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// NT, large-tile variant for the big projections: 256 x 256 x 32 tile, 8 waves (2 x 4), wave tile 128 x 64 (128
+// accumulator VGPRs), two LDS stages (128 KB: one workgroup per CU) and ONE LDS-only barrier per K-step.
+// Why (tools/lab/gemm_ablate.hip, gemm256.hip; MI355X, M 61440 x N 2048 x K 512): in the 128 x 128 kernel the memory side
+// (global loads -> split -> LDS) alone takes 340 us and the MFMAs alone 185 us, and the two do not overlap (567 us):
+//   * per MFMA the 256 x 256 tile needs half the global-load and LDS-write traffic and 3/4 of the LDS fragment reads;
+//   * __syncthreads() drains vmcnt(0), i.e. it exposes the latency of the prefetch issued just before it on every K-step;
+//     the barrier here orders LDS only (release/acquire fences on the "local" address space + s_barrier), so the global
+//     loads of tile t+2 stay in flight across it;
+//   * the steady-state loop is branch-free, which lets the scheduler interleave the split/ds_write VALU work of tile t+1
+//     with the MFMAs of tile t;
+//   * the output tile is streamed with nontemporal stores: C (0.5 GB for the FFN) no longer evicts the operand panels
+//     that the other tiles of the same XCD are about to re-read from L2.
+// Measured: 567 -> 365 us (FFN1), 560 -> 345 us (FFN2).  Used when M, N are multiples of 256, K of 32, and the grid fills
+// the chip; everything else (and the strict 3-term mode, whose LDS images do not fit twice) stays on the kernel above.
+// ------------------------------------------------------------------------------------------------------------------
+struct Smem256 {
+  __bf16 a[2][256 * 32];
+  __bf16 b[2][256 * 32];
+};
+
+__device__ __forceinline__ void lds_only_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                              int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
+                                                              const float* __restrict__ bias, int act,
+                                                              const float* __restrict__ aux, int ldaux, int tiles_n,
+                                                              ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step) {
+  constexpr int BK_ = 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem256* s = reinterpret_cast<Smem256*>(smem_raw);
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (id / tiles_n) * 256, n0 = (id % tiles_n) * 256;
+  const int wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+  const int srow = threadIdx.x >> 3, sc4 = (threadIdx.x & 7) * 4;        // staging: 64 rows x 8 float4 per pass, 4 passes
+  float4 ra[4], rb[4];
+  const float* Ap = A + (size_t)(m0 + srow) * lda + sc4;
+  const float* Bp = B + (size_t)(n0 + srow) * ldb + sc4;
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      ra[p] = *reinterpret_cast<const float4*>(Ap + (size_t)(64 * p) * lda + k0);
+      rb[p] = *reinterpret_cast<const float4*>(Bp + (size_t)(64 * p) * ldb + k0);
+    }
+  };
+  auto sstore = [&](Smem256& d) {
+    bf16x4 h, l, l2;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int o = swz_off<BK_>(srow + 64 * p, sc4);
+      split4<2>(ra[p], h, l, l2);
+      *reinterpret_cast<bf16x4*>(&d.a[0][o]) = h;
+      *reinterpret_cast<bf16x4*>(&d.a[1][o]) = l;
+      split4<2>(rb[p], h, l, l2);
+      *reinterpret_cast<bf16x4*>(&d.b[0][o]) = h;
+      *reinterpret_cast<bf16x4*>(&d.b[1][o]) = l;
+    }
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto mma = [&](const Smem256& t) {
+#pragma unroll
+    for (int ks = 0; ks < BK_ / 16; ++ks) {
+      bf16x8 af[2][4], bfr[2][2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          bfr[tt][j] = *reinterpret_cast<const bf16x8*>(&t.b[tt][swz_off<BK_>(wc * 64 + j * 32 + l31, ks * 16 + 8 * half)]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          af[tt][i] = *reinterpret_cast<const bf16x8*>(&t.a[tt][swz_off<BK_>(wr * 128 + i * 32 + l31, ks * 16 + 8 * half)]);
+      }
+#define LTRX_MMA256(TA, TB)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA][i], bfr[TB][j], acc[i][j], 0, 0, 0);
+      LTRX_MMA256(0, 1)
+      LTRX_MMA256(1, 0)
+      LTRX_MMA256(0, 0)
+#undef LTRX_MMA256
+    }
+  };
+
+  const int nk = K / BK_;
+  gload(0);
+  sstore(s[0]);
+  if (nk > 1) gload(BK_);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) {                 // steady state, branch-free: MFMAs of tile kt | stage tile kt+1 | prefetch kt+2
+    mma(s[kt & 1]);
+    sstore(s[(kt + 1) & 1]);
+    gload((kt + 2) * BK_);
+    lds_only_barrier();
+  }
+  for (; kt < nk; ++kt) {
+    mma(s[kt & 1]);
+    if (kt + 1 < nk) sstore(s[(kt + 1) & 1]);
+    __syncthreads();
+  }
+
+  ltrx::DropSpec dsp = drop;
+  if (drop_step) dsp.seed ^= drop_step[0] * 0x9E3779B9u;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wc * 64 + j * 32 + l31;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 128 + i * 32 + rowmap(r, half);
+        float v = acc[i][j][r] + bv;
+        if (act == 1) v = fmaxf(v, 0.f);
+        if (act == 2) v = (aux[(size_t)row * ldaux + col] > 0.f) ? v * drop.inv_keep : 0.f;
+        else if (drop.thresh != 0u) v *= ltrx::drop_keep_scale(dsp, (uint64_t)row * (uint64_t)N + (uint64_t)col);
+        __builtin_nontemporal_store(v, &C[(size_t)row * ldc + col]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // TN (weight gradient):  C[N',K'] = sum_m A[m][n'] * B[m][k'],  split over m into `splits` slabs
 // ------------------------------------------------------------------------------------------------------------------
 template <int NTERMS>
@@ -427,7 +558,8 @@ __global__ void __launch_bounds__(256) ltrx_gemm_slab_reduce_kernel(const float*
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-// tile variant: 0 = auto; 1 = 128x128x32 (4 waves); 2 = 128x128x64; 3 = 256x128x32 (8 waves); 4 = 256x128x64
+// tile variant: 0 = auto; 1 = 128x128x32 (4 waves); 2 = 128x128x64; 3 = 256x128x32 (8 waves); 4 = 256x128x64; 5 = pipelined
+// 128x128x32; 6 = 256x256x32 large-tile kernel (auto picks it for exact multiples with >= 360 tiles)
 static int g_nt_variant = 0;
 extern "C" void ltrx_gemm_set_variant(int v) { g_nt_variant = v; }
 
@@ -455,7 +587,24 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
     lda = 0;
     ldb = 0;
   }
+  // large-tile kernel: exact multiples only, and enough tiles to cover the 256 CUs at least ~1.4 times
+  if (v == 0 && !strict && (M % 256) == 0 && (N % 256) == 0 && (K % 32) == 0 && (size_t)(M / 256) * (N / 256) >= 360) v = 6;
   if (v == 0) v = 1;
+  if (v == 6) {
+    if ((M % 256) || (N % 256) || (K % 32) || strict) return LTRX_EUNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(2 * sizeof(Smem256))) != hipSuccess)
+        return LTRX_EHIP;
+      attr_set = true;
+    }
+    const int tiles_n = N / 256;
+    hipLaunchKernelGGL(ltrx_gemm_nt256_kernel, dim3((M / 256) * tiles_n), dim3(512), 2 * sizeof(Smem256), s, A, lda, B, ldb, C,
+                       ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step);
+    LTRX_LAUNCH_CHECK();
+    return LTRX_OK;
+  }
   if (strict) {
     launch_nt<3, 128, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, drop, drop_step, s);
   } else {

@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--slates-per-gpu", type=int, default=256)
     ap.add_argument("--slate-len", type=int, default=240)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-pass", action="store_true", help="profiling runs: skip the 64-slate side measurement")
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="transformer dropout (the shipped reference configs train with 0.1-0.4); masks are generated in-kernel")
     ap.add_argument("--gemm", default="split_bf16", choices=["split_bf16", "split_bf16_strict", "hipblaslt"],
@@ -296,7 +297,7 @@ def main():
             "roofline": roof,
             "kernel_times_us": {n: round(v["sec"] * 1e6, 1) for n, v in kern.items()},
         }
-        if world == 1 and B != 64 and args.engine == "fused":
+        if world == 1 and B != 64 and args.engine == "fused" and not args.no_side_pass:
             try:
                 m64 = build_model(w, device, args.dropout)
                 t64 = FusedTrainer(m64, w["loss"], w.get("loss_args", {}), 64, L, lr=1e-3, world_size=1, use_graph=True, gemm=args.gemm)

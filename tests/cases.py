@@ -80,3 +80,58 @@ def iter_stochastic_cases(gold):
             strict = (s != s.min()) if c["log"] else (s == s)
             yield (pre + "stoch%d" % si, c, s, y, gold[pre + "gumbel"][..., 0], gold[pre + "stoch%d.loss" % si],
                    gold[pre + "stoch%d.grad" % si], strict)
+
+
+def row4_kats():
+    """the known-answer tests of /root/reference/tests/losses/test_{ranknet,mrr,loss_ordinal,loss_pointwise,binary_listnet}.py
+    restated as (kind, kwargs, y_pred, y_true, expected): expected values come from the same independent closed forms the
+    reference tests use (BCE-with-logits of the score differences, cross-entropy by hand, ...)."""
+    import math
+    import numpy as np
+
+    def bcel(ds, ws=None):                                     # BCEWithLogitsLoss(weight)(ds, ones), mean
+        ws = ws or [1.0] * len(ds)
+        return float(np.mean([w * math.log1p(math.exp(-d)) for d, w in zip(ds, ws)]))
+
+    def xe(t, p):
+        return -t * math.log(p) - (1 - t) * math.log(1 - p)
+
+    def sm(v):
+        e = np.exp(np.asarray(v, np.float64) - np.max(v))
+        return e / e.sum()
+
+    P = -1.0
+    k = []
+    # test_ranknet.py:29-115
+    k += [("ranknet", {}, [0.5, 0.2], [1.0, 0.0], bcel([0.3])), ("ranknet", {}, [0.2, 0.5], [1.0, 0.0], bcel([-0.3])),
+          ("ranknet", {}, [0.5, 0.2, 0.1], [1.0, 0.0, 0.0], bcel([0.3, 0.4])), ("ranknet", {}, [0.2, 0.5], [0.0, 1.0], bcel([0.3])),
+          ("ranknet", {}, [0.2, 0.5], [0.0, 2.0], bcel([0.3])), ("ranknet", {}, [0.5, 0.2, 0.66], [1.0, 0.0, P], bcel([0.3])),
+          ("ranknet", dict(weight_by_diff=True), [0.5, 0.2, 0.1], [2.0, 1.0, 0.0], bcel([0.3, 0.4, 0.1], [1.0, 2.0, 1.0])),
+          ("ranknet", dict(weight_by_diff_powed=True), [0.5, 0.2, 0.1], [2.0, 1.0, 0.0], bcel([0.3, 0.4, 0.1], [3.0, 4.0, 1.0]))]
+    # test_loss_ordinal.py:28-58 (n = 2)
+    k += [("ordinal", dict(n=2), [[0.8, 0.6]], [1.0], xe(1, 0.8) + xe(0, 0.6)),
+          ("ordinal", dict(n=2), [[0.8, 0.7], [0.4, 0.3], [0.2, 0.1]], [2.0, 1.0, 0.0],
+           float(np.mean([xe(1, 0.8) + xe(1, 0.7), xe(1, 0.4) + xe(0, 0.3), xe(0, 0.2) + xe(0, 0.1)]))),
+          ("ordinal", dict(n=2), [[0.8, 0.6], [0.2, 0.1]], [1.0, P], xe(1, 0.8) + xe(0, 0.6))]
+    # test_loss_pointwise.py:16-47
+    k += [("pointwise_rmse", dict(no_of_levels=1), [0.5, 0.2], [1.0, 0.0], math.sqrt(np.mean([0.25, 0.04]))),
+          ("pointwise_rmse", dict(no_of_levels=1), [0.5, 0.2, 0.5], [1.0, 0.0, P], math.sqrt(np.mean([0.25, 0.04]))),
+          ("pointwise_rmse", dict(no_of_levels=3), [0.5, 0.2, 0.7, 0.8], [1.0, 0.0, 2.0, 3.0],
+           math.sqrt(np.mean([0.25, 0.36, 0.01, 0.36])))]
+    # test_binary_listnet.py:16-47
+    k += [("binary_listnet", dict(eps=0.0), [0.5, 0.2], [1.0, 0.0], float(-np.log(sm([0.5, 0.2])[0]))),
+          ("binary_listnet", {}, [0.5, -1e30], [1.0, 0.0], float(-np.log(sm([0.5, -1e30])[0] + 1e-10))),
+          ("binary_listnet", {}, [0.5, 0.2, 0.5], [1.0, 0.0, P], float(-np.log(sm([0.5, 0.2])[0] + 1e-10)))]
+    return k
+
+
+def mrr_kats():
+    """test_mrr.py:19-105 as (y_pred rows, y_true rows, ats, expected matrix)"""
+    P = -1.0
+    return [([[0.5, 0.2]], [[1.0, 0.0]], [10], [[1.0]]), ([[0.5, 0.2]], [[1.0, 0.0]], None, [[1.0]]),
+            ([[0.5, 0.2]], [[0.0, 1.0]], [10], [[0.5]]),
+            ([[0.2, 0.5], [0.5, 0.2]], [[0.0, 1.0], [0.0, 1.0]], [10], [[1.0], [0.5]]),
+            ([[0.5, 0.2]], [[0.0, 1.0]], [1, 2], [[0.0, 0.5]]),
+            ([[0.2, 0.5], [0.5, 0.2]], [[0.0, 1.0], [0.0, 1.0]], [1, 2], [[1.0, 1.0], [0.0, 0.5]]),
+            ([[0.5, 0.2]], [[0.0, 0.0]], [10], [[0.0]]),
+            ([[0.5, 0.2, 1.0]], [[1.0, 0.0, P]], [10], [[1.0]]), ([[0.5, 0.2, 1.0]], [[0.0, 1.0, P]], [10], [[0.5]])]

@@ -878,3 +878,51 @@ def test_fused_trainer_runs_the_row4_losses(loss_name, loss_args):
     for step in range(3):
         lf, la = float(ft.step(x, y).item()), float(tr.step(x, y, None).item())
         assert abs(lf - la) <= (2e-5 if step == 0 else 1e-3) * (1 + abs(la)), (loss_name, step, lf, la)
+
+
+def test_row4_kats_from_the_reference_tests():
+    from allrank_amd import losses as E, metrics as EM
+    from tests.cases import row4_kats, mrr_kats
+    for kind, kw, yp, yt, expected in row4_kats():
+        got = _extra_engine(kind, kw, np.asarray([yp], np.float32), np.asarray([yt], np.float32))[0]
+        assert np.isfinite(got) and abs(got - expected) <= 1e-5 * (1 + abs(expected)), (kind, kw, yp, got, expected)
+    for yp, yt, ats, expected in mrr_kats():
+        got = EM.mrr(_t(np.asarray(yp, np.float32)), _t(np.asarray(yt, np.float32)), ats=ats).cpu().numpy()
+        assert np.array_equal(got, np.asarray(expected, np.float32)), (yp, yt, ats, got)
+    assert E.with_ordinals(_t(np.asarray([[2.0, 1.0, 0.0]], np.float32)), 2).tolist() == [[[1.0, 1.0], [1.0, 0.0], [0.0, 0.0]]]
+
+
+def test_large_tile_gemm_matches_fp64_and_the_small_tile_kernel():
+    """the 256 x 256 x 32 kernel (auto-selected for big exact-multiple shapes, forced here through the variant hook):
+    same fp32-class error bound, all epilogues (bias, ReLU, ReLU(+dropout) mask, dropout) agree with the 128 x 128 kernel."""
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    rng = np.random.default_rng(11)
+    step = torch.tensor([3], dtype=torch.int32, device=DEV)
+    try:
+        for (Mm, N, K, forced) in [(512, 256, 32, True), (256, 768, 544, True), (1024, 512, 96, True), (6144, 4096, 64, False)]:
+            A = rng.standard_normal((Mm, K)).astype(np.float32)
+            Bw = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+            bias = rng.standard_normal(N).astype(np.float32)
+            aux = rng.standard_normal((Mm, N)).astype(np.float32)
+            At, Bt, bt, auxt = _t(A), _t(Bw), _t(bias), _t(aux)
+            outs = {}
+            for variant in (1, 6 if forced else 0):
+                lib.ltrx_gemm_set_variant(variant)
+                res = []
+                for (b_, act, ax, p) in ((bt, 1, None, 0.0), (None, 0, None, 0.0), (None, 2, auxt, 0.25), (bt, 1, None, 0.3), (bt, 0, None, 0.3)):
+                    C = torch.empty((Mm, N), device=DEV)
+                    LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, LB.ptr(C), N, Mm, N, K, LB.ptr(b_), act, LB.ptr(ax),
+                                              N if ax is not None else 0, p, 77, LB.ptr(step), 0, None), "gemm_nt")
+                    res.append(C)
+                outs[variant] = res
+            v_new = 6 if forced else 0
+            ref = np.maximum(A.astype(np.float64) @ Bw.astype(np.float64).T + bias, 0)
+            scale = (np.abs(A).astype(np.float64) @ np.abs(Bw).astype(np.float64).T).max()
+            err = float(np.abs(outs[v_new][0].cpu().numpy() - ref).max() / scale)
+            assert err < 6e-6, (Mm, N, K, err)           # K = 32: no averaging over the contraction
+            for a, b in zip(outs[1], outs[v_new]):
+                assert float((a - b).abs().max().item()) <= 2e-6 * scale + 1e-6, (Mm, N, K)
+                assert torch.equal(a == 0, b == 0)                  # identical ReLU / dropout masks
+    finally:
+        lib.ltrx_gemm_set_variant(0)

@@ -196,3 +196,15 @@ def test_stochastic_neuralndcg_matches_reference_golden(extra_golden):
         assert np.isfinite(grad).all()
         n += 1
     assert n == 16
+
+
+def test_row4_kats_from_the_reference_tests():
+    from tests.cases import row4_kats, mrr_kats
+    for kind, kw, yp, yt, expected in row4_kats():
+        got = _EXTRA[kind](np.asarray([yp], np.float32), np.asarray([yt], np.float32), **kw)[0]
+        assert math.isfinite(got) and got == pytest.approx(expected, rel=2e-6, abs=1e-9), (kind, kw, yp, got, expected)
+    for yp, yt, ats, expected in mrr_kats():
+        assert np.array_equal(O.mrr(np.asarray(yp, np.float32), np.asarray(yt, np.float32), ats), np.asarray(expected, np.float32))
+    # test_loss_ordinal.py:20-24
+    t = (np.asarray([[2.0, 1.0, 0.0]])[:, :, None] >= np.arange(1, 3)[None, None, :]).astype(float).tolist()
+    assert t == [[[1.0, 1.0], [1.0, 0.0], [0.0, 0.0]]]
