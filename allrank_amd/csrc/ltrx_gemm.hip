@@ -544,6 +544,134 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// TN, large-tile variant (weight gradients of the big projections): 256 x 256 output tile, 8 waves (wave tile 128 x 64),
+// K-step = 32 contraction rows, two LDS stages + LDS-only barrier, split-K slabs as above.
+// Staging: 8 consecutive lanes fetch 128 contiguous bytes of one contraction row (16-byte loads, 4x fewer VMEM
+// instructions than the dword loads above); a thread owns a 4 (m) x 4 (column) block of A and of B, i.e. after the split
+// one 8-byte LDS write per column lands at [column][m .. m+3].  Rows r and r + 16 of an image swap bank halves (swz_t) so
+// that the 16 lanes of a store group (8 column groups x 2 m-groups) hit 16 distinct bank pairs; the fragment reads stay
+// conflict-free under that row permutation.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz_t(int row, int k) {
+  const int c = (k >> 3) ^ ((row >> 2) & 3);
+  return (row ^ ((row >> 4) & 1)) * 32 + c * 8 + (k & 7);
+}
+
+__global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                              int ldb, float* __restrict__ slabs, float* __restrict__ bias_slabs,
+                                                              int M, int NP, int KP, int tiles_k, int m_per_split) {
+  constexpr int BK_ = 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem256* s = reinterpret_cast<Smem256*>(smem_raw);
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 256;
+  const int wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+  const int mbeg = split * m_per_split, mend = min(M, mbeg + m_per_split);
+  const int cg = (threadIdx.x & 7) + 8 * wave, mg = (threadIdx.x >> 3) & 7;
+  const float* PA = A + n0 + (size_t)(4 * mg) * lda + 4 * cg;
+  const float* PB = B + k0 + (size_t)(4 * mg) * ldb + 4 * cg;
+  float4 r[2][4];                    // [operand][m row]
+  auto gload = [&](int mt) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      r[0][e] = *reinterpret_cast<const float4*>(PA + (size_t)(mt + e) * lda);
+      r[1][e] = *reinterpret_cast<const float4*>(PB + (size_t)(mt + e) * ldb);
+    }
+  };
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = bias_slabs != nullptr && (tile % tiles_k) == 0;      // column sums of A = the bias gradient
+  auto sstore = [&](Smem256& d) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      __bf16* img0 = g ? d.b[0] : d.a[0];
+      __bf16* img1 = g ? d.b[1] : d.a[1];
+      const float cx[4][4] = {{r[g][0].x, r[g][1].x, r[g][2].x, r[g][3].x}, {r[g][0].y, r[g][1].y, r[g][2].y, r[g][3].y},
+                              {r[g][0].z, r[g][1].z, r[g][2].z, r[g][3].z}, {r[g][0].w, r[g][1].w, r[g][2].w, r[g][3].w}};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x4 h, l, l2;
+        split4<2>(make_float4(cx[c][0], cx[c][1], cx[c][2], cx[c][3]), h, l, l2);
+        const int o = swz_t(4 * cg + c, 4 * mg);
+        *reinterpret_cast<bf16x4*>(&img0[o]) = h;
+        *reinterpret_cast<bf16x4*>(&img1[o]) = l;
+        if (g == 0 && want_bias) bsum[c] += (cx[c][0] + cx[c][1]) + (cx[c][2] + cx[c][3]);
+      }
+    }
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  auto mma = [&](const Smem256& t) {
+#pragma unroll
+    for (int ks = 0; ks < BK_ / 16; ++ks) {
+      bf16x8 af[2][4], bfr[2][2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          bfr[tt][j] = *reinterpret_cast<const bf16x8*>(&t.b[tt][swz_t(wc * 64 + j * 32 + l31, ks * 16 + 8 * half)]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          af[tt][i] = *reinterpret_cast<const bf16x8*>(&t.a[tt][swz_t(wr * 128 + i * 32 + l31, ks * 16 + 8 * half)]);
+      }
+#define LTRX_MMA256(TA, TB)                                                                                       \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA][i], bfr[TB][j], acc[i][j], 0, 0, 0);
+      LTRX_MMA256(0, 1)
+      LTRX_MMA256(1, 0)
+      LTRX_MMA256(0, 0)
+#undef LTRX_MMA256
+    }
+  };
+  const int nk = (mend - mbeg) / BK_;            // M and m_per_split are multiples of 32 (host)
+  if (nk > 0) {
+    gload(mbeg);
+    sstore(s[0]);
+    if (nk > 1) gload(mbeg + BK_);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+      sstore(s[(kt + 1) & 1]);
+      gload(mbeg + (kt + 2) * BK_);
+      mma(s[kt & 1]);
+      lds_only_barrier();
+    }
+    for (; kt < nk; ++kt) {
+      mma(s[kt & 1]);
+      if (kt + 1 < nk) sstore(s[(kt + 1) & 1]);
+      __syncthreads();
+    }
+  }
+  if (want_bias) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = bsum[c];
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (mg == 0) bias_slabs[(size_t)split * NP + n0 + 4 * cg + c] = v;
+    }
+  }
+  float* slab = slabs + (size_t)split * NP * KP;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = k0 + wc * 64 + j * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = n0 + wr * 128 + i * 32 + rowmap(q, half);
+        slab[(size_t)row * KP + col] = acc[i][j][q];
+      }
+  }
+}
+
 // C[i] = sum_s slabs[s][i]   (fixed order; 16-byte accesses when n % 4 == 0, scalar otherwise)
 __global__ void __launch_bounds__(256) ltrx_gemm_slab_reduce_kernel(const float* __restrict__ slabs, int splits,
                                                                     size_t n, float* __restrict__ C) {
@@ -633,10 +761,27 @@ static int tn_splits(int M, int tiles) {
   return want < 1 ? 1 : want;
 }
 
+// large-tile wgrad kernel: exact multiples only
+static bool tn256_ok(int M, int NP, int KP) { return (NP % 256) == 0 && (KP % 256) == 0 && (M % 32) == 0 && M >= 2048; }
+static void tn256_plan(int M, int NP, int KP, int* splits, int* mps) {
+  const int tiles = (NP / 256) * (KP / 256);
+  int sp = (256 + tiles - 1) / tiles;                 // one workgroup per CU
+  if (sp > M / 128) sp = M / 128;                     // at least 4 K-steps per split
+  if (sp < 1) sp = 1;
+  int m = ((M + sp - 1) / sp + 31) / 32 * 32;
+  *mps = m;
+  *splits = (M + m - 1) / m;
+}
+
 extern "C" size_t ltrx_gemm_tn_workspace_bytes(int M, int NP, int KP) {
   if (M <= 0 || NP <= 0 || KP <= 0) return 0;
   const int tiles = ((NP + 127) / 128) * ((KP + BN - 1) / BN);
-  const size_t sp = (size_t)tn_splits(M, tiles);
+  size_t sp = (size_t)tn_splits(M, tiles);
+  if (tn256_ok(M, NP, KP)) {
+    int s2, mps;
+    tn256_plan(M, NP, KP, &s2, &mps);
+    if ((size_t)s2 > sp) sp = (size_t)s2;
+  }
   return (sp * NP * KP + 2 * sp * NP) * sizeof(float);
 }
 
@@ -644,6 +789,33 @@ extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, fl
                             int KP, int strict, void* ws, ltrx_stream_t stream) {
   if (!A || !B || !C || !ws || M <= 0 || NP <= 0 || KP <= 0) return LTRX_EINVAL;
   if (lda < NP || ldb < KP) return LTRX_EUNSUPPORTED;
+  if (!strict && g_nt_variant != 1 && tn256_ok(M, NP, KP) && (lda & 3) == 0 && (ldb & 3) == 0) {
+    hipStream_t s = (hipStream_t)stream;
+    int splits, mps;
+    tn256_plan(M, NP, KP, &splits, &mps);
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)ltrx_gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(2 * sizeof(Smem256))) != hipSuccess)
+        return LTRX_EHIP;
+      attr_set = true;
+    }
+    float* bslabs = bias_out ? (float*)ws + (size_t)splits * NP * KP : nullptr;
+    hipLaunchKernelGGL(ltrx_gemm_tn256_kernel, dim3((NP / 256) * (KP / 256), splits), dim3(512), 2 * sizeof(Smem256), s, A, lda, B,
+                       ldb, (float*)ws, bslabs, M, NP, KP, KP / 256, mps);
+    LTRX_LAUNCH_CHECK();
+    if (bias_out) {
+      hipLaunchKernelGGL(ltrx_gemm_slab_reduce_kernel, dim3((NP + 255) / 256), dim3(256), 0, s, (const float*)bslabs, splits,
+                         (size_t)NP, bias_out);
+      LTRX_LAUNCH_CHECK();
+    }
+    const size_t n = (size_t)NP * KP;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ltrx_gemm_slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)ws, splits, n, C);
+    LTRX_LAUNCH_CHECK();
+    return LTRX_OK;
+  }
   const int tiles_n = (NP + 127) / 128, tiles_k = (KP + BN - 1) / BN;
   const int tiles = tiles_n * tiles_k;
   const int splits = tn_splits(M, tiles);

@@ -179,14 +179,14 @@ __device__ __forceinline__ void zero_acc(f32x16 (&o)[DKP / 32]) {
 // ------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------
-template <int DKP>
+template <int DKP, bool DROP>
 __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                               const float* __restrict__ v,
                                                               const uint8_t* __restrict__ kpm, int L, int h, int dk,
                                                               int rs, float* __restrict__ o, int ors,
                                                               float* __restrict__ lse, float scale, DropCfg drop,
                                                               const uint32_t* __restrict__ drop_step) {
-  if (drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
+  if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   __shared__ __attribute__((aligned(16))) float ktile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float vtile[Tile<DKP>::FLOATS];
   __shared__ float kmask[32];
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
       ps += p[r];
     }
     l = l * alpha + ps;                      // the softmax normaliser counts every key (dropout comes after softmax)
-    if (drop.thresh != 0u) {
+    if (DROP) {
       const int qd = q0 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) p[r] *= drop_scale(drop, blockIdx.y, L, qd, kt * 32 + rowmap(r, half));
@@ -261,13 +261,13 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------------------------
 // backward: dQ   (wave owns 32 queries, streams key tiles)
 // ------------------------------------------------------------------------------------------------------------------
-template <int DKP>
+template <int DKP, bool DROP>
 __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ kpm, const float* __restrict__ o, const float* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ delta, int L, int h, int dk, int rs, int ors,
     float* __restrict__ dq, int drs, float scale, DropCfg drop, const uint32_t* __restrict__ drop_step) {
-  if (drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
+  if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   __shared__ __attribute__((aligned(16))) float ktile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float vtile[Tile<DKP>::FLOATS];
   __shared__ float kmask[32];
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float p = (kmask[rowmap(r, half)] != 0.f) ? 0.f : expf(s[r] * scale - lse_q);
-      const float dm = (drop.thresh != 0u) ? drop_scale(drop, blockIdx.y, L, qrow, kt * 32 + rowmap(r, half)) : 1.0f;
+      const float dm = DROP ? drop_scale(drop, blockIdx.y, L, qrow, kt * 32 + rowmap(r, half)) : 1.0f;
       ds[r] = p * (dp[r] * dm - del_q) * scale;
     }
     cols_x_p<DKP>(ktile, ds, dqacc);
@@ -330,13 +330,13 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
 // ------------------------------------------------------------------------------------------------------------------
 // backward: dK, dV   (wave owns 32 keys, streams query tiles)
 // ------------------------------------------------------------------------------------------------------------------
-template <int DKP>
-__global__ void __launch_bounds__(256) ltrx_mha_bwd_dkdv_kernel(
+template <int DKP, bool DROP>
+__global__ void __launch_bounds__(256, DROP ? 1 : 2) ltrx_mha_bwd_dkdv_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ kpm, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, int L, int h, int dk, int rs, int ors, float* __restrict__ dkout,
     float* __restrict__ dvout, int drs, float scale, DropCfg drop, const uint32_t* __restrict__ drop_step) {
-  if (drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
+  if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   __shared__ __attribute__((aligned(16))) float qtile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float dotile[Tile<DKP>::FLOATS];
   __shared__ float lse_t[32];
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(256) ltrx_mha_bwd_dkdv_kernel(
     f32x16 dm;                                             // dropout keep-scale of (q, key), 1 when dropout is off
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      dm[r] = (drop.thresh != 0u) ? drop_scale(drop, blockIdx.y, L, qt * 32 + rowmap(r, half), key) : 1.0f;
+      dm[r] = DROP ? drop_scale(drop, blockIdx.y, L, qt * 32 + rowmap(r, half), key) : 1.0f;
     {
       f32x16 pd;
 #pragma unroll
@@ -460,8 +460,12 @@ extern "C" int ltrx_mha_fwd(const float* q, const float* k, const float* v, cons
   const dim3 grid((L + 127) / 128, B * h);
   const float scale = 1.0f / sqrtf((float)d_k);
 #define CALL(DKP)                                                                                                 \
-  hipLaunchKernelGGL(ltrx_mha_fwd_kernel<DKP>, grid, dim3(256), 0, s, q, k, v, key_pad_mask, L, h, d_k, row_stride, o, \
-                     o_row_stride, lse_out, scale, drop, seed_step)
+  if (drop.thresh != 0u)                                                                                          \
+    hipLaunchKernelGGL((ltrx_mha_fwd_kernel<DKP, true>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, L, h, d_k, row_stride, \
+                       o, o_row_stride, lse_out, scale, drop, seed_step);                                          \
+  else                                                                                                            \
+    hipLaunchKernelGGL((ltrx_mha_fwd_kernel<DKP, false>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, L, h, d_k, row_stride, \
+                       o, o_row_stride, lse_out, scale, drop, seed_step)
   LTRX_DKP_DISPATCH(d_k, CALL);
 #undef CALL
   LTRX_LAUNCH_CHECK();
@@ -491,14 +495,22 @@ extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, cons
   const dim3 grid((L + 127) / 128, B * h);
   const float scale = 1.0f / sqrtf((float)d_k);
 #define CALLQ(DKP)                                                                                                   \
-  hipLaunchKernelGGL(ltrx_mha_bwd_dq_kernel<DKP>, grid, dim3(256), 0, s, q, k, v, key_pad_mask, o, dout, lse, delta, L, h, \
-                     d_k, row_stride, o_row_stride, dq, d_row_stride, scale, drop, seed_step)
+  if (drop.thresh != 0u)                                                                                             \
+    hipLaunchKernelGGL((ltrx_mha_bwd_dq_kernel<DKP, true>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, o, dout, lse, delta, \
+                       L, h, d_k, row_stride, o_row_stride, dq, d_row_stride, scale, drop, seed_step);                \
+  else                                                                                                               \
+    hipLaunchKernelGGL((ltrx_mha_bwd_dq_kernel<DKP, false>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, o, dout, lse, delta, \
+                       L, h, d_k, row_stride, o_row_stride, dq, d_row_stride, scale, drop, seed_step)
   LTRX_DKP_DISPATCH(d_k, CALLQ);
 #undef CALLQ
   LTRX_LAUNCH_CHECK();
 #define CALLK(DKP)                                                                                                     \
-  hipLaunchKernelGGL(ltrx_mha_bwd_dkdv_kernel<DKP>, grid, dim3(256), 0, s, q, k, v, key_pad_mask, dout, lse, delta, L, h, \
-                     d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale, drop, seed_step)
+  if (drop.thresh != 0u)                                                                                               \
+    hipLaunchKernelGGL((ltrx_mha_bwd_dkdv_kernel<DKP, true>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, dout, lse, delta, L, \
+                       h, d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale, drop, seed_step);                  \
+  else                                                                                                                 \
+    hipLaunchKernelGGL((ltrx_mha_bwd_dkdv_kernel<DKP, false>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, dout, lse, delta, L, \
+                       h, d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale, drop, seed_step)
   LTRX_DKP_DISPATCH(d_k, CALLK);
 #undef CALLK
   LTRX_LAUNCH_CHECK();

@@ -110,8 +110,9 @@ def time_kernels(w, B, L, device):
         t_g = ev(lambda: LB.check(lib.ltrx_gemm_nt(LB.ptr(A_), Kk, LB.ptr(W_), Kk, LB.ptr(C_), Nn, Mrows, Nn, Kk, LB.ptr(b_), 1,
                                                    None, 0, 0.0, 0, None, 0, st), "gemm_nt"))
         n_nt = 1 + 8 * w["N"] - 1          # fwd: fc + 4/layer; dgrad: 4/layer  (head GEMV is a separate kernel)
-        res["ltrx_gemm_nt_kernel<2,128,32> @FFN1"] = dict(sec=t_g, flops=2.0 * Mrows * Nn * Kk, launches_per_step=n_nt,
-                                                          shape=[Mrows, Nn, Kk])
+        big = (Mrows % 256 == 0 and Nn % 256 == 0 and Kk % 32 == 0 and (Mrows // 256) * (Nn // 256) >= 360)   # ltrx_gemm.hip dispatch
+        res["%s @FFN1" % ("ltrx_gemm_nt256_kernel" if big else "ltrx_gemm_nt_kernel<2,128,32>")] = dict(
+            sec=t_g, flops=2.0 * Mrows * Nn * Kk, launches_per_step=n_nt, shape=[Mrows, Nn, Kk])
         del A_, W_, b_, C_
     y = torch.zeros(B, L, device=device)
     s = torch.randn(B, L, device=device, requires_grad=True)
@@ -261,7 +262,7 @@ def main():
             alg = k["flops"] / k["sec"] / 1e12            # algorithmic: the 2*M*N*K flop of the fp32 GEMM it replaces
             traffic = None
             try:                                           # HBM bytes per launch from the committed PMC passes (same shape only)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm256.json" if "nt256" in name else "r01_pmc_gemm.json")))
                 if [pm["shape"]["M"], pm["shape"]["N"], pm["shape"]["K"]] == k["shape"]:
                     traffic = pm["derived"]["nt_hbm_read_bytes_corrected"] + pm["derived"]["nt_hbm_write_bytes"]
             except Exception:

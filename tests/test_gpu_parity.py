@@ -926,3 +926,31 @@ def test_large_tile_gemm_matches_fp64_and_the_small_tile_kernel():
                 assert torch.equal(a == 0, b == 0)                  # identical ReLU / dropout masks
     finally:
         lib.ltrx_gemm_set_variant(0)
+
+
+def test_large_tile_wgrad_gemm_matches_fp64_and_the_small_tile_kernel():
+    """the 256 x 256 split-K weight-gradient kernel (auto for NP, KP multiples of 256) vs fp64 and vs the 128 x 128 kernel."""
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    rng = np.random.default_rng(12)
+    try:
+        for (Mm, NP, KP) in [(2048, 256, 256), (4096, 512, 768), (15360, 2048, 512), (6176, 256, 512)]:
+            A = rng.standard_normal((Mm, NP)).astype(np.float32)
+            Bx = rng.standard_normal((Mm, KP)).astype(np.float32)
+            At, Bt = _t(A), _t(Bx)
+            ws = torch.empty(max(lib.ltrx_gemm_tn_workspace_bytes(Mm, NP, KP), 64), dtype=torch.uint8, device=DEV)
+            outs = {}
+            for variant in (1, 0):
+                lib.ltrx_gemm_set_variant(variant)
+                C = torch.empty((NP, KP), device=DEV)
+                gb = torch.empty(NP, device=DEV)
+                LB.check(lib.ltrx_gemm_tn(LB.ptr(At), NP, LB.ptr(Bt), KP, LB.ptr(C), LB.ptr(gb), Mm, NP, KP, 0, LB.ptr(ws), None), "gemm_tn")
+                outs[variant] = (C, gb)
+            ref = A.astype(np.float64).T @ Bx.astype(np.float64)
+            scale = (np.abs(A).astype(np.float64).T @ np.abs(Bx).astype(np.float64)).max()
+            assert float(np.abs(outs[0][0].cpu().numpy() - ref).max() / scale) < 4e-6, (Mm, NP, KP)
+            assert float((outs[0][0] - outs[1][0]).abs().max().item()) <= 4e-6 * scale
+            bref = A.astype(np.float64).sum(0)
+            assert float(np.abs(outs[0][1].cpu().numpy() - bref).max()) < 1e-5 * max(1.0, np.abs(A).sum(0).max())
+    finally:
+        lib.ltrx_gemm_set_variant(0)

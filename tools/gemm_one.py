@@ -5,7 +5,7 @@ lib = LB.lib()
 m, n, k = int(os.environ.get('GM', '15360')), 2048, 512
 A = torch.randn(m, k, device="cuda"); B = torch.randn(n, k, device="cuda") / k ** 0.5; bias = torch.randn(n, device="cuda")
 C = torch.empty(m, n, device="cuda")
-lib.ltrx_gemm_set_variant(int(os.environ.get("GV", "1")))
+lib.ltrx_gemm_set_variant(int(os.environ.get("GV", "0")))
 for _ in range(5):
     LB.check(lib.ltrx_gemm_nt(LB.ptr(A), k, LB.ptr(B), k, LB.ptr(C), n, m, n, k, LB.ptr(bias), 0, None, 0, 0.0, 0, None, 0, None), "nt")
 dY = torch.randn(m, n, device="cuda"); X = torch.randn(m, k, device="cuda")
