@@ -29,7 +29,8 @@ def main():
     x = torch.tensor(rng.standard_normal((G, L, 20)).astype(np.float32), device="cuda:0")
     y = torch.tensor(rng.integers(0, 5, (G, L)).astype(np.float32), device="cuda:0")
     y[5, 30:] = -1
-    for loss_name, args in (("approxNDCGLoss", {}), ("neuralNDCG", {}), ("lambdaLoss", dict(weighing_scheme="lambdaRank_scheme", reduction="mean"))):
+    for loss_name, args in (("approxNDCGLoss", {}), ("neuralNDCG", {}), ("lambdaLoss", dict(weighing_scheme="lambdaRank_scheme", reduction="mean")),
+                            ("rankNet_weightByGTDiff", {})):
         lo, hi = parallel.shard_slates(G, rank, world)
         m_sh = build()
         ft = FusedTrainer(m_sh, loss_name, args, hi - lo, L, lr=1e-3, world_size=world, use_graph=False, gemm="hipblaslt")
@@ -45,6 +46,27 @@ def main():
         assert gerr < 1e-4, (loss_name, "grad", gerr)
         werr = (ft.flat_p - f1.flat_p).abs().max().item()
         assert werr <= 2.1e-3, (loss_name, "weights", werr)   # one Adam step of lr=1e-3; ~0-gradient params may flip sign
+    # count-normalised pointwise losses through the plugin functions: the rank shares (each divided by the GLOBAL count,
+    # all-reduced inside the loss) add up to the single-process value, and so do the gradients
+    from allrank_amd import losses as E, sharding
+    lo, hi = parallel.shard_slates(G, rank, world)
+    p = torch.sigmoid(x[:, :, 0]).contiguous()
+    p3 = torch.sigmoid(x[:, :, :3]).contiguous()
+    yb = torch.where(y == -1, y, (y >= 2).float())
+    for fn, pred, tgt, kw in ((E.bce, p, yb, {}), (E.ordinal, p3, y, dict(n=3)), (E.rankNet, x[:, :, 1].contiguous(), y, {}),
+                              (E.pointwise_rmse, p, y, dict(no_of_levels=4)), (E.binary_listNet, x[:, :, 2].contiguous(), yb, {})):
+        full_in = pred.clone().requires_grad_(True)
+        full = fn(full_in, tgt, **kw)
+        full.backward()
+        part_in = pred[lo:hi].clone().requires_grad_(True)
+        with sharding.shard_context(G, None):
+            part = fn(part_in, tgt[lo:hi], **kw)
+        part.backward()
+        tot = part.detach().clone()
+        dist.all_reduce(tot)
+        assert abs(tot.item() - full.item()) <= 1e-5 * (1 + abs(full.item())), (fn.__name__, tot.item(), full.item())
+        gerr = (part_in.grad - full_in.grad[lo:hi]).abs().max().item()
+        assert gerr <= 1e-6 + 1e-4 * full_in.grad.abs().max().item(), (fn.__name__, "grad", gerr)
     if rank == 0:
         print("EQUIV_OK")
     dist.destroy_process_group()
