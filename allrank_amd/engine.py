@@ -150,6 +150,17 @@ class FusedTrainer(object):
         self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
         self.drop_step = torch.zeros(1, dtype=torch.int32, device=dev)       # u32 word folded into every dropout seed
+        # gradient buckets for the multi-GPU all-reduce, in the order the backward completes them: the tail of the flat
+        # buffer (last encoder layer + final norm + head) first, then one bucket per earlier layer, the FC stack last
+        offs_of = {id(p): o for p, o in zip(order, offs)}
+        starts = [offs_of[id(lay.self_attn.linears[0].weight)] for lay in enc.layers] if enc is not None else []
+        self._buckets = []
+        prev_hi = n
+        for st_ in reversed(starts):
+            self._buckets.append((st_, prev_hi))
+            prev_hi = st_
+        self._buckets.append((0, prev_hi))
+        self._works = []
         self._pv, self._gv = {}, {}
         with torch.no_grad():
             for p, o in zip(order, offs):
@@ -303,6 +314,15 @@ class FusedTrainer(object):
         for st in self.layers:
             st["wqkvT"].copy_(st["wqkv"].t())
 
+    def _bucket_done(self, k):
+        """gradient bucket k is final: start its all-reduce(SUM) now, behind the rest of the backward (the collective runs
+        on the process group's own stream; ``_full`` waits for all of them before the optimizer step)"""
+        if self.world > 1:
+            import torch.distributed as dist
+            lo, hi = self._buckets[k]
+            if hi > lo:
+                self._works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def _lin_fwd(self, x, w, b, out, act=0, p=0.0, seed=0):
         """out = drop_p(act(x w^T + b))   (nn.Linear forward, act 1 = ReLU; dropout in the epilogue)"""
         if self.gemm == "hipblaslt":
@@ -430,6 +450,7 @@ class FusedTrainer(object):
                 self._lin_dgrad(dq, st["wqkv"], st.get("wqkvT"), self.tmp_d)
                 self._ln_bwd(self.tmp_d, st["xin"], W(n0.a_2), st["mean0"], st["rstd0"], ds, other, G(n0.a_2), G(n0.b_2))
                 ds, other = other, ds                              # ds = d loss / d (layer input)
+                self._bucket_done(self.N - 1 - i)
         else:
             ds, other = ga, gb
         # FC stack
@@ -447,6 +468,7 @@ class FusedTrainer(object):
                                 relu_of=self.fc_out[i - 1] if self.fc_act == 1 else None, p=self.p_fc,
                                 seed=self._site(1000 + i - 1))
                 ds = self.fc_dgrad[i - 1]
+        self._bucket_done(len(self._buckets) - 1)
         return loss
 
     def _adam(self):
@@ -458,9 +480,9 @@ class FusedTrainer(object):
     def _full(self):
         self.LB.check(self.lib.ltrx_bump_u32(self.LB.ptr(self.drop_step), self._st()), "bump_u32")   # fresh masks every step
         loss = self._body()
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+        for w_ in self._works:                                   # bucketed gradient all-reduces launched during the backward
+            w_.wait()
+        self._works = []
         self._adam()
         self._refresh_transposes()
         return loss
