@@ -323,8 +323,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 //     with the MFMAs of tile t;
 //   * the output tile is streamed with nontemporal stores: C (0.5 GB for the FFN) no longer evicts the operand panels
 //     that the other tiles of the same XCD are about to re-read from L2.
-// Measured: 567 -> 365 us (FFN1), 560 -> 345 us (FFN2).  Used when M, N are multiples of 256, K of 32, and the grid fills
-// the chip; everything else (and the strict 3-term mode, whose LDS images do not fit twice) stays on the kernel above.
+// Measured: 567 -> 365 us (FFN1), 560 -> 345 us (FFN2).  Used when N is a multiple of 256, K of 32, and the grid fills
+// the chip (a ragged last row tile is handled by clamped loads and guarded stores); everything else (and the strict
+// 3-term mode, whose LDS images do not fit twice) stays on the kernel above.
 // ------------------------------------------------------------------------------------------------------------------
 struct Smem256 {
   __bf16 a[2][256 * 32];
@@ -337,6 +338,7 @@ __device__ __forceinline__ void lds_only_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+template <bool TAIL>
 __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                               int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
                                                               const float* __restrict__ bias, int act,
@@ -351,12 +353,20 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
   const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
   const int srow = threadIdx.x >> 3, sc4 = (threadIdx.x & 7) * 4;        // staging: 64 rows x 8 float4 per pass, 4 passes
   float4 ra[4], rb[4];
-  const float* Ap = A + (size_t)(m0 + srow) * lda + sc4;
+  // rows of A beyond M (the last row tile of a batch whose size is not a multiple of 256) are clamped to row M-1: they
+  // are read but their results are never stored
+  // (TAIL: only instantiated for a batch whose row count is not a multiple of 256 -- the extra address registers cost the
+  // exact-multiple kernel 20 % when they are always there)
+  const int ar0 = TAIL ? min(m0 + srow, M - 1) : m0 + srow;
+  const float* Ap = A + (size_t)ar0 * lda + sc4;
   const float* Bp = B + (size_t)(n0 + srow) * ldb + sc4;
   auto gload = [&](int k0) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      ra[p] = *reinterpret_cast<const float4*>(Ap + (size_t)(64 * p) * lda + k0);
+      if constexpr (TAIL)
+        ra[p] = *reinterpret_cast<const float4*>(Ap + (size_t)min(64 * p, M - 1 - ar0) * lda + k0);
+      else
+        ra[p] = *reinterpret_cast<const float4*>(Ap + (size_t)(64 * p) * lda + k0);
       rb[p] = *reinterpret_cast<const float4*>(Bp + (size_t)(64 * p) * ldb + k0);
     }
   };
@@ -432,6 +442,7 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wr * 128 + i * 32 + rowmap(r, half);
+        if (TAIL && row >= M) continue;
         float v = acc[i][j][r] + bv;
         if (act == 1) v = fmaxf(v, 0.f);
         if (act == 2) v = (aux[(size_t)row * ldaux + col] > 0.f) ? v * drop.inv_keep : 0.f;
@@ -716,20 +727,27 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
     ldb = 0;
   }
   // large-tile kernel: exact multiples only, and enough tiles to cover the 256 CUs at least ~1.4 times
-  if (v == 0 && !strict && (M % 256) == 0 && (N % 256) == 0 && (K % 32) == 0 && (size_t)(M / 256) * (N / 256) >= 360) v = 6;
+  if (v == 0 && !strict && (N % 256) == 0 && (K % 32) == 0 && (size_t)((M + 255) / 256) * (N / 256) >= 360) v = 6;
   if (v == 0) v = 1;
   if (v == 6) {
-    if ((M % 256) || (N % 256) || (K % 32) || strict) return LTRX_EUNSUPPORTED;
+    if ((N % 256) || (K % 32) || strict) return LTRX_EUNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      if (hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(2 * sizeof(Smem256))) != hipSuccess ||
+          hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(2 * sizeof(Smem256))) != hipSuccess)
         return LTRX_EHIP;
       attr_set = true;
     }
     const int tiles_n = N / 256;
-    hipLaunchKernelGGL(ltrx_gemm_nt256_kernel, dim3((M / 256) * tiles_n), dim3(512), 2 * sizeof(Smem256), s, A, lda, B, ldb, C,
-                       ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step);
+    const dim3 grid(((M + 255) / 256) * tiles_n);
+    if (M % 256)
+      hipLaunchKernelGGL(ltrx_gemm_nt256_kernel<true>, grid, dim3(512), 2 * sizeof(Smem256), s, A, lda, B, ldb, C, ldc, M, N, K,
+                         bias, act, aux, ldaux, tiles_n, drop, drop_step);
+    else
+      hipLaunchKernelGGL(ltrx_gemm_nt256_kernel<false>, grid, dim3(512), 2 * sizeof(Smem256), s, A, lda, B, ldb, C, ldc, M, N, K,
+                         bias, act, aux, ldaux, tiles_n, drop, drop_step);
     LTRX_LAUNCH_CHECK();
     return LTRX_OK;
   }

@@ -900,7 +900,8 @@ def test_large_tile_gemm_matches_fp64_and_the_small_tile_kernel():
     rng = np.random.default_rng(11)
     step = torch.tensor([3], dtype=torch.int32, device=DEV)
     try:
-        for (Mm, N, K, forced) in [(512, 256, 32, True), (256, 768, 544, True), (1024, 512, 96, True), (6144, 4096, 64, False)]:
+        for (Mm, N, K, forced) in [(512, 256, 32, True), (256, 768, 544, True), (1024, 512, 96, True), (6144, 4096, 64, False),
+                                   (700, 512, 64, True), (33, 256, 160, True), (24000, 1536, 64, False)]:      # ragged last row tile
             A = rng.standard_normal((Mm, K)).astype(np.float32)
             Bw = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
             bias = rng.standard_normal(N).astype(np.float32)
