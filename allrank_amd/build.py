@@ -26,7 +26,7 @@ def _digest():
     files = _sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     files.append(os.path.join(os.path.dirname(HERE), "include", "ltrx.h"))
     for f in files:
-        h.update(f.encode())
+        h.update(os.path.basename(f).encode())       # content-addressed: the same tree at another path is up to date
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
