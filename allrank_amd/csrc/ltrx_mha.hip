@@ -166,6 +166,14 @@ __device__ __forceinline__ float drop_scale(const DropCfg& d, uint32_t bh, int L
   return drop_keep_scale(d, ((uint64_t)bh * (uint64_t)L + (uint64_t)qrow) * (uint64_t)L + (uint64_t)key);
 }
 
+// Softmax arithmetic runs in the log2 domain: one v_exp_f32 per probability (exp2 of scores pre-multiplied by
+// log2(e)/sqrt(d_k)) instead of the 14-instruction expf expansion, and key padding enters as an additive -inf bias, so
+// masked and out-of-range entries fall out of exp2(-inf) = 0 without compare/select pairs.  The backward kernels recompute
+// P = exp2(s * log2e/sqrt(d_k) - lse * log2e) from the stored natural-log LSE (lse_out keeps its meaning).
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 template <int DKP>
 __device__ __forceinline__ void zero_acc(f32x16 (&o)[DKP / 32]) {
 #pragma unroll
@@ -202,7 +210,8 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
   load_fixed<DKP>(qfrag, qb, q0, L, dk, rs);
   f32x16 oacc[DKP / 32];
   zero_acc<DKP>(oacc);
-  float m = -INFINITY, l = 0.f;
+  float m = -INFINITY, l = 0.f;        // running max (log2 domain) and normaliser
+  const float sl2 = scale * kLog2e;
 
   const int nkt = (L + 31) / 32;
   TileRegs<DKP> kr, vr;
@@ -214,7 +223,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
     tile_sstore<DKP>(vtile, vr);
     if (threadIdx.x < 32) {
       const int key = kt * 32 + threadIdx.x;
-      kmask[threadIdx.x] = (key >= L || kpm[slate + key]) ? 1.f : 0.f;
+      kmask[threadIdx.x] = (key >= L || kpm[slate + key]) ? -INFINITY : 0.f;       // additive bias
     }
     __syncthreads();
     if (kt + 1 < nkt) {   // prefetch: in flight during this tile's MFMAs
@@ -225,17 +234,18 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
     float mt = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[r] = (kmask[rowmap(r, half)] != 0.f) ? -INFINITY : s[r] * scale;
+      s[r] = s[r] * sl2 + kmask[rowmap(r, half)];          // log2 domain
       mt = fmaxf(mt, s[r]);
     }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float mn = fmaxf(m, mt);
-    const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);   // mn == -inf implies m == -inf
+    const float mref = (mn == -INFINITY) ? 0.f : mn;             // all keys so far padded: keep the differences finite
+    const float alpha = fast_exp2(m - mref);                      // m == -inf -> 0
     float ps = 0.f;
     f32x16 p;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      p[r] = (s[r] == -INFINITY) ? 0.f : expf(s[r] - mn);
+      p[r] = fast_exp2(s[r] - mref);
       ps += p[r];
     }
     l = l * alpha + ps;                      // the softmax normaliser counts every key (dropout comes after softmax)
@@ -255,7 +265,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
   const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;   // a row whose keys are all padded: 0 (the reference yields NaN)
   store_rows<DKP>(o + slate * ors + (size_t)head * dk, q0, L, dk, ors, oacc, inv);
   const int qrow = q0 + (lane & 31);
-  if (half == 0 && qrow < L) lse[((size_t)b * h + head) * L + qrow] = (lt > 0.f) ? m + logf(lt) : 0.f;
+  if (half == 0 && qrow < L) lse[((size_t)b * h + head) * L + qrow] = (lt > 0.f) ? (m + log2f(lt)) * kLn2 : 0.f;   // natural log
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -282,7 +292,8 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
   load_fixed<DKP>(dofrag, dout + slate * ors + (size_t)head * dk, q0, L, dk, ors);
   const int qrow = q0 + (lane & 31);
   const size_t stat = ((size_t)b * h + head) * L + qrow;
-  const float lse_q = (qrow < L) ? lse[stat] : 0.f;
+  const float lse_q = (qrow < L) ? lse[stat] * kLog2e : 0.f;          // log2 domain
+  const float sl2 = scale * kLog2e;
   // delta_q = <dO_q, O_q> (rowsum(dP * P)); each half-wave holds half of the head dimension.  Published for the
   // dK/dV kernel, which is launched after this one on the same stream.
   float del_q = 0.f;
@@ -306,7 +317,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
     tile_sstore<DKP>(vtile, vr);
     if (threadIdx.x < 32) {
       const int key = kt * 32 + threadIdx.x;
-      kmask[threadIdx.x] = (key >= L || kpm[slate + key]) ? 1.f : 0.f;
+      kmask[threadIdx.x] = (key >= L || kpm[slate + key]) ? -INFINITY : 0.f;       // additive bias
     }
     __syncthreads();
     if (kt + 1 < nkt) {
@@ -318,7 +329,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
     f32x16 ds;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = (kmask[rowmap(r, half)] != 0.f) ? 0.f : expf(s[r] * scale - lse_q);
+      const float p = fast_exp2(s[r] * sl2 + kmask[rowmap(r, half)] - lse_q);
       const float dm = DROP ? drop_scale(drop, blockIdx.y, L, qrow, kt * 32 + rowmap(r, half)) : 1.0f;
       ds[r] = p * (dp[r] * dm - del_q) * scale;
     }
@@ -352,6 +363,8 @@ __global__ void __launch_bounds__(256, DROP ? 1 : 2) ltrx_mha_bwd_dkdv_kernel(
   load_fixed<DKP>(vfrag, v + slate * rs + (size_t)head * dk, k0, L, dk, rs);
   const int key = k0 + (lane & 31);
   const bool key_masked = (key >= L) || (kpm[slate + (key < L ? key : 0)] != 0);
+  const float kbias = key_masked ? -INFINITY : 0.f;
+  const float sl2 = scale * kLog2e;
   f32x16 dkacc[DKP / 32], dvacc[DKP / 32];
   zero_acc<DKP>(dkacc);
   zero_acc<DKP>(dvacc);
@@ -366,7 +379,7 @@ __global__ void __launch_bounds__(256, DROP ? 1 : 2) ltrx_mha_bwd_dkdv_kernel(
     tile_sstore<DKP>(dotile, dor);
     if (threadIdx.x < 32) {
       const int qrow = qt * 32 + threadIdx.x;
-      lse_t[threadIdx.x] = (qrow < L) ? lse[statb + qrow] : INFINITY;   // +inf -> P = exp(-inf) = 0 for rows >= L
+      lse_t[threadIdx.x] = (qrow < L) ? lse[statb + qrow] * kLog2e : INFINITY;   // +inf -> P = exp2(-inf) = 0 for rows >= L
       del_t[threadIdx.x] = (qrow < L) ? delta[statb + qrow] : 0.f;
     }
     __syncthreads();
@@ -377,7 +390,7 @@ __global__ void __launch_bounds__(256, DROP ? 1 : 2) ltrx_mha_bwd_dkdv_kernel(
     const f32x16 s = rows_x_fixed<DKP>(qtile, kfrag);     // S[q = row(r,half)][key = l&31]
     f32x16 p;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) p[r] = key_masked ? 0.f : expf(s[r] * scale - lse_t[rowmap(r, half)]);
+    for (int r = 0; r < 16; ++r) p[r] = fast_exp2(s[r] * sl2 + kbias - lse_t[rowmap(r, half)]);
     f32x16 dm;                                             // dropout keep-scale of (q, key), 1 when dropout is off
 #pragma unroll
     for (int r = 0; r < 16; ++r)
