@@ -120,6 +120,10 @@ __global__ void __launch_bounds__(512) gemm256(const float* __restrict__ A, int 
   };
 
   const int nk = K / BK;
+  if (VAR & 16384) {                       // static MFMA priority for the first wave of every SIMD
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) == 0) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
+  }
   gload(0);
   sstore(s[0]);
   if (nk > 1) gload(BK);
@@ -348,6 +352,8 @@ int main(int argc, char** argv) {
   RUN("peeled+raw+sched (mma,st,ld)", 96)
   RUN("peeled+raw+sched (st,ld,mma)", 97)
   RUN("ping-pong by wave>>2", 160)
+  RUN("static prio, nt stores", 32 + 2048 + 16384)
+  RUN("static prio, no epilogue", 32 + 8 + 16384)
   RUN("ping-pong 2-trip loop", 32 + 8192)
   RUN("ping-pong 2-trip loop, nt stores", 32 + 8192 + 2048)
   RUN("ping-pong 2-trip, no epilogue", 32 + 8192 + 8)
