@@ -206,7 +206,49 @@ __global__ void __launch_bounds__(512) gemm256(const float* __restrict__ A, int 
     for (; kt + 2 < nk; ++kt) {            // steady state: no branches in the body
       Smem& cur = s[kt & 1];
       Smem& nxt = s[(kt + 1) & 1];
-      if (VAR & 8192) {
+      if (VAR & 32768) {
+        // source-level interleave: 8 x { 6 MFMAs ; fence ; split + 2x2 ds_write of one staged float4 pair ; fence }
+        bf16x8 af[2][4], bfr[2][2];
+        auto frags = [&](int ks) {
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              bfr[tt][j] = *reinterpret_cast<const bf16x8*>(&cur.b[tt][swz_off(wc * 64 + j * 32 + l31, ks * 16 + 8 * half)]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              af[tt][i] = *reinterpret_cast<const bf16x8*>(&cur.a[tt][swz_off(wr * 128 + i * 32 + l31, ks * 16 + 8 * half)]);
+          }
+        };
+        auto store_one = [&](int p) {
+          bf16x4 h, l;
+          const int o = swz_off(srow + 64 * p, sc4);
+          split4(ra[p], h, l);
+          *reinterpret_cast<bf16x4*>(&nxt.a[0][o]) = h;
+          *reinterpret_cast<bf16x4*>(&nxt.a[1][o]) = l;
+          split4(rb[p], h, l);
+          *reinterpret_cast<bf16x4*>(&nxt.b[0][o]) = h;
+          *reinterpret_cast<bf16x4*>(&nxt.b[1][o]) = l;
+          ra[p] = *reinterpret_cast<const float4*>(Ap + (size_t)(64 * p) * lda + (kt + 2) * BK);
+          rb[p] = *reinterpret_cast<const float4*>(Bp + (size_t)(64 * p) * ldb + (kt + 2) * BK);
+        };
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          frags(ks);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {              // 4 chunks of 6 MFMAs: linear index m = 6c .. 6c+5 over (product, i, j)
+#pragma unroll
+            for (int m = 6 * c; m < 6 * c + 6; ++m) {
+              const int prod = m / 8, ij = m % 8, i = ij >> 1, j = ij & 1;
+              const int ta = prod == 1 ? 1 : 0, tb = prod == 0 ? 1 : 0;     // (0,1) (1,0) (0,0)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ta][i], bfr[tb][j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (c & 1) store_one(2 * ks + (c >> 1));  // 4 staged (A,B) float4 pairs per K-step: after chunks 1,3 of each ks
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else if (VAR & 8192) {
         // both wave groups run the same two blocks; `late` only selects which one comes first (2-trip loop, not unrolled)
 #pragma unroll 1
         for (int ph = 0; ph < 2; ++ph) {
@@ -352,6 +394,8 @@ int main(int argc, char** argv) {
   RUN("peeled+raw+sched (mma,st,ld)", 96)
   RUN("peeled+raw+sched (st,ld,mma)", 97)
   RUN("ping-pong by wave>>2", 160)
+  RUN("source interleave, nt stores", 32 + 2048 + 32768)
+  RUN("source interleave, no epilogue", 32 + 8 + 32768)
   RUN("static prio, nt stores", 32 + 2048 + 16384)
   RUN("static prio, no epilogue", 32 + 8 + 16384)
   RUN("ping-pong 2-trip loop", 32 + 8192)
@@ -385,7 +429,7 @@ int main(int argc, char** argv) {
   }
   for (int pass = 0; pass < 2 && only < 0; ++pass) {
     hipMemset(C, 0, (size_t)M * N * 4);
-    if (pass == 0) run<10272>(A, B, C, bias, M, N, K, 1); else run<33>(A, B, C, bias, M, N, K, 1);
+    if (pass == 0) run<34848>(A, B, C, bias, M, N, K, 1); else run<33>(A, B, C, bias, M, N, K, 1);
     std::vector<float> hc((size_t)256 * N);
     hipMemcpy(hc.data(), C + (size_t)(M - 256) * N, hc.size() * 4, hipMemcpyDeviceToHost);
     double maxerr = 0;
