@@ -229,18 +229,71 @@ __global__ void __launch_bounds__(256) ltrx_score_head_bwd_kernel(const float* _
   }
 }
 
+// vectorised variant for D % 256 == 0 (NV = D / 256): a lane owns float4 columns 4 * lane + 256 * t, keeps its dw partials in
+// registers over all the rows of its wave, 16-byte accesses; one LDS combine per workgroup at the end
+template <int NV>
+__global__ void __launch_bounds__(256) ltrx_score_head_bwd_vec_kernel(const float* __restrict__ ds, const float* __restrict__ x,
+                                                                      const float* __restrict__ w, int M,
+                                                                      float* __restrict__ dx, float* __restrict__ partial) {
+  constexpr int D = 256 * NV;
+  __shared__ float lds[4][D + 4];
+  const int lane = lane_id(), wv = wave_id(), wpb = blockDim.x >> 6;
+  float4 wreg[NV], acc[NV];
+#pragma unroll
+  for (int t = 0; t < NV; ++t) {
+    wreg[t] = reinterpret_cast<const float4*>(w)[lane + 64 * t];
+    acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float dbacc = 0.f;
+  for (int row = blockIdx.x * wpb + wv; row < M; row += gridDim.x * wpb) {
+    const float g = ds[row];
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * D);
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      const float4 xv = xr[lane + 64 * t];
+      dxr[lane + 64 * t] = make_float4(g * wreg[t].x, g * wreg[t].y, g * wreg[t].z, g * wreg[t].w);
+      acc[t].x += g * xv.x;
+      acc[t].y += g * xv.y;
+      acc[t].z += g * xv.z;
+      acc[t].w += g * xv.w;
+    }
+    dbacc += g;
+  }
+#pragma unroll
+  for (int t = 0; t < NV; ++t) *reinterpret_cast<float4*>(&lds[wv][4 * (lane + 64 * t)]) = acc[t];
+  if (lane == 0) lds[wv][D] = dbacc;
+  __syncthreads();
+  float* pa = partial + (size_t)blockIdx.x * (D + 1);
+  for (int c = threadIdx.x; c <= D; c += blockDim.x) pa[c] = (lds[0][c] + lds[1][c]) + (lds[2][c] + lds[3][c]);
+}
+
+// dw[c] = sum_k partial[k][c] (c < D), db = column D; 64 columns x 4 row groups per workgroup, fixed combine order
 __global__ void __launch_bounds__(256) ltrx_score_head_reduce_kernel(const float* __restrict__ partial, int nblk, int D,
                                                                      float* __restrict__ dw, float* __restrict__ db) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c > D) return;
-  float a = 0.f;
-  for (int k = 0; k < nblk; ++k) a += partial[(size_t)k * (D + 1) + c];
-  if (c < D) dw[c] = a; else db[0] = a;
+  __shared__ float sh[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float a0 = 0.f, a1 = 0.f;
+  if (c <= D) {
+    int k = rg;
+    for (; k + 4 < nblk; k += 8) {
+      a0 += partial[(size_t)k * (D + 1) + c];
+      a1 += partial[(size_t)(k + 4) * (D + 1) + c];
+    }
+    if (k < nblk) a0 += partial[(size_t)k * (D + 1) + c];
+  }
+  sh[rg][cl] = a0 + a1;
+  __syncthreads();
+  if (rg == 0 && c <= D) {
+    const float a = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+    if (c < D) dw[c] = a; else db[0] = a;
+  }
 }
 
 static int head_grid(int M) {
   int g = (M + 63) / 64;
-  return g > 128 ? 128 : (g < 1 ? 1 : g);
+  return g > 512 ? 512 : (g < 1 ? 1 : g);
 }
 
 extern "C" int ltrx_score_head_fwd(const float* x, const float* w, const float* b, int M, int D, float* scores,
@@ -264,10 +317,18 @@ extern "C" int ltrx_score_head_bwd(const float* dscores, const float* x, const f
   if ((size_t)(4 * D + 4) * sizeof(float) > 64 * 1024) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const int g = head_grid(M);
-  hipLaunchKernelGGL(ltrx_score_head_bwd_kernel, dim3(g), dim3(256), (size_t)(4 * D + 4) * sizeof(float), s, dscores, x, w, M,
-                     D, dx, (float*)ws);
+  const bool al16 = ((((uintptr_t)x) | ((uintptr_t)dx) | ((uintptr_t)w)) & 15) == 0;
+  if (D == 256 && al16)
+    hipLaunchKernelGGL(ltrx_score_head_bwd_vec_kernel<1>, dim3(g), dim3(256), 0, s, dscores, x, w, M, dx, (float*)ws);
+  else if (D == 512 && al16)
+    hipLaunchKernelGGL(ltrx_score_head_bwd_vec_kernel<2>, dim3(g), dim3(256), 0, s, dscores, x, w, M, dx, (float*)ws);
+  else if (D == 1024 && al16)
+    hipLaunchKernelGGL(ltrx_score_head_bwd_vec_kernel<4>, dim3(g), dim3(256), 0, s, dscores, x, w, M, dx, (float*)ws);
+  else
+    hipLaunchKernelGGL(ltrx_score_head_bwd_kernel, dim3(g), dim3(256), (size_t)(4 * D + 4) * sizeof(float), s, dscores, x, w, M,
+                       D, dx, (float*)ws);
   LTRX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ltrx_score_head_reduce_kernel, dim3((D + 1 + 255) / 256), dim3(256), 0, s, (const float*)ws, g, D, dw, db);
+  hipLaunchKernelGGL(ltrx_score_head_reduce_kernel, dim3((D + 1 + 63) / 64), dim3(256), 0, s, (const float*)ws, g, D, dw, db);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }

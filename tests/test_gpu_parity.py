@@ -993,3 +993,27 @@ def test_row4_losses_edge_shapes():
     s = rng.standard_normal((2, 2048)).astype(np.float32)
     y = rng.integers(0, 5, (2, 2048)).astype(np.float32)
     assert np.array_equal(EM.mrr(_t(s), _t(y), ats=[1, 10, 2048]).cpu().numpy(), O.mrr(s, y, [1, 10, 2048]))
+
+
+@pytest.mark.parametrize("D", [512, 256, 96])
+def test_score_head_kernels_match_torch(D):
+    """OutputLayer with d_output == 1 (model.py:111-117): forward scores and backward (dx, dw, db) of the explicit step's head
+    kernels (vectorised for D % 256 == 0, generic otherwise) against torch."""
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    rng = np.random.default_rng(D)
+    Mm = 3000
+    x = _t(rng.standard_normal((Mm, D)).astype(np.float32))
+    w = _t(rng.standard_normal((1, D)).astype(np.float32))
+    b = _t(rng.standard_normal(1).astype(np.float32))
+    ds = _t(rng.standard_normal(Mm).astype(np.float32))
+    sc = torch.empty(Mm, device=DEV)
+    LB.check(lib.ltrx_score_head_fwd(LB.ptr(x), LB.ptr(w), LB.ptr(b), Mm, D, LB.ptr(sc), None), "head_fwd")
+    ref = (x.double() @ w.double().t()).squeeze(1) + b.double()
+    assert float((sc.double() - ref).abs().max()) < 1e-4
+    dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(b)
+    ws = torch.empty(max(lib.ltrx_score_head_bwd_workspace_bytes(Mm, D), 64), dtype=torch.uint8, device=DEV)
+    LB.check(lib.ltrx_score_head_bwd(LB.ptr(ds), LB.ptr(x), LB.ptr(w), Mm, D, LB.ptr(dx), LB.ptr(dw), LB.ptr(db), LB.ptr(ws), None), "head_bwd")
+    assert torch.equal(dx, ds[:, None] * w)
+    assert float((dw.double() - ds.double()[None, :] @ x.double()).abs().max()) < 2e-3
+    assert abs(float(db.item()) - float(ds.double().sum())) < 1e-3
