@@ -53,6 +53,7 @@ SIGNATURES = {
     "ltrx_relu_bwd": (_i, [_vp, _vp, _sz, _f, _vp]),
     "ltrx_dropout_apply": (_i, [_vp, _vp, _sz, _f, ctypes.c_uint32, _vp, _vp]),
     "ltrx_bump_u32": (_i, [_vp, _vp]),
+    "ltrx_transpose_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ltrx_bias_act": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ltrx_score_head_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ltrx_score_head_bwd_workspace_bytes": (_sz, [_i, _i]),

@@ -363,3 +363,44 @@ extern "C" int ltrx_bump_u32(uint32_t* word, ltrx_stream_t stream) {
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batched transpose: every weight matrix the input-gradient GEMMs need in transposed (K-contiguous) form, refreshed after
+// the optimizer step by ONE launch.  desc[m] = {src offset, dst offset, rows, cols} in floats relative to the two base
+// pointers; tile_start[m] = first workgroup of matrix m (32 x 32 tiles, row-major), tile_start[n] = total.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ltrx_transpose_batch_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
+                                                                   const int64_t* __restrict__ desc,
+                                                                   const int32_t* __restrict__ tile_start, int n) {
+  __shared__ float tile[32][33];
+  int m = 0;
+  while (m + 1 < n && (int)blockIdx.x >= tile_start[m + 1]) ++m;
+  const int64_t so = desc[4 * m + 0], dof = desc[4 * m + 1];
+  const int rows = (int)desc[4 * m + 2], cols = (int)desc[4 * m + 3];
+  const int t = blockIdx.x - tile_start[m];
+  const int tiles_c = (cols + 31) / 32;
+  const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  const float* src = src_base + so;
+  float* dst = dst_base + dof;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 8 * k][tx] = src[(size_t)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;              // dst[c][r] = src[r][c]
+    if (r < rows && c < cols) dst[(size_t)c * rows + r] = tile[tx][ty + 8 * k];
+  }
+}
+
+extern "C" int ltrx_transpose_batch(const float* src_base, float* dst_base, const int64_t* desc, const int32_t* tile_start,
+                                    int n, int total_tiles, ltrx_stream_t stream) {
+  if (!src_base || !dst_base || !desc || !tile_start || n <= 0 || total_tiles <= 0) return LTRX_EINVAL;
+  hipLaunchKernelGGL(ltrx_transpose_batch_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, src_base, dst_base, desc,
+                     tile_start, n);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}

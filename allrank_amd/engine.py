@@ -238,16 +238,31 @@ class FusedTrainer(object):
             for (npp, kpp) in shapes:
                 nb = max(nb, self.lib.ltrx_gemm_tn_workspace_bytes(M, npp, kpp))
             self.ws_tn = torch.empty(max(nb, 64), dtype=torch.uint8, device=dev)
-            # transposed weight copies for the input-gradient GEMMs (refreshed after every optimizer step)
+            # transposed weight copies for the input-gradient GEMMs (refreshed after every optimizer step by ONE batched
+            # transpose launch): all copies live in one flat buffer, the descriptor table is built once
             tw = [l.weight for l in fc.layers[1:]]
+            srcs = [(self._pv[id(p)][0], p.shape[0], p.shape[1], ("w", id(p))) for p in tw]
             if enc is not None:
-                for st in self.layers:
+                for li, st in enumerate(self.layers):
                     lay = st["mod"]
-                    tw += [lay.self_attn.linears[3].weight, lay.feed_forward.w_1.weight, lay.feed_forward.w_2.weight]
-                    st["wqkvT"] = torch.zeros((d, 3 * d), **f32)
-            for p in tw:
-                self._wT[id(p)] = torch.zeros((p.shape[1], p.shape[0]), **f32)
-            self._tw = tw
+                    for p in (lay.self_attn.linears[3].weight, lay.feed_forward.w_1.weight, lay.feed_forward.w_2.weight):
+                        srcs.append((self._pv[id(p)][0], p.shape[0], p.shape[1], ("w", id(p))))
+                    srcs.append((self._pv[id(lay.self_attn.linears[0].weight)][0], 3 * d, d, ("qkv", li)))
+            tot = sum((r * c + 3) // 4 * 4 for _, r, c, _ in srcs)
+            self.flat_t = torch.zeros(max(tot, 4), **f32)
+            desc, tstart, o = [], [0], 0
+            for (so, r, c, key) in srcs:
+                view = self.flat_t[o:o + r * c].view(c, r)
+                if key[0] == "w":
+                    self._wT[key[1]] = view
+                else:
+                    self.layers[key[1]]["wqkvT"] = view
+                desc += [so, o, r, c]
+                tstart.append(tstart[-1] + ((r + 31) // 32) * ((c + 31) // 32))
+                o += (r * c + 3) // 4 * 4
+            self._tdesc = torch.tensor(desc if desc else [0, 0, 0, 0], dtype=torch.int64, device=dev)
+            self._tstart = torch.tensor(tstart, dtype=torch.int32, device=dev)
+            self._tn, self._ttiles = len(srcs), tstart[-1]
             self._refresh_transposes()
         self.loss = FusedLoss(loss_name, B, L, dev, **(loss_args or {}))
         self.use_graph = use_graph
@@ -309,10 +324,10 @@ class FusedTrainer(object):
     def _refresh_transposes(self):
         if self.gemm == "hipblaslt":
             return
-        for p in self._tw:
-            self._wT[id(p)].copy_(p.data.t())
-        for st in self.layers:
-            st["wqkvT"].copy_(st["wqkv"].t())
+        if self._tn:
+            P = self.LB.ptr
+            self.LB.check(self.lib.ltrx_transpose_batch(P(self.flat_p), P(self.flat_t), P(self._tdesc), P(self._tstart), self._tn,
+                                                        self._ttiles, self._st()), "transpose_batch")
 
     def _bucket_done(self, k):
         """gradient bucket k is final: start its all-reduce(SUM) now, behind the rest of the backward (the collective runs

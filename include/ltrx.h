@@ -225,6 +225,12 @@ int ltrx_dropout_apply(const float* src, float* dst, size_t n, float p, uint32_t
                        ltrx_stream_t stream);
 int ltrx_bump_u32(uint32_t* word, ltrx_stream_t stream);
 
+/* all transposed weight copies of the explicit step in one launch: matrix m = rows x cols floats at src_base + desc[4m],
+ * written transposed (cols x rows) at dst_base + desc[4m+1]; desc[4m+2..3] = rows, cols; tile_start[n+1] = prefix sums of
+ * ceil(rows/32)*ceil(cols/32) (all arrays in DEVICE memory except the scalars). */
+int ltrx_transpose_batch(const float* src_base, float* dst_base, const int64_t* desc, const int32_t* tile_start, int n,
+                         int total_tiles, ltrx_stream_t stream);
+
 /* y = act(y + bias) in place over a contiguous [M,N] matrix (model.py:42-43); act 0 = identity, 1 = ReLU; N % 4 == 0. */
 int ltrx_bias_act(float* y_inout, const float* bias, int M, int N, int act, ltrx_stream_t stream);
 
