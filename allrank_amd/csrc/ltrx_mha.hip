@@ -158,12 +158,24 @@ __device__ __forceinline__ void store_rows(float* __restrict__ base, int row0, i
   }
 }
 
-// Dropout on the attention probabilities (transformer.py:154-155): the counter-based generator of ltrx_device.h keyed by
-// the element index ((slate*head) * L + query) * L + key: forward and both backward kernels regenerate the same mask.
+// Dropout on the attention probabilities (transformer.py:154-155): counter-based, two-level -- a fully mixed 32-bit seed
+// per (slate*head, query) row and a short 2-multiply mix per key, so the per-element cost is ~8 VALU operations with 32-bit
+// arithmetic only.  The forward and both backward kernels regenerate the same mask from (seed, row, key).
 typedef DropSpec DropCfg;
-__device__ __forceinline__ float drop_scale(const DropCfg& d, uint32_t bh, int L, int qrow, int key) {
-  if (d.thresh == 0u) return 1.0f;
-  return drop_keep_scale(d, ((uint64_t)bh * (uint64_t)L + (uint64_t)qrow) * (uint64_t)L + (uint64_t)key);
+__device__ __forceinline__ uint32_t drop_row_seed(const DropCfg& d, uint32_t bh, int L, int qrow) {
+  uint32_t x = d.seed ^ ((bh * (uint32_t)L + (uint32_t)qrow) * 0x9E3779B9u);
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float drop_scale_rk(const DropCfg& d, uint32_t row_seed, int key) {
+  uint32_t x = (row_seed ^ (uint32_t)key) * 0x9E3779B1u;
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  return ((x >> 8) >= d.thresh) ? d.inv_keep : 0.f;
 }
 
 // Softmax arithmetic runs in the log2 domain: one v_exp_f32 per probability (exp2 of scores pre-multiplied by
@@ -211,6 +223,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
   f32x16 oacc[DKP / 32];
   zero_acc<DKP>(oacc);
   float m = -INFINITY, l = 0.f;        // running max (log2 domain) and normaliser
+  const uint32_t drow = DROP ? drop_row_seed(drop, blockIdx.y, L, q0 + (lane & 31)) : 0u;
   const float sl2 = scale * kLog2e;
 
   const int nkt = (L + 31) / 32;
@@ -250,9 +263,8 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
     }
     l = l * alpha + ps;                      // the softmax normaliser counts every key (dropout comes after softmax)
     if (DROP) {
-      const int qd = q0 + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) p[r] *= drop_scale(drop, blockIdx.y, L, qd, kt * 32 + rowmap(r, half));
+      for (int r = 0; r < 16; ++r) p[r] *= drop_scale_rk(drop, drow, kt * 32 + rowmap(r, half));
     }
 #pragma unroll
     for (int ct = 0; ct < DKP / 32; ++ct)
@@ -293,6 +305,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
   const int qrow = q0 + (lane & 31);
   const size_t stat = ((size_t)b * h + head) * L + qrow;
   const float lse_q = (qrow < L) ? lse[stat] * kLog2e : 0.f;          // log2 domain
+  const uint32_t drow = DROP ? drop_row_seed(drop, blockIdx.y, L, qrow) : 0u;
   const float sl2 = scale * kLog2e;
   // delta_q = <dO_q, O_q> (rowsum(dP * P)); each half-wave holds half of the head dimension.  Published for the
   // dK/dV kernel, which is launched after this one on the same stream.
@@ -330,7 +343,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float p = fast_exp2(s[r] * sl2 + kmask[rowmap(r, half)] - lse_q);
-      const float dm = DROP ? drop_scale(drop, blockIdx.y, L, qrow, kt * 32 + rowmap(r, half)) : 1.0f;
+      const float dm = DROP ? drop_scale_rk(drop, drow, kt * 32 + rowmap(r, half)) : 1.0f;
       ds[r] = p * (dp[r] * dm - del_q) * scale;
     }
     cols_x_p<DKP>(ktile, ds, dqacc);
@@ -342,7 +355,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dq_kernel(
 // backward: dK, dV   (wave owns 32 keys, streams query tiles)
 // ------------------------------------------------------------------------------------------------------------------
 template <int DKP, bool DROP>
-__global__ void __launch_bounds__(256, DROP ? 1 : 2) ltrx_mha_bwd_dkdv_kernel(
+__global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dkdv_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ kpm, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, int L, int h, int dk, int rs, int ors, float* __restrict__ dkout,
@@ -352,6 +365,7 @@ __global__ void __launch_bounds__(256, DROP ? 1 : 2) ltrx_mha_bwd_dkdv_kernel(
   __shared__ __attribute__((aligned(16))) float dotile[Tile<DKP>::FLOATS];
   __shared__ float lse_t[32];
   __shared__ float del_t[32];
+  __shared__ uint32_t drow_t[32];
   const int b = blockIdx.y / h, head = blockIdx.y % h;
   const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
   const int k0 = blockIdx.x * 128 + wave * 32;
@@ -381,6 +395,7 @@ __global__ void __launch_bounds__(256, DROP ? 1 : 2) ltrx_mha_bwd_dkdv_kernel(
       const int qrow = qt * 32 + threadIdx.x;
       lse_t[threadIdx.x] = (qrow < L) ? lse[statb + qrow] * kLog2e : INFINITY;   // +inf -> P = exp2(-inf) = 0 for rows >= L
       del_t[threadIdx.x] = (qrow < L) ? delta[statb + qrow] : 0.f;
+      if (DROP) drow_t[threadIdx.x] = drop_row_seed(drop, blockIdx.y, L, qrow);
     }
     __syncthreads();
     if (qt + 1 < nqt) {
@@ -394,7 +409,7 @@ __global__ void __launch_bounds__(256, DROP ? 1 : 2) ltrx_mha_bwd_dkdv_kernel(
     f32x16 dm;                                             // dropout keep-scale of (q, key), 1 when dropout is off
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      dm[r] = DROP ? drop_scale(drop, blockIdx.y, L, qt * 32 + rowmap(r, half), key) : 1.0f;
+      dm[r] = DROP ? drop_scale_rk(drop, drow_t[rowmap(r, half)], key) : 1.0f;
     {
       f32x16 pd;
 #pragma unroll
