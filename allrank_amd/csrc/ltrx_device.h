@@ -28,21 +28,39 @@ namespace ltrx {
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
-// ---- wave (64-lane) reductions by butterfly shuffles: every lane ends with the full result ----
+// ---- wave (64-lane) reductions on the DPP cross-lane network: four in-row steps (quad_perm x2, row_half_mirror,
+// row_mirror: every lane of a 16-lane row holds the row total), two row broadcasts (row_bcast15 into rows 1 and 3,
+// row_bcast31 into rows 2 and 3: lane 63 holds the wave total) and one v_readlane -- 7 VALU-rate instructions instead of
+// six dependent ds_bpermute round trips through the LDS crossbar.  Every lane gets the result; the order is fixed.
+#define LTRX_DPP_I(old, src, ctrl, rowmask, bound) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rowmask), 0xF, (bound))
+#define LTRX_DPP_F(old, src, ctrl, rowmask, bound) \
+  __builtin_bit_cast(float, LTRX_DPP_I(__builtin_bit_cast(int, (old)), __builtin_bit_cast(int, (src)), (ctrl), (rowmask), (bound)))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += LTRX_DPP_F(0.f, v, 0xB1, 0xF, true);     // quad_perm [1,0,3,2]
+  v += LTRX_DPP_F(0.f, v, 0x4E, 0xF, true);     // quad_perm [2,3,0,1]
+  v += LTRX_DPP_F(0.f, v, 0x141, 0xF, true);    // row_half_mirror
+  v += LTRX_DPP_F(0.f, v, 0x140, 0xF, true);    // row_mirror
+  v += LTRX_DPP_F(0.f, v, 0x142, 0xA, false);   // row_bcast15 -> rows 1, 3
+  v += LTRX_DPP_F(0.f, v, 0x143, 0xC, false);   // row_bcast31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, LTRX_DPP_F(v, v, 0xB1, 0xF, false));
+  v = fmaxf(v, LTRX_DPP_F(v, v, 0x4E, 0xF, false));
+  v = fmaxf(v, LTRX_DPP_F(v, v, 0x141, 0xF, false));
+  v = fmaxf(v, LTRX_DPP_F(v, v, 0x140, 0xF, false));
+  v = fmaxf(v, LTRX_DPP_F(v, v, 0x142, 0xA, false));
+  v = fmaxf(v, LTRX_DPP_F(v, v, 0x143, 0xC, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += LTRX_DPP_I(0, v, 0xB1, 0xF, true);
+  v += LTRX_DPP_I(0, v, 0x4E, 0xF, true);
+  v += LTRX_DPP_I(0, v, 0x141, 0xF, true);
+  v += LTRX_DPP_I(0, v, 0x140, 0xF, true);
+  v += LTRX_DPP_I(0, v, 0x142, 0xA, false);
+  v += LTRX_DPP_I(0, v, 0x143, 0xC, false);
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 // ---- workgroup reductions: wave partials through LDS, summed in a fixed order (deterministic). ----
