@@ -20,7 +20,9 @@ __global__ void ltrx_bump_step_kernel(float* __restrict__ step) { step[0] += 1.0
 __global__ void __launch_bounds__(256) ltrx_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, size_t n,
                                                         float lr, float b1, float b2, float eps,
-                                                        const float* __restrict__ step, float grad_scale) {
+                                                        const float* __restrict__ step, float grad_scale,
+                                                        const float* __restrict__ grad_scale_dev) {
+  if (grad_scale_dev) grad_scale *= grad_scale_dev[0];
   const float t = step[0];
   const float bc1 = 1.0f - powf(b1, t);
   const float bc2s = sqrtf(1.0f - powf(b2, t));
@@ -58,7 +60,7 @@ __global__ void __launch_bounds__(256) ltrx_adam_kernel(float* __restrict__ p, c
 
 extern "C" int ltrx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
                               float beta1, float beta2, float eps, float* step_count, float grad_scale,
-                              ltrx_stream_t stream) {
+                              const float* grad_scale_dev, ltrx_stream_t stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !step_count || n == 0) return LTRX_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(ltrx_bump_step_kernel, dim3(1), dim3(1), 0, s, step_count);
@@ -67,7 +69,7 @@ extern "C" int ltrx_adam_step(float* params, const float* grads, float* exp_avg,
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(ltrx_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n, lr,
-                     beta1, beta2, eps, step_count, grad_scale);
+                     beta1, beta2, eps, step_count, grad_scale, grad_scale_dev);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }
@@ -401,6 +403,51 @@ extern "C" int ltrx_transpose_batch(const float* src_base, float* dst_base, cons
   if (!src_base || !dst_base || !desc || !tile_start || n <= 0 || total_tiles <= 0) return LTRX_EINVAL;
   hipLaunchKernelGGL(ltrx_transpose_batch_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, src_base, dst_base, desc,
                      tile_start, n);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gradient clipping (torch.nn.utils.clip_grad_norm_, train_utils.py:24-25) for the flat gradient buffer:
+// scale_out[0] = min(1, max_norm / (||g||_2 + 1e-6)); the Adam kernel multiplies the gradients by it on the fly.
+// Two-stage deterministic sum of squares (grid-stride partials, then one block).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ltrx_sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partial) {
+  __shared__ float red[LTRX_MAX_WAVES];
+  float acc = 0.f;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += g[i] * g[i];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+__global__ void __launch_bounds__(256) ltrx_clip_scale_kernel(const float* __restrict__ partial, int nb, float max_norm,
+                                                              float* __restrict__ scale_out, float* __restrict__ norm_out) {
+  __shared__ float red[LTRX_MAX_WAVES];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += partial[i];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    const float norm = sqrtf(acc);
+    const float c = max_norm / (norm + 1e-6f);            // clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6)
+    scale_out[0] = c < 1.0f ? c : 1.0f;
+    if (norm_out) norm_out[0] = norm;
+  }
+}
+
+extern "C" size_t ltrx_clip_workspace_bytes(size_t n) {
+  (void)n;
+  return 1024 * sizeof(float);
+}
+
+extern "C" int ltrx_clip_grad_norm_scale(const float* grads, size_t n, float max_norm, float* scale_out, float* norm_out, void* ws,
+                                         ltrx_stream_t stream) {
+  if (!grads || !scale_out || !ws || n == 0 || !(max_norm > 0.f)) return LTRX_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  size_t nb = (n + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(ltrx_sumsq_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, grads, n, (float*)ws);
+  LTRX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ltrx_clip_scale_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, (int)nb, max_norm, scale_out, norm_out);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }

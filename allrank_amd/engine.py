@@ -73,10 +73,11 @@ class FusedTrainer(object):
     """
 
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
-                 use_graph=True, gemm="split_bf16", dropout=True, seed=None):
+                 use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None):
         """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
         products), or "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs).  dropout=False trains with every
-        nn.Dropout of the model disabled; seed keys the dropout masks (default: drawn from torch's global generator)."""
+        nn.Dropout of the model disabled; seed keys the dropout masks (default: drawn from torch's global generator);
+        gradient_clipping_norm: clip_grad_norm_ of train_utils.py:24-25 (the coefficient stays on the device)."""
         import torch.nn as nn
         from . import _lib as LB
         from .losses import FusedLoss
@@ -149,6 +150,10 @@ class FusedTrainer(object):
         self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.clip = float(gradient_clipping_norm) if gradient_clipping_norm else None
+        self.clip_scale = torch.ones(1, dtype=torch.float32, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.ws_clip = torch.empty(max(self.lib.ltrx_clip_workspace_bytes(n), 64), dtype=torch.uint8, device=dev)
         self.drop_step = torch.zeros(1, dtype=torch.int32, device=dev)       # u32 word folded into every dropout seed
         # gradient buckets for the multi-GPU all-reduce, in the order the backward completes them: the tail of the flat
         # buffer (last encoder layer + final norm + head) first, then one bucket per earlier layer, the FC stack last
@@ -488,9 +493,13 @@ class FusedTrainer(object):
 
     def _adam(self):
         P = self.LB.ptr
+        if self.clip:
+            self.LB.check(self.lib.ltrx_clip_grad_norm_scale(P(self.flat_g), self.nflat, self.clip, P(self.clip_scale),
+                                                             P(self.grad_norm), P(self.ws_clip), self._st()), "clip_grad_norm")
         self.LB.check(self.lib.ltrx_adam_step(P(self.flat_p), P(self.flat_g), P(self.flat_m), P(self.flat_v), self.nflat,
                                               float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                              P(self.step_count), 1.0, self._st()), "adam_step")
+                                              P(self.step_count), 1.0, P(self.clip_scale) if self.clip else None, self._st()),
+                      "adam_step")
 
     def _full(self):
         self.LB.check(self.lib.ltrx_bump_u32(self.LB.ptr(self.drop_step), self._st()), "bump_u32")   # fresh masks every step

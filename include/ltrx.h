@@ -208,9 +208,16 @@ int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* 
 
 /* torch.optim.Adam.step (allrank/main.py:82, Adam in every shipped config) over one flat fp32 buffer of n elements;
  * step_count[1] (device, float) is incremented first and used for the bias corrections; grads are multiplied by
- * grad_scale on the fly (1.0 normally). */
+ * grad_scale (1.0 normally) and, when given, by grad_scale_dev[0] (device; the clipping coefficient) on the fly. */
 int ltrx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
-                   float beta2, float eps, float* step_count, float grad_scale, ltrx_stream_t stream);
+                   float beta2, float eps, float* step_count, float grad_scale, const float* grad_scale_dev,
+                   ltrx_stream_t stream);
+
+/* torch.nn.utils.clip_grad_norm_ (allrank/training/train_utils.py:24-25) over the flat gradient buffer:
+ * scale_out[0] = min(1, max_norm / (||grads||_2 + 1e-6)), norm_out[0] (optional) = the norm; deterministic two-stage sum. */
+size_t ltrx_clip_workspace_bytes(size_t n);
+int ltrx_clip_grad_norm_scale(const float* grads, size_t n, float max_norm, float* scale_out, float* norm_out, void* ws,
+                              ltrx_stream_t stream);
 
 /* nn.Linear bias gradient: out[n] (+)= sum_m a[m*ld + n] for a row-major [M,N] matrix; deterministic two-stage. */
 size_t ltrx_colsum_workspace_bytes(int M, int N);

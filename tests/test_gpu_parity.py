@@ -1017,3 +1017,28 @@ def test_score_head_kernels_match_torch(D):
     assert torch.equal(dx, ds[:, None] * w)
     assert float((dw.double() - ds.double()[None, :] @ x.double()).abs().max()) < 2e-3
     assert abs(float(db.item()) - float(ds.double().sum())) < 1e-3
+
+
+def test_fused_trainer_gradient_clipping_matches_clip_grad_norm():
+    """train_utils.py:24-25: clip_grad_norm_ before the optimizer step -- the explicit step keeps the coefficient on the
+    device (graph-capturable) and must follow the autograd path step for step."""
+    import copy
+    from allrank_amd import losses as E
+    from allrank_amd.engine import FusedTrainer, Trainer
+    torch.manual_seed(11)
+    m1 = _dropout_model(0.0, None, 0.0, N=1)
+    m2 = copy.deepcopy(m1)
+    rng = np.random.default_rng(12)
+    B, L = 6, 30
+    x = _t(rng.standard_normal((B, L, 20)).astype(np.float32))
+    y = _t(rng.integers(0, 5, (B, L)).astype(np.float32))
+    clip = 0.05
+    ft = FusedTrainer(m1, "listNet", {}, B, L, lr=1e-3, use_graph=True, gemm="split_bf16_strict", gradient_clipping_norm=clip)
+    tr = Trainer(m2, E.listNet, torch.optim.Adam(m2.parameters(), lr=1e-3), gradient_clipping_norm=clip)
+    for step in range(5):
+        lf, la = float(ft.step(x, y).item()), float(tr.step(x, y, None).item())
+        assert abs(lf - la) <= (2e-5 if step == 0 else 1e-3) * (1 + abs(la)), (step, lf, la)
+    assert float(ft.grad_norm.item()) > clip and float(ft.clip_scale.item()) < 1.0       # the clip was active
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        assert float((sd1[k] - sd2[k]).abs().max().item()) <= 1.01e-2, k
