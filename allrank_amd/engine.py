@@ -511,6 +511,13 @@ class FusedTrainer(object):
         self._refresh_transposes()
         return loss
 
+    def set_lr(self, lr):
+        """change the learning rate (per-epoch scheduler step): the rate is a launch argument of the Adam kernel, so a
+        captured graph is dropped and re-captured on the next step"""
+        if float(lr) != float(self.lr):
+            self.lr = float(lr)
+            self.graph = None
+
     def step(self, xb, yb, indices=None, global_batch=None):
         """copy the batch into the static input buffers and run (or replay) the step; returns the device loss [1]."""
         self._divisor = float(global_batch if global_batch is not None else self.B * self.world)
@@ -543,29 +550,40 @@ class _null(object):
 # epoch loop on device-resident data  (the body of fit(), allrank/training/train_utils.py:78-147, without its host work)
 # ------------------------------------------------------------------------------------------------------------------
 def fit_device(model, loss_name, loss_args, train_ds, val_ds, epochs, batch_size, slate_length, metrics=None, lr=1e-3,
-               val_metric=None, early_stopping_patience=None, generator=None, use_fused=True, log=None):
+               val_metric=None, early_stopping_patience=None, generator=None, use_fused=True, log=None,
+               gradient_clipping_norm=None, lr_schedule=None):
     """Train ``model`` on a DeviceSlates dataset; returns {"epochs", "train_loss", "val_metrics", "history"}.
 
     Per epoch: shuffled batches produced on the device (DeviceSlates.batches), one training step each (FusedTrainer when
     the model family / dropout allow it, else the autograd Trainer), the running loss is accumulated ON THE DEVICE (one
     host sync per epoch instead of the reference's ``loss.item()`` per step, train_utils.py:29), then one no-grad
     metrics pass over the validation set (train_utils.py:101-107).  The reference's second full pass over the TRAIN set
-    for train metrics (train_utils.py:99, dropout active) is not reproduced."""
+    for train metrics (train_utils.py:99, dropout active) is not reproduced.
+    ``gradient_clipping_norm``: train_utils.py:24-25; ``lr_schedule(epoch) -> lr`` plays the role of the per-epoch
+    ``scheduler.step()`` (train_utils.py:117-118), e.g. ``lambda e: 1e-3 * 0.1 ** (e // 50)`` for StepLR(50, 0.1)."""
     from . import losses as E
     from .data import evaluate
     metrics = metrics or {"ndcg": [5]}
     trainer, fused = None, False
     if use_fused:
         try:
-            trainer = FusedTrainer(model, loss_name, loss_args, batch_size, slate_length, lr=lr, use_graph=True)
+            trainer = FusedTrainer(model, loss_name, loss_args, batch_size, slate_length, lr=lr, use_graph=True,
+                                   gradient_clipping_norm=gradient_clipping_norm)
             fused = True
         except NotImplementedError:
             trainer = None
     if trainer is None:
         lossfn = (lambda s, t: getattr(E, loss_name)(s, t, **(loss_args or {})))
-        trainer = Trainer(model, lossfn, torch.optim.Adam(model.parameters(), lr=lr))
+        trainer = Trainer(model, lossfn, torch.optim.Adam(model.parameters(), lr=lr), gradient_clipping_norm)
     history, best, best_epoch = [], -1.0, 0
     for epoch in range(epochs):
+        if lr_schedule is not None:
+            new_lr = float(lr_schedule(epoch))
+            if fused:
+                trainer.set_lr(new_lr)
+            else:
+                for g_ in trainer.opt.param_groups:
+                    g_["lr"] = new_lr
         model.train()
         tot = torch.zeros(1, device=train_ds.device)
         nb = 0

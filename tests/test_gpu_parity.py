@@ -588,7 +588,7 @@ def test_end_to_end_training_on_device_resident_libsvm_data(tmp_path):
     before = evaluate(model, vali, {"ndcg": [5]})["ndcg_5"]
     g = torch.Generator(device=DEV).manual_seed(0)
     res = fit_device(model, "approxNDCGLoss", {}, train, vali, epochs=6, batch_size=32, slate_length=24, metrics={"ndcg": [5, 10]},
-                     lr=2e-3, generator=g)
+                     lr=2e-3, generator=g, gradient_clipping_norm=5.0, lr_schedule=lambda e: 2e-3 * (0.5 ** (e // 4)))
     after = res["val_metrics"]["ndcg_5"]
     _log("fit_device", dict(before=before, after=after, history=res["history"], fused=res["fused"]))
     assert res["fused"] and np.isfinite(after) and after > before + 0.03, (before, res["history"])
