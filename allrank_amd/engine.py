@@ -558,10 +558,13 @@ def fit_device(model, loss_name, loss_args, train_ds, val_ds, epochs, batch_size
     the model family / dropout allow it, else the autograd Trainer), the running loss is accumulated ON THE DEVICE (one
     host sync per epoch instead of the reference's ``loss.item()`` per step, train_utils.py:29), then one no-grad
     metrics pass over the validation set (train_utils.py:101-107).  The reference's second full pass over the TRAIN set
-    for train metrics (train_utils.py:99, dropout active) is not reproduced.
+    for train metrics (train_utils.py:99, in train() mode, i.e. dropout active) is replaced by metrics taken from the
+    scores of the TRAINING forward itself (same mode, no extra model pass): ``train_<metric>_<k>`` in
+    the history is the mean over the epoch's training batches, each evaluated with the weights it was scored with.
     ``gradient_clipping_norm``: train_utils.py:24-25; ``lr_schedule(epoch) -> lr`` plays the role of the per-epoch
     ``scheduler.step()`` (train_utils.py:117-118), e.g. ``lambda e: 1e-3 * 0.1 ** (e // 50)`` for StepLR(50, 0.1)."""
     from . import losses as E
+    from . import metrics as EMx
     from .data import evaluate
     metrics = metrics or {"ndcg": [5]}
     trainer, fused = None, False
@@ -587,13 +590,22 @@ def fit_device(model, loss_name, loss_args, train_ds, val_ds, epochs, batch_size
         model.train()
         tot = torch.zeros(1, device=train_ds.device)
         nb = 0
+        tm = {name: None for name in metrics} if fused else {}
         for xb, yb, idx in train_ds.batches(batch_size, slate_length, shuffle=True, generator=generator, drop_last=fused):
             loss = trainer.step(xb, yb, idx)
             tot += loss.detach().view(1) * xb.shape[0]
             nb += xb.shape[0]
+            for name in tm:                                   # metrics of the training forward (scores of this very step)
+                v = getattr(EMx, name)(trainer.scores, trainer.y_in, ats=metrics[name]).sum(0)
+                tm[name] = v if tm[name] is None else tm[name] + v
         train_loss = float(tot.item()) / max(nb, 1)
         val = evaluate(model, val_ds, metrics)
-        history.append(dict(epoch=epoch, train_loss=train_loss, **val))
+        rec = dict(epoch=epoch, train_loss=train_loss, **val)
+        for name, v in tm.items():
+            if v is not None:
+                for at, x_ in zip(metrics[name], (v / max(nb, 1)).cpu().numpy()):
+                    rec["train_%s_%d" % (name, at)] = float(x_)
+        history.append(rec)
         if log:
             log(history[-1])
         if val_metric is not None and early_stopping_patience is not None:
@@ -603,5 +615,6 @@ def fit_device(model, loss_name, loss_args, train_ds, val_ds, epochs, batch_size
             if epoch - best_epoch > early_stopping_patience:       # early_stop.py:17-19
                 break
     return dict(epochs=epoch, train_loss=history[-1]["train_loss"], val_metrics={k: v for k, v in history[-1].items()
-                                                                                 if k not in ("epoch", "train_loss")},
+                                                                                 if k not in ("epoch", "train_loss")
+                                                                                 and not k.startswith("train_")},
                 history=history, fused=fused)

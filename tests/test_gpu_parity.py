@@ -592,6 +592,8 @@ def test_end_to_end_training_on_device_resident_libsvm_data(tmp_path):
     after = res["val_metrics"]["ndcg_5"]
     _log("fit_device", dict(before=before, after=after, history=res["history"], fused=res["fused"]))
     assert res["fused"] and np.isfinite(after) and after > before + 0.03, (before, res["history"])
+    h = res["history"]
+    assert "train_ndcg_5" in h[-1] and 0.0 < h[-1]["train_ndcg_5"] <= 1.0 and h[-1]["train_ndcg_5"] > h[0]["train_ndcg_5"]
 
 
 # ------------------------------------------------------------------------------------------------------------------
