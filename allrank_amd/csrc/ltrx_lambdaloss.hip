@@ -63,7 +63,9 @@ __device__ __forceinline__ void pair_terms(const PairCtx& c, float w, float sig,
 
 }  // namespace
 
-__global__ void __launch_bounds__(256) ltrx_lambdaloss_kernel(const float* __restrict__ y_pred,
+// 1024 threads per slate: thread (i, q) = (tid & 255 [+256 ...], tid >> 8) owns item i and a quarter of the partner range j;
+// the four partial sums per item are combined through LDS (16 waves per CU instead of 4 hide the exp/log latency).
+__global__ void __launch_bounds__(1024) ltrx_lambdaloss_kernel(const float* __restrict__ y_pred,
                                                               const float* __restrict__ y_true, int L, float eps,
                                                               float pad, int scheme, int k, float sigma, float mu,
                                                               int logbase, float* __restrict__ per_loss,
@@ -75,6 +77,8 @@ __global__ void __launch_bounds__(256) ltrx_lambdaloss_kernel(const float* __res
   float* Gs = lds + 2 * L;            // [L] gains / maxDCG
   int* rk = (int*)(lds + 3 * L);      // [L] rank by score (valid items; padded get L)
   float* invD = lds + 4 * L;          // [L+2]
+  float* part = lds + 5 * L + 2;      // [4][L] float partials
+  int* parti = (int*)(lds + 9 * L + 2);   // [4][L] int partials (score-rank and label-rank counts packed: rs | ry << 16)
   __shared__ float red[LTRX_MAX_WAVES];
   __shared__ int redi[LTRX_MAX_WAVES];
   const int b = blockIdx.x;
@@ -91,26 +95,38 @@ __global__ void __launch_bounds__(256) ltrx_lambdaloss_kernel(const float* __res
   nv = block_sum_i(nv, redi);         // barriers publish ss/ys/invD
   const int kk = (k <= 0 || k > L) ? L : k;
 
+  const int q = threadIdx.x >> 8, i0 = threadIdx.x & 255;
+  const int lq = (L + 3) >> 2;
+  const int j0 = q * lq, j1 = min(L, j0 + lq);
   // ---- ranks by score, ideal DCG@k by label rank ----
-  float dsum = 0.f;
-  for (int i = threadIdx.x; i < L; i += blockDim.x) {
-    const float yi = ys[i];
-    if (yi == pad) {
-      rk[i] = L;
-      continue;
-    }
-    const float si = ss[i];
+  for (int i = i0; i < L; i += 256) {
+    const float yi = ys[i], si = ss[i];
     int rs = 0, ry = 0;
-    for (int j = 0; j < L; ++j) {
-      const float yj = ys[j];
-      if (yj == pad) continue;
-      const float sj = ss[j];
-      rs += (sj > si) || (sj == si && j < i);
-      ry += (yj > yi) || (yj == yi && j < i);
-    }
-    rk[i] = rs;
-    if (ry < kk) dsum += (exp2f(fmaxf(yi, 0.f)) - 1.0f) * invD[ry + 1];     // lambdaLoss.py:54
+    if (yi != pad)
+      for (int j = j0; j < j1; ++j) {
+        const float yj = ys[j];
+        if (yj == pad) continue;
+        const float sj = ss[j];
+        rs += (sj > si) || (sj == si && j < i);
+        ry += (yj > yi) || (yj == yi && j < i);
+      }
+    parti[q * L + i] = rs | (ry << 16);            // L <= 2048: both counts fit 16 bits
   }
+  __syncthreads();
+  float dsum = 0.f;
+  if (q == 0)
+    for (int i = i0; i < L; i += 256) {
+      const float yi = ys[i];
+      if (yi == pad) {
+        rk[i] = L;
+        continue;
+      }
+      const int a0 = parti[i], a1 = parti[L + i], a2 = parti[2 * L + i], a3 = parti[3 * L + i];
+      const int rs = (a0 & 0xFFFF) + (a1 & 0xFFFF) + (a2 & 0xFFFF) + (a3 & 0xFFFF);
+      const int ry = (a0 >> 16) + (a1 >> 16) + (a2 >> 16) + (a3 >> 16);
+      rk[i] = rs;
+      if (ry < kk) dsum += (exp2f(fmaxf(yi, 0.f)) - 1.0f) * invD[ry + 1];     // lambdaLoss.py:54
+    }
   const float maxdcg = fmaxf(block_sum(dsum, red), eps);
   for (int i = threadIdx.x; i < L; i += blockDim.x) Gs[i] = (ys[i] == pad) ? 0.f : (exp2f(fmaxf(ys[i], 0.f)) - 1.0f) / maxdcg;
   __syncthreads();
@@ -139,40 +155,41 @@ __global__ void __launch_bounds__(256) ltrx_lambdaloss_kernel(const float* __res
 
   float lsum = 0.f, csum = 0.f;
   float* gp = grad ? grad + (size_t)b * L : nullptr;
-  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+  for (int i = i0; i < L; i += 256) {
     const float yi = ys[i];
     const int ri = rk[i];
-    if (yi == pad || ri >= kk) {
-      if (gp) gp[i] = 0.f;
-      continue;
-    }
-    const float si = ss[i], Gi = Gs[i], yci = fmaxf(yi, 0.f);
     float gacc = 0.f;
-    for (int j = 0; j < L; ++j) {
-      const float yj = ys[j];
-      const int rj = rk[j];
-      if (yj == pad || rj >= kk) continue;
-      const bool fwd = all_pairs || (yi > yj);          // pair (i, j): i is the "first" element
-      const bool bwd = (j != i) && (all_pairs || (yj > yi));   // pair (j, i): i is the "second" element
-      if (!(fwd || bwd)) continue;
-      const float Gj = Gs[j], ycj = fmaxf(yj, 0.f);
-      const float dx = sigma * (si - ss[j]);
-      if (fwd) {
-        float l, g;
-        pair_terms(c, pair_weight(c, Gi, Gj, ri, rj, yci, ycj), 1.0f / (1.0f + expf(-dx)), l, g);
-        lsum += l;
-        csum += 1.0f;
-        if (j != i) gacc -= g;   // d(-l_ij)/d s_i ; the diagonal pair (ndcgLoss1 only) has no score dependence
-      }
-      if (bwd) {
-        // sigmoid(sigma (s_j - s_i)) evaluated directly (1 - sigmoid(dx) would cancel catastrophically for large dx)
-        float l, g;
-        pair_terms(c, pair_weight(c, Gj, Gi, rj, ri, ycj, yci), 1.0f / (1.0f + expf(dx)), l, g);
-        gacc += g;               // d(-l_ji)/d s_i   (s_i enters pair (j,i) with a minus sign)
+    if (yi != pad && ri < kk) {
+      const float si = ss[i], Gi = Gs[i], yci = fmaxf(yi, 0.f);
+      for (int j = j0; j < j1; ++j) {
+        const float yj = ys[j];
+        const int rj = rk[j];
+        if (yj == pad || rj >= kk) continue;
+        const bool fwd = all_pairs || (yi > yj);          // pair (i, j): i is the "first" element
+        const bool bwd = (j != i) && (all_pairs || (yj > yi));   // pair (j, i): i is the "second" element
+        if (!(fwd || bwd)) continue;
+        const float Gj = Gs[j], ycj = fmaxf(yj, 0.f);
+        const float dx = sigma * (si - ss[j]);
+        if (fwd) {
+          float l, g;
+          pair_terms(c, pair_weight(c, Gi, Gj, ri, rj, yci, ycj), 1.0f / (1.0f + expf(-dx)), l, g);
+          lsum += l;
+          csum += 1.0f;
+          if (j != i) gacc -= g;   // d(-l_ij)/d s_i ; the diagonal pair (ndcgLoss1 only) has no score dependence
+        }
+        if (bwd) {
+          // sigmoid(sigma (s_j - s_i)) evaluated directly (1 - sigmoid(dx) would cancel catastrophically for large dx)
+          float l, g;
+          pair_terms(c, pair_weight(c, Gj, Gi, rj, ri, ycj, yci), 1.0f / (1.0f + expf(dx)), l, g);
+          gacc += g;               // d(-l_ji)/d s_i   (s_i enters pair (j,i) with a minus sign)
+        }
       }
     }
-    if (gp) gp[i] = gacc;
+    part[q * L + i] = gacc;
   }
+  __syncthreads();
+  if (gp && q == 0)
+    for (int i = i0; i < L; i += 256) gp[i] = (part[i] + part[L + i]) + (part[2 * L + i] + part[3 * L + i]);
   lsum = block_sum(lsum, red);
   csum = block_sum(csum, red);
   if (threadIdx.x == 0) {
@@ -231,8 +248,15 @@ extern "C" int ltrx_lambdaloss_fwd_bwd(const float* y_pred, const float* y_true,
   float* per_loss = (float*)ws;
   float* per_cnt = per_loss + B;
   float* scale = per_cnt + B;
-  const size_t lds = (size_t)(5 * L + 2) * sizeof(float);
-  hipLaunchKernelGGL(ltrx_lambdaloss_kernel, dim3(B), dim3(256), lds, s, y_pred, y_true, L, eps, pad_value, scheme, k,
+  const size_t lds = (size_t)(13 * L + 2) * sizeof(float);
+  static bool attr_set = false;          // long slates need more than the default 64 KB of dynamic LDS
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)ltrx_lambdaloss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)((13 * LTRX_MAX_SLATE_LEN + 2) * sizeof(float))) != hipSuccess)
+      return LTRX_EHIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ltrx_lambdaloss_kernel, dim3(B), dim3(1024), lds, s, y_pred, y_true, L, eps, pad_value, scheme, k,
                      sigma, mu, logbase, per_loss, per_cnt, grad_out, order_out);
   LTRX_LAUNCH_CHECK();
   hipLaunchKernelGGL(ltrx_lambdaloss_finalize_kernel, dim3(1), dim3(256), 0, s, per_loss, per_cnt, B, reduction,

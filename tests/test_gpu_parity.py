@@ -1044,3 +1044,18 @@ def test_fused_trainer_gradient_clipping_matches_clip_grad_norm():
     sd1, sd2 = m1.state_dict(), m2.state_dict()
     for k in sd1:
         assert float((sd1[k] - sd2[k]).abs().max().item()) <= 1.01e-2, k
+
+
+def test_listwise_losses_at_the_maximum_slate_length():
+    """L = LTRX_MAX_SLATE_LEN (2048): the per-slate LDS working sets (up to 106 KB for lambdaLoss) and the partner-range split
+    still agree with the oracle."""
+    rng = np.random.default_rng(2048)
+    s = rng.standard_normal((2, 2048)).astype(np.float32)
+    y = rng.integers(0, 5, (2, 2048)).astype(np.float32)
+    y[1, 1500:] = -1
+    for kind, kw in [("lambdaloss", dict(weighing_scheme="lambdaRank_scheme", k=None)), ("lambdaloss", dict(weighing_scheme="ndcgLoss2PP_scheme", k=100)),
+                     ("approxndcg", dict(alpha=1.0)), ("listnet", {})]:
+        l, g = _engine_loss(kind, kw, s, y)
+        lo, go = _oracle_loss(kind, kw, s, y)
+        assert close(l, lo, rtol=3e-5), (kind, l, lo)
+        assert grad_close(g, go, rtol=5e-4), (kind, float(np.abs(g - go).max()))
