@@ -16,7 +16,7 @@
 
 using namespace ltrx;
 
-__global__ void __launch_bounds__(256) ltrx_listmle_kernel(const float* __restrict__ y_pred,
+__global__ void __launch_bounds__(1024) ltrx_listmle_kernel(const float* __restrict__ y_pred,
                                                            const float* __restrict__ y_true,
                                                            const int64_t* __restrict__ perm, int L, float eps,
                                                            float pad, float inv_div, float* __restrict__ per_ws,
@@ -122,7 +122,7 @@ extern "C" int ltrx_listmle_fwd_bwd(const float* y_pred, const float* y_true, co
   if (L > LTRX_MAX_SLATE_LEN) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* per = (float*)ws;
-  hipLaunchKernelGGL(ltrx_listmle_kernel, dim3(B), dim3(256), 6 * (size_t)L * sizeof(float), s, y_pred, y_true, perm, L,
+  hipLaunchKernelGGL(ltrx_listmle_kernel, dim3(B), dim3(L > 512 ? 1024 : 256), 6 * (size_t)L * sizeof(float),   /* long slates: 16 waves */ s, y_pred, y_true, perm, L,
                      eps, pad_value, 1.0f / batch_divisor, per, per_slate_out, grad_out, order_out);
   LTRX_LAUNCH_CHECK();
   return ltrx_launch_finalize_sum(per, B, 1.0f / batch_divisor, loss_out, s);

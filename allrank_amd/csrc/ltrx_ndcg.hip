@@ -13,7 +13,7 @@
 using namespace ltrx;
 
 
-__global__ void __launch_bounds__(256) ltrx_ndcg_kernel(const float* __restrict__ y_pred,
+__global__ void __launch_bounds__(1024) ltrx_ndcg_kernel(const float* __restrict__ y_pred,
                                                         const float* __restrict__ y_true, int L, float pad,
                                                         float filler, LtrxAts ats, float* __restrict__ ndcg_out,
                                                         float* __restrict__ dcg_out, int64_t* __restrict__ order_out) {
@@ -88,7 +88,7 @@ extern "C" int ltrx_ndcg_at(const float* y_pred, const float* y_true, int B, int
     if (ats[i] <= 0) return LTRX_EINVAL;
     a.at[i] = ats[i];
   }
-  hipLaunchKernelGGL(ltrx_ndcg_kernel, dim3(B), dim3(256), 4 * (size_t)L * sizeof(float), (hipStream_t)stream, y_pred,
+  hipLaunchKernelGGL(ltrx_ndcg_kernel, dim3(B), dim3(L > 512 ? 1024 : 256) /* long slates: 16 waves */, 4 * (size_t)L * sizeof(float), (hipStream_t)stream, y_pred,
                      y_true, L, pad_value, filler_value, a, ndcg_out, dcg_out, order_out);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
