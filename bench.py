@@ -287,9 +287,10 @@ def main():
             "metric": "slate-items/sec training (WEB30K synth, slate 240)", "value": round(value, 1),
             "unit": "slate-items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (dense projections: fp32-accurate split-bf16 on the bf16 MFMA; attention: exact fp32 MFMA)" if (args.engine == "fused" and args.gemm != "hipblaslt") else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["desc"], "slates_per_gpu": B, "slate_len": L, "global_batch": B * world,
-                       "optimizer": "Adam lr=1e-3", "dropout": args.dropout, "engine": args.engine, "gemm": args.gemm if args.engine == "fused" else "hipblaslt", "parallelism": "slate-sharded dp%d" % world,
+                       "optimizer": "Adam lr=1e-3", "dropout": args.dropout,
+                       "arithmetic": ("fp32 storage and accumulation; dense projections as fp32-accurate split-bf16 (3 bf16 MFMA products per fp32 product); attention on the exact fp32 MFMA" if (args.engine == "fused" and args.gemm != "hipblaslt") else "fp32 (hipBLASLt GEMMs, fp32 MFMA attention)"), "engine": args.engine, "gemm": args.gemm if args.engine == "fused" else "hipblaslt", "parallelism": "slate-sharded dp%d" % world,
                        "train_flops_per_item": fl_item},
             "model_tflops": round(value * fl_item / 1e12, 2),
             "model_mfma_frac_fp32": round(value * fl_item / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
