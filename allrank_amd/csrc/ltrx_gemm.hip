@@ -727,7 +727,12 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
     ldb = 0;
   }
   // large-tile kernel: exact multiples only, and enough tiles to cover the 256 CUs at least ~1.4 times
-  if (v == 0 && !strict && (N % 256) == 0 && (K % 32) == 0 && (size_t)((M + 255) / 256) * (N / 256) >= 360) v = 6;
+  if (v == 0 && !strict && (N % 256) == 0 && (K % 32) == 0) {
+    // one workgroup per CU: a grid that fills 3/4 .. 1 round, or at least ~1.4 rounds (measured, tools/gemm_variants.py:
+    // 240 tiles 53 vs 77 us, 360 tiles parity, 120 tiles parity, 480 tiles 102 vs 132 us)
+    const size_t t = (size_t)((M + 255) / 256) * (N / 256);
+    if (t >= 360 || (t >= 192 && t <= 256)) v = 6;
+  }
   if (v == 0) v = 1;
   if (v == 6) {
     if ((N % 256) || (K % 32) || strict) return LTRX_EUNSUPPORTED;
