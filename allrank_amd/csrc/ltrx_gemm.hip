@@ -17,10 +17,15 @@
 //                  -> weight gradient dW = dY^T X; both operands are contraction-STRIDED in memory, they are transposed
 //                     on the way into LDS (each lane converts a 4(m) x 1(n) register column into one 8-byte LDS write).
 //
-// Tiling: workgroup = 4 waves (2 x 2), tile 128 x 128 x 32; wave tile 64 x 64 = 2 x 2 MFMA tiles (64 accumulator
-// VGPRs).  LDS operand images are [row][k] bf16 with k contiguous and a row stride of 40 elements (80 B): every lane
-// fetches its 8-element MFMA fragment with one ds_read_b128, conflict-free.  Global loads of K-tile t+1 are issued
-// into registers before the MFMAs of tile t (register double buffering); two workgroups fit per CU (40 KB LDS each).
+// Two kernel families (the host wrappers pick per shape):
+//   * 128 x 128 x 32 tiles, 4 waves (2 x 2) of 64 x 64 wave tiles, one LDS stage (32 KB), two workgroups per CU -- every
+//     shape, ragged edges, the strict 3-term mode; global loads of K-tile t+1 are issued into registers before the MFMAs of
+//     tile t (register double buffering).
+//   * 256 x 256 x 32 tiles, 8 waves (2 x 4) of 128 x 64 wave tiles, two LDS stages (128 KB, one workgroup per CU), LDS-only
+//     barrier, nontemporal output -- the big projections and their weight gradients (ltrx_gemm_nt256_kernel,
+//     ltrx_gemm_tn256_kernel below; 1.3-1.6x the small tile on those shapes, see DESIGN.md section 4 for the measurements).
+// LDS operand images are [row][k] bf16 with k contiguous, UNPADDED 64-byte rows and an XOR swizzle of the 16-byte chunks
+// (swz_off): every lane fetches its 8-element MFMA fragment with one ds_read_b128, conflict-free in both directions.
 // Workgroup ids are remapped so that the column tiles of one A row-panel run on the same XCD (shared L2).
 #include "ltrx_device.h"
 
