@@ -46,7 +46,8 @@ __device__ __forceinline__ unsigned long long stamp() {
 template <int VAR>
 __global__ void __launch_bounds__(512) gemm256(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                float* __restrict__ C, int ldc, int M, int N, int K,
-                                               const float* __restrict__ bias, int tiles_n) {
+                                               const float* __restrict__ bias, int tiles_n,
+                                               const __bf16* __restrict__ Bh = nullptr, const __bf16* __restrict__ Bl = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem* s = reinterpret_cast<Smem*>(smem_raw);
   const int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -184,6 +185,57 @@ __global__ void __launch_bounds__(512) gemm256(const float* __restrict__ A, int 
     };
     const bool late = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;     // waves 4..7: store first
     int kt = 0;
+    if (VAR & 65536) {
+      // B pre-split: per K-step a thread fetches 2 x 16 B of the hi image and 2 x 16 B of the lo image (row = t >> 2 (+128),
+      // chunk = t & 3) and stores them with ds_write_b128; A is staged as before (4 float4 -> split -> 8 ds_write_b64)
+      const int brow = threadIdx.x >> 2, bch = threadIdx.x & 3;
+      typedef __bf16 bx8 __attribute__((ext_vector_type(8)));
+      bx8 bh[2], bl[2];
+      auto gloadB = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          bh[p] = *reinterpret_cast<const bx8*>(Bh + (size_t)(n0 + brow + 128 * p) * ldb + k0 + 8 * bch);
+          bl[p] = *reinterpret_cast<const bx8*>(Bl + (size_t)(n0 + brow + 128 * p) * ldb + k0 + 8 * bch);
+        }
+      };
+      auto gloadA = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) ra[p] = *reinterpret_cast<const float4*>(Ap + (size_t)(64 * p) * lda + k0);
+      };
+      auto sstoreAB = [&](Smem& d) {
+        bf16x4 h, l;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int o = swz_off(srow + 64 * p, sc4);
+          split4(ra[p], h, l);
+          *reinterpret_cast<bf16x4*>(&d.a[0][o]) = h;
+          *reinterpret_cast<bf16x4*>(&d.a[1][o]) = l;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int o = swz_off(brow + 128 * p, 8 * bch);
+          *reinterpret_cast<bx8*>(&d.b[0][o]) = bh[p];
+          *reinterpret_cast<bx8*>(&d.b[1][o]) = bl[p];
+        }
+      };
+      // (the generic prologue above staged tile 0 from the fp32 B; redo it from the pre-split images for a clean measurement)
+      gloadA(0); gloadB(0);
+      __syncthreads();
+      sstoreAB(s[0]);
+      if (nk > 1) { gloadA(BK); gloadB(BK); }
+      __syncthreads();
+      for (; kt + 2 < nk; ++kt) {
+        mma(s[kt & 1]);
+        sstoreAB(s[(kt + 1) & 1]);
+        gloadA((kt + 2) * BK); gloadB((kt + 2) * BK);
+        lds_barrier();
+      }
+      for (; kt < nk; ++kt) {
+        mma(s[kt & 1]);
+        if (kt + 1 < nk) sstoreAB(s[(kt + 1) & 1]);
+        __syncthreads();
+      }
+    }
     if (VAR & 4096) {
       const bool rec = (blockIdx.x == 1000) && lane == 0;
       for (; kt + 2 < nk; ++kt) {
@@ -344,6 +396,8 @@ __global__ void __launch_bounds__(512) gemm256(const float* __restrict__ A, int 
   }
 }
 
+static const __bf16* g_Bh = nullptr;
+static const __bf16* g_Bl = nullptr;
 template <int VAR>
 static float run(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int iters) {
   const int tiles_n = N / BN, tiles = (M / BM) * tiles_n;
@@ -352,10 +406,10 @@ static float run(const float* A, const float* B, float* C, const float* bias, in
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   for (int i = 0; i < 2; ++i)
-    hipLaunchKernelGGL((gemm256<VAR>), dim3(tiles), dim3(512), 2 * sizeof(Smem), 0, A, K, B, K, C, N, M, N, K, bias, tiles_n);
+    hipLaunchKernelGGL((gemm256<VAR>), dim3(tiles), dim3(512), 2 * sizeof(Smem), 0, A, K, B, K, C, N, M, N, K, bias, tiles_n, g_Bh, g_Bl);
   hipEventRecord(e0, 0);
   for (int i = 0; i < iters; ++i)
-    hipLaunchKernelGGL((gemm256<VAR>), dim3(tiles), dim3(512), 2 * sizeof(Smem), 0, A, K, B, K, C, N, M, N, K, bias, tiles_n);
+    hipLaunchKernelGGL((gemm256<VAR>), dim3(tiles), dim3(512), 2 * sizeof(Smem), 0, A, K, B, K, C, N, M, N, K, bias, tiles_n, g_Bh, g_Bl);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -379,6 +433,21 @@ int main(int argc, char** argv) {
   hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(bias, hbias.data(), (size_t)N * 4, hipMemcpyHostToDevice);
+  {
+    std::vector<__bf16> hh((size_t)N * K), hl((size_t)N * K);
+    for (size_t i = 0; i < hh.size(); ++i) {
+      const __bf16 h = (__bf16)hb[i];
+      hh[i] = h;
+      hl[i] = (__bf16)(hb[i] - (float)h);
+    }
+    __bf16 *dh, *dl;
+    hipMalloc(&dh, hh.size() * 2);
+    hipMalloc(&dl, hl.size() * 2);
+    hipMemcpy(dh, hh.data(), hh.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dl, hl.data(), hl.size() * 2, hipMemcpyHostToDevice);
+    g_Bh = dh;
+    g_Bl = dl;
+  }
   const double fl = 2.0 * M * N * K;
   printf("M=%d N=%d K=%d\n", M, N, K);
   const int only = argc > 4 ? atoi(argv[4]) : -1;
@@ -394,6 +463,8 @@ int main(int argc, char** argv) {
   RUN("peeled+raw+sched (mma,st,ld)", 96)
   RUN("peeled+raw+sched (st,ld,mma)", 97)
   RUN("ping-pong by wave>>2", 160)
+  RUN("B pre-split, nt stores", 32 + 2048 + 65536)
+  RUN("B pre-split, no epilogue", 32 + 8 + 65536)
   RUN("source interleave, nt stores", 32 + 2048 + 32768)
   RUN("source interleave, no epilogue", 32 + 8 + 32768)
   RUN("static prio, nt stores", 32 + 2048 + 16384)
@@ -429,7 +500,7 @@ int main(int argc, char** argv) {
   }
   for (int pass = 0; pass < 2 && only < 0; ++pass) {
     hipMemset(C, 0, (size_t)M * N * 4);
-    if (pass == 0) run<34848>(A, B, C, bias, M, N, K, 1); else run<33>(A, B, C, bias, M, N, K, 1);
+    if (pass == 0) run<67616>(A, B, C, bias, M, N, K, 1); else run<33>(A, B, C, bias, M, N, K, 1);
     std::vector<float> hc((size_t)256 * N);
     hipMemcpy(hc.data(), C + (size_t)(M - 256) * N, hc.size() * 4, hipMemcpyDeviceToHost);
     double maxerr = 0;
