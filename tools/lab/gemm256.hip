@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(512) gemm256(const float* __restrict__ A, int 
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     };
     const bool late = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;     // waves 4..7: store first
+    const int stag_pos = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // 0..7
     int kt = 0;
     if (VAR & 65536) {
       // B pre-split: per K-step a thread fetches 2 x 16 B of the hi image and 2 x 16 B of the lo image (row = t >> 2 (+128),
@@ -296,7 +297,18 @@ __global__ void __launch_bounds__(512) gemm256(const float* __restrict__ A, int 
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ta][i], bfr[tb][j], acc[i][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (c & 1) store_one(2 * ks + (c >> 1));  // 4 staged (A,B) float4 pairs per K-step: after chunks 1,3 of each ks
+            if (VAR & 131072) {
+              // every wave stages its share (all 4 float4 pairs) after a DIFFERENT chunk: the 8 waves' load groups are spread
+              // over the K-step instead of arriving at the vector-memory path together
+              if (stag_pos == 4 * ks + c) {
+                store_one(0);
+                store_one(1);
+                store_one(2);
+                store_one(3);
+              }
+            } else {
+              if (c & 1) store_one(2 * ks + (c >> 1));  // 4 staged (A,B) float4 pairs per K-step: after chunks 1,3 of each ks
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -463,6 +475,8 @@ int main(int argc, char** argv) {
   RUN("peeled+raw+sched (mma,st,ld)", 96)
   RUN("peeled+raw+sched (st,ld,mma)", 97)
   RUN("ping-pong by wave>>2", 160)
+  RUN("staggered staging, nt stores", 32 + 2048 + 32768 + 131072)
+  RUN("staggered staging, no epilogue", 32 + 8 + 32768 + 131072)
   RUN("B pre-split, nt stores", 32 + 2048 + 65536)
   RUN("B pre-split, no epilogue", 32 + 8 + 65536)
   RUN("source interleave, nt stores", 32 + 2048 + 32768)
@@ -500,7 +514,7 @@ int main(int argc, char** argv) {
   }
   for (int pass = 0; pass < 2 && only < 0; ++pass) {
     hipMemset(C, 0, (size_t)M * N * 4);
-    if (pass == 0) run<67616>(A, B, C, bias, M, N, K, 1); else run<33>(A, B, C, bias, M, N, K, 1);
+    if (pass == 0) run<165920>(A, B, C, bias, M, N, K, 1); else run<33>(A, B, C, bias, M, N, K, 1);
     std::vector<float> hc((size_t)256 * N);
     hipMemcpy(hc.data(), C + (size_t)(M - 256) * N, hc.size() * 4, hipMemcpyDeviceToHost);
     double maxerr = 0;
