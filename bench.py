@@ -59,8 +59,9 @@ def train_flops_per_item(w, L):
     return 3 * fwd - 2 * F * d
 
 
-def synth_batch(n_slates, L, F, seed, device):
-    """SURVEY.md §8d recipe, dense slates: x ~ N(0,1), labels ~ Cat(.52,.32,.13,.02,.01), 3% of slates all-zero."""
+def synth_batch(n_slates, L, F, seed, device, ragged=False):
+    """SURVEY.md §8d recipe: x ~ N(0,1), labels ~ Cat(.52,.32,.13,.02,.01), 3% of slates all-zero; dense slates, or
+    (ragged) WEB30K-like lengths n_valid ~ clip(round(lognormal(ln 100, 0.6)), 1, L) padded like FixLength._pad."""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn((n_slates, L, F), generator=g, dtype=torch.float32)
     probs = torch.tensor([0.52, 0.32, 0.13, 0.02, 0.01])
@@ -68,6 +69,13 @@ def synth_batch(n_slates, L, F, seed, device):
     zero = torch.rand(n_slates, generator=g) < 0.03
     y[zero] = 0.0
     idx = torch.arange(L).expand(n_slates, L).contiguous()
+    if ragged:
+        nv = torch.exp(torch.randn(n_slates, generator=g) * 0.6 + np.log(100.0)).round().clamp(1, L).long()
+        pad = torch.arange(L)[None, :] >= nv[:, None]
+        y[pad] = -1.0
+        x[pad] = 0.0
+        idx = idx.clone()
+        idx[pad] = -1
     return x.to(device), y.to(device), idx.to(device)
 
 
@@ -185,6 +193,8 @@ def main():
     ap.add_argument("--workload", default="attn_approxndcg", choices=sorted(WORKLOADS))
     ap.add_argument("--slates-per-gpu", type=int, default=256)
     ap.add_argument("--slate-len", type=int, default=240)
+    ap.add_argument("--ragged", action="store_true",
+                    help="WEB30K-like slate lengths (lognormal, mean ~100 of 240 slots); also reports valid items/s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-pass", action="store_true", help="profiling runs: skip the 64-slate side measurement")
     ap.add_argument("--dropout", type=float, default=0.0,
@@ -228,7 +238,7 @@ def main():
         _lf, _la = getattr(E, w["loss"]), w.get("loss_args", {})
         trainer = Trainer(model, (lambda sc, yt: _lf(sc, yt, **_la)), opt, None, world, None)
     n_batches = 8
-    x, y, idx = synth_batch(n_batches * B, L, w["n_features"], 42 + rank, device)
+    x, y, idx = synth_batch(n_batches * B, L, w["n_features"], 42 + rank, device, ragged=args.ragged)
 
     def one_step(i):
         j = (i % n_batches) * B
@@ -290,13 +300,14 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["desc"], "slates_per_gpu": B, "slate_len": L, "global_batch": B * world,
-                       "optimizer": "Adam lr=1e-3", "dropout": args.dropout,
+                       "optimizer": "Adam lr=1e-3", "dropout": args.dropout, "slates": ("ragged (lognormal lengths)" if args.ragged else "dense"),
                        "arithmetic": ("fp32 storage and accumulation; dense projections as fp32-accurate split-bf16 (3 bf16 MFMA products per fp32 product); attention on the exact fp32 MFMA" if (args.engine == "fused" and args.gemm != "hipblaslt") else "fp32 (hipBLASLt GEMMs, fp32 MFMA attention)"), "engine": args.engine, "gemm": args.gemm if args.engine == "fused" else "hipblaslt", "parallelism": "slate-sharded dp%d" % world,
                        "train_flops_per_item": fl_item},
             "model_tflops": round(value * fl_item / 1e12, 2),
             "model_mfma_frac_fp32": round(value * fl_item / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
             "algorithmic_hbm_frac": round(value * (4 * w["n_features"] + 8) / 1e9 / (PEAK_HBM_GBPS * world), 6),
             "last_loss": last_loss,
+            "valid_items_per_s": (round(value * float((y != -1).float().mean().item()), 1) if args.ragged else None),
             "roofline": roof,
             "kernel_times_us": {n: round(v["sec"] * 1e6, 1) for n, v in kern.items()},
         }
