@@ -225,7 +225,8 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
                                                               const uint8_t* __restrict__ kpm, int L, int h, int dk,
                                                               int rs, float* __restrict__ o, int ors,
                                                               float* __restrict__ lse, float scale, DropCfg drop,
-                                                              const uint32_t* __restrict__ drop_step) {
+                                                              const uint32_t* __restrict__ drop_step,
+                                                              const int* __restrict__ cu) {
   if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   __shared__ __attribute__((aligned(16))) float ktile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float vtile[Tile<DKP>::FLOATS];
@@ -233,7 +234,12 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
   const int b = blockIdx.y / h, head = blockIdx.y % h;
   const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
   const int q0 = blockIdx.x * 128 + wave * 32;
-  const size_t slate = (size_t)b * L;
+  // variable-length (compacted) batches: cu[b] = first row of slate b, cu[b+1] - cu[b] its item count; L stays the stride of
+  // the per-query statistics (lse / delta) and of the dropout row hash
+  const int Lmax = L;
+  const size_t slate = cu ? (size_t)cu[b] : (size_t)b * L;
+  if (cu) L = cu[b + 1] - cu[b];
+  if ((int)(blockIdx.x * 128) >= L) return;          // whole workgroup beyond this slate (uniform: no barrier is skipped)
   const float* qb = q + slate * rs + (size_t)head * dk;
   const float* kb = k + slate * rs + (size_t)head * dk;
   const float* vb = v + slate * rs + (size_t)head * dk;
@@ -243,7 +249,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
   f32x16 oacc[DKP / 32];
   zero_acc<DKP>(oacc);
   float m = -INFINITY, l = 0.f;        // running max (log2 domain) and normaliser
-  const uint32_t drow = DROP ? drop_row_seed(drop, blockIdx.y, L, q0 + (lane & 31)) : 0u;
+  const uint32_t drow = DROP ? drop_row_seed(drop, blockIdx.y, Lmax, q0 + (lane & 31)) : 0u;
   const float sl2 = scale * kLog2e;
 
   const int nkt = (L + 31) / 32;
@@ -256,7 +262,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
     tile_sstore<DKP>(vtile, vr);
     if (threadIdx.x < 32) {
       const int key = kt * 32 + threadIdx.x;
-      kmask[threadIdx.x] = (key >= L || kpm[slate + key]) ? -INFINITY : 0.f;       // additive bias
+      kmask[threadIdx.x] = (key >= L || (kpm && kpm[slate + key])) ? -INFINITY : 0.f;       // additive bias
     }
     __syncthreads();
     if (kt + 1 < nkt) {   // prefetch: in flight during this tile's MFMAs
@@ -297,7 +303,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
   const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;   // a row whose keys are all padded: 0 (the reference yields NaN)
   store_rows<DKP>(o + slate * ors + (size_t)head * dk, q0, L, dk, ors, oacc, inv);
   const int qrow = q0 + (lane & 31);
-  if (half == 0 && qrow < L) lse[((size_t)b * h + head) * L + qrow] = (lt > 0.f) ? (m + log2f(lt)) * kLn2 : 0.f;   // natural log
+  if (half == 0 && qrow < L) lse[((size_t)b * h + head) * Lmax + qrow] = (lt > 0.f) ? (m + log2f(lt)) * kLn2 : 0.f;   // natural log
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -308,7 +314,8 @@ __global__ void __launch_bounds__(256, (DKP <= 64) ? 3 : 2) ltrx_mha_bwd_dq_kern
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ kpm, const float* __restrict__ o, const float* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ delta, int L, int h, int dk, int rs, int ors,
-    float* __restrict__ dq, int drs, float scale, DropCfg drop, const uint32_t* __restrict__ drop_step) {
+    float* __restrict__ dq, int drs, float scale, DropCfg drop, const uint32_t* __restrict__ drop_step,
+    const int* __restrict__ cu) {
   if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   __shared__ __attribute__((aligned(16))) float ktile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float vtile[Tile<DKP>::FLOATS];
@@ -318,16 +325,21 @@ __global__ void __launch_bounds__(256, (DKP <= 64) ? 3 : 2) ltrx_mha_bwd_dq_kern
   const int b = blockIdx.y / h, head = blockIdx.y % h;
   const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
   const int q0 = blockIdx.x * 128 + wave * 32;
-  const size_t slate = (size_t)b * L;
+  // variable-length (compacted) batches: cu[b] = first row of slate b, cu[b+1] - cu[b] its item count; L stays the stride of
+  // the per-query statistics (lse / delta) and of the dropout row hash
+  const int Lmax = L;
+  const size_t slate = cu ? (size_t)cu[b] : (size_t)b * L;
+  if (cu) L = cu[b + 1] - cu[b];
+  if ((int)(blockIdx.x * 128) >= L) return;          // whole workgroup beyond this slate (uniform: no barrier is skipped)
   const float* kb = k + slate * rs + (size_t)head * dk;
   const float* vb = v + slate * rs + (size_t)head * dk;
   float qfrag[DKP / 2];
   load_fixed<DKP>(qfrag, q + slate * rs + (size_t)head * dk, q0, L, dk, rs);
   float* myimg = doimg + wave * Tile<DKP>::FLOATS;
   const int qrow = q0 + (lane & 31);
-  const size_t stat = ((size_t)b * h + head) * L + qrow;
+  const size_t stat = ((size_t)b * h + head) * Lmax + qrow;
   const float lse_q = (qrow < L) ? lse[stat] * kLog2e : 0.f;          // log2 domain
-  const uint32_t drow = DROP ? drop_row_seed(drop, blockIdx.y, L, qrow) : 0u;
+  const uint32_t drow = DROP ? drop_row_seed(drop, blockIdx.y, Lmax, qrow) : 0u;
   const float sl2 = scale * kLog2e;
   // delta_q = <dO_q, O_q> (rowsum(dP * P)); each half-wave holds half of the head dimension.  Published for the
   // dK/dV kernel, which is launched after this one on the same stream.
@@ -357,7 +369,7 @@ __global__ void __launch_bounds__(256, (DKP <= 64) ? 3 : 2) ltrx_mha_bwd_dq_kern
     tile_sstore<DKP>(vtile, vr);
     if (threadIdx.x < 32) {
       const int key = kt * 32 + threadIdx.x;
-      kmask[threadIdx.x] = (key >= L || kpm[slate + key]) ? -INFINITY : 0.f;       // additive bias
+      kmask[threadIdx.x] = (key >= L || (kpm && kpm[slate + key])) ? -INFINITY : 0.f;       // additive bias
     }
     __syncthreads();
     if (kt + 1 < nkt) {
@@ -386,7 +398,8 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dkdv_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ kpm, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, int L, int h, int dk, int rs, int ors, float* __restrict__ dkout,
-    float* __restrict__ dvout, int drs, float scale, DropCfg drop, const uint32_t* __restrict__ drop_step) {
+    float* __restrict__ dvout, int drs, float scale, DropCfg drop, const uint32_t* __restrict__ drop_step,
+    const int* __restrict__ cu) {
   if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   __shared__ __attribute__((aligned(16))) float qtile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float dotile[Tile<DKP>::FLOATS];
@@ -396,20 +409,25 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dkdv_kernel(
   const int b = blockIdx.y / h, head = blockIdx.y % h;
   const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
   const int k0 = blockIdx.x * 128 + wave * 32;
-  const size_t slate = (size_t)b * L;
+  // variable-length (compacted) batches: cu[b] = first row of slate b, cu[b+1] - cu[b] its item count; L stays the stride of
+  // the per-query statistics (lse / delta) and of the dropout row hash
+  const int Lmax = L;
+  const size_t slate = cu ? (size_t)cu[b] : (size_t)b * L;
+  if (cu) L = cu[b + 1] - cu[b];
+  if ((int)(blockIdx.x * 128) >= L) return;          // whole workgroup beyond this slate (uniform: no barrier is skipped)
   const float* qb = q + slate * rs + (size_t)head * dk;
   const float* dob = dout + slate * ors + (size_t)head * dk;
   float kfrag[DKP / 2], vfrag[DKP / 2];
   load_fixed<DKP>(kfrag, k + slate * rs + (size_t)head * dk, k0, L, dk, rs);
   load_fixed<DKP>(vfrag, v + slate * rs + (size_t)head * dk, k0, L, dk, rs);
   const int key = k0 + (lane & 31);
-  const bool key_masked = (key >= L) || (kpm[slate + (key < L ? key : 0)] != 0);
+  const bool key_masked = (key >= L) || (kpm && kpm[slate + (key < L ? key : 0)] != 0);
   const float kbias = key_masked ? -INFINITY : 0.f;
   const float sl2 = scale * kLog2e;
   f32x16 dkacc[DKP / 32], dvacc[DKP / 32];
   zero_acc<DKP>(dkacc);
   zero_acc<DKP>(dvacc);
-  const size_t statb = ((size_t)b * h + head) * L;
+  const size_t statb = ((size_t)b * h + head) * Lmax;
   const int nqt = (L + 31) / 32;
   TileRegs<DKP> qr, dor;
   tile_gload<DKP>(qr, qb, 0, L, dk, rs);
@@ -422,7 +440,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dkdv_kernel(
       const int qrow = qt * 32 + threadIdx.x;
       lse_t[threadIdx.x] = (qrow < L) ? lse[statb + qrow] * kLog2e : INFINITY;   // +inf -> P = exp2(-inf) = 0 for rows >= L
       del_t[threadIdx.x] = (qrow < L) ? delta[statb + qrow] : 0.f;
-      if (DROP) drow_t[threadIdx.x] = drop_row_seed(drop, blockIdx.y, L, qrow);
+      if (DROP) drow_t[threadIdx.x] = drop_row_seed(drop, blockIdx.y, Lmax, qrow);
     }
     __syncthreads();
     if (qt + 1 < nqt) {
@@ -504,12 +522,12 @@ static DropCfg make_drop(float p_drop, uint32_t seed) { return ltrx_make_drop(p_
 
 extern "C" int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L,
                             int h, int d_k, int row_stride, float* o, int o_row_stride, float* lse_out, float p_drop,
-                            uint32_t seed, const uint32_t* seed_step, ltrx_stream_t stream) {
-  if (!q || !k || !v || !key_pad_mask || !o || !lse_out || !(p_drop >= 0.f) || p_drop >= 1.f) return LTRX_EINVAL;
+                            uint32_t seed, const uint32_t* seed_step, const int32_t* cu_seqlens, ltrx_stream_t stream) {
+  if (!q || !k || !v || (!key_pad_mask && !cu_seqlens) || !o || !lse_out || !(p_drop >= 0.f) || p_drop >= 1.f) return LTRX_EINVAL;
   int rc = mha_check(B, L, h, d_k, row_stride, o_row_stride);
   if (rc != LTRX_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (g_mha_mode == 1 && p_drop == 0.f)      // (dropout is implemented in the exact-fp32 kernels only)
+  if (g_mha_mode == 1 && p_drop == 0.f && !cu_seqlens)      // (dropout / variable-length batches: exact-fp32 kernels only)
     return ltrx_mha_fwd_bf16_launch(q, k, v, key_pad_mask, B, L, h, d_k, row_stride, o, o_row_stride, lse_out, s);
   const DropCfg drop = make_drop(p_drop, seed);
   const dim3 grid((L + 127) / 128, B * h);
@@ -517,10 +535,10 @@ extern "C" int ltrx_mha_fwd(const float* q, const float* k, const float* v, cons
 #define CALL(DKP)                                                                                                 \
   if (drop.thresh != 0u)                                                                                          \
     hipLaunchKernelGGL((ltrx_mha_fwd_kernel<DKP, true>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, L, h, d_k, row_stride, \
-                       o, o_row_stride, lse_out, scale, drop, seed_step);                                          \
+                       o, o_row_stride, lse_out, scale, drop, seed_step, cu_seqlens);                              \
   else                                                                                                            \
     hipLaunchKernelGGL((ltrx_mha_fwd_kernel<DKP, false>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, L, h, d_k, row_stride, \
-                       o, o_row_stride, lse_out, scale, drop, seed_step)
+                       o, o_row_stride, lse_out, scale, drop, seed_step, cu_seqlens)
   LTRX_DKP_DISPATCH(d_k, CALL);
 #undef CALL
   LTRX_LAUNCH_CHECK();
@@ -535,15 +553,16 @@ extern "C" size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h) {
 extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, const float* o,
                             const float* dout, const float* lse, int B, int L, int h, int d_k, int row_stride,
                             int o_row_stride, float* dq, float* dk, float* dv, int d_row_stride, float p_drop,
-                            uint32_t seed, const uint32_t* seed_step, void* ws, ltrx_stream_t stream) {
-  if (!q || !k || !v || !key_pad_mask || !o || !dout || !lse || !dq || !dk || !dv || !ws) return LTRX_EINVAL;
+                            uint32_t seed, const uint32_t* seed_step, const int32_t* cu_seqlens, void* ws,
+                            ltrx_stream_t stream) {
+  if (!q || !k || !v || (!key_pad_mask && !cu_seqlens) || !o || !dout || !lse || !dq || !dk || !dv || !ws) return LTRX_EINVAL;
   if (!(p_drop >= 0.f) || p_drop >= 1.f) return LTRX_EINVAL;
   int rc = mha_check(B, L, h, d_k, row_stride, o_row_stride);
   if (rc != LTRX_OK) return rc;
   if (d_row_stride % 4 != 0 || d_row_stride < h * d_k) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* delta = (float*)ws;
-  if (g_mha_mode == 1 && p_drop == 0.f)
+  if (g_mha_mode == 1 && p_drop == 0.f && !cu_seqlens)
     return ltrx_mha_bwd_bf16_launch(q, k, v, key_pad_mask, o, dout, lse, B, L, h, d_k, row_stride, o_row_stride, dq, dk, dv,
                                     d_row_stride, delta, s);
   const DropCfg drop = make_drop(p_drop, seed);
@@ -552,20 +571,20 @@ extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, cons
 #define CALLQ(DKP)                                                                                                   \
   if (drop.thresh != 0u)                                                                                             \
     hipLaunchKernelGGL((ltrx_mha_bwd_dq_kernel<DKP, true>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, o, dout, lse, delta, \
-                       L, h, d_k, row_stride, o_row_stride, dq, d_row_stride, scale, drop, seed_step);                \
+                       L, h, d_k, row_stride, o_row_stride, dq, d_row_stride, scale, drop, seed_step, cu_seqlens);    \
   else                                                                                                               \
     hipLaunchKernelGGL((ltrx_mha_bwd_dq_kernel<DKP, false>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, o, dout, lse, delta, \
-                       L, h, d_k, row_stride, o_row_stride, dq, d_row_stride, scale, drop, seed_step)
+                       L, h, d_k, row_stride, o_row_stride, dq, d_row_stride, scale, drop, seed_step, cu_seqlens)
   LTRX_DKP_DISPATCH(d_k, CALLQ);
 #undef CALLQ
   LTRX_LAUNCH_CHECK();
 #define CALLK(DKP)                                                                                                     \
   if (drop.thresh != 0u)                                                                                               \
     hipLaunchKernelGGL((ltrx_mha_bwd_dkdv_kernel<DKP, true>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, dout, lse, delta, L, \
-                       h, d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale, drop, seed_step);                  \
+                       h, d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale, drop, seed_step, cu_seqlens);      \
   else                                                                                                                 \
     hipLaunchKernelGGL((ltrx_mha_bwd_dkdv_kernel<DKP, false>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, dout, lse, delta, L, \
-                       h, d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale, drop, seed_step)
+                       h, d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale, drop, seed_step, cu_seqlens)
   LTRX_DKP_DISPATCH(d_k, CALLK);
 #undef CALLK
   LTRX_LAUNCH_CHECK();

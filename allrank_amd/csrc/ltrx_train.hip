@@ -408,6 +408,79 @@ extern "C" int ltrx_transpose_batch(const float* src_base, float* dst_base, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Row gather / scatter for compacted (variable-length) batches: the valid items of a padded [B, L] batch are packed into
+// consecutive rows before the row-wise part of the step (dataset.py:28-38 pads every slate to the batch's slate length;
+// the padded rows carry no gradient and are masked out as attention keys, so the step never needs them).
+//   gather : dst[i, :] = src[idx[i], :]  for i < n, and dst[i, :] = 0 for n <= i < n_pad (alignment rows)
+//   scatter: dst[idx[i], :] = src[i, :]  for i < n
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ltrx_gather_rows_kernel(const float* __restrict__ src, int ld_src,
+                                                               const int32_t* __restrict__ idx, int n, int n_pad, int cols,
+                                                               float* __restrict__ dst, int ld_dst) {
+  const size_t total = (size_t)n_pad * cols;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / cols), c = (int)(e % cols);
+    dst[(size_t)r * ld_dst + c] = (r < n) ? src[(size_t)idx[r] * ld_src + c] : 0.f;
+  }
+}
+__global__ void __launch_bounds__(256) ltrx_scatter_rows_kernel(const float* __restrict__ src, int ld_src,
+                                                                const int32_t* __restrict__ idx, int n, int cols,
+                                                                float* __restrict__ dst, int ld_dst) {
+  const size_t total = (size_t)n * cols;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / cols), c = (int)(e % cols);
+    dst[(size_t)idx[r] * ld_dst + c] = src[(size_t)r * ld_src + c];
+  }
+}
+
+// packed row r of a cu_seqlens layout whose slates keep their valid items first (dataset.py:28-38 pads at the end):
+// idx[r] = b * L + (r - cu[b]) with cu[b] <= r < cu[b+1]  (binary search over the B+1 prefix sums)
+__global__ void __launch_bounds__(256) ltrx_packed_row_index_kernel(const int32_t* __restrict__ cu, int B, int L, int n,
+                                                                    int32_t* __restrict__ idx) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int lo = 0, hi = B;                 // invariant: cu[lo] <= r < cu[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (cu[mid] <= r) lo = mid; else hi = mid;
+  }
+  idx[r] = lo * L + (r - cu[lo]);
+}
+
+static inline int row_copy_grid(size_t total) {
+  size_t g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+extern "C" int ltrx_gather_rows(const float* src, int ld_src, const int32_t* idx, int n, int n_pad, int cols, float* dst,
+                                int ld_dst, ltrx_stream_t stream) {
+  if (!src || !idx || !dst || n < 0 || n_pad < n || cols <= 0 || ld_src < cols || ld_dst < cols) return LTRX_EINVAL;
+  if (n_pad == 0) return LTRX_OK;
+  hipLaunchKernelGGL(ltrx_gather_rows_kernel, dim3(row_copy_grid((size_t)n_pad * cols)), dim3(256), 0, (hipStream_t)stream, src,
+                     ld_src, idx, n, n_pad, cols, dst, ld_dst);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+extern "C" int ltrx_packed_row_index(const int32_t* cu_seqlens, int B, int L, int n, int32_t* idx, ltrx_stream_t stream) {
+  if (!cu_seqlens || !idx || B <= 0 || L <= 0 || n < 0 || (size_t)n > (size_t)B * L) return LTRX_EINVAL;
+  if (n == 0) return LTRX_OK;
+  hipLaunchKernelGGL(ltrx_packed_row_index_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, cu_seqlens, B, L, n, idx);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+extern "C" int ltrx_scatter_rows(const float* src, int ld_src, const int32_t* idx, int n, int cols, float* dst, int ld_dst,
+                                 ltrx_stream_t stream) {
+  if (!src || !idx || !dst || n < 0 || cols <= 0 || ld_src < cols || ld_dst < cols) return LTRX_EINVAL;
+  if (n == 0) return LTRX_OK;
+  hipLaunchKernelGGL(ltrx_scatter_rows_kernel, dim3(row_copy_grid((size_t)n * cols)), dim3(256), 0, (hipStream_t)stream, src,
+                     ld_src, idx, n, cols, dst, ld_dst);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Gradient clipping (torch.nn.utils.clip_grad_norm_, train_utils.py:24-25) for the flat gradient buffer:
 // scale_out[0] = min(1, max_norm / (||g||_2 + 1e-6)); the Adam kernel multiplies the gradients by it on the fly.
 // Two-stage deterministic sum of squares (grid-stride partials, then one block).

@@ -73,11 +73,16 @@ class FusedTrainer(object):
     """
 
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
-                 use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None):
+                 use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None, compact=False):
         """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
         products), or "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs).  dropout=False trains with every
         nn.Dropout of the model disabled; seed keys the dropout masks (default: drawn from torch's global generator);
-        gradient_clipping_norm: clip_grad_norm_ of train_utils.py:24-25 (the coefficient stays on the device)."""
+        gradient_clipping_norm: clip_grad_norm_ of train_utils.py:24-25 (the coefficient stays on the device).
+        compact=True: variable-length execution -- the valid items of each padded batch (dataset.py:28-38) are packed into
+        consecutive rows, every row-wise kernel runs over the packed rows only, attention reads per-slate extents from
+        cu_seqlens, and scores / d loss/d scores move between the packed rows and the padded [B, L] grid the loss kernels
+        work on.  Same loss and gradients as the padded step (padded rows carry no gradient and are masked as keys); the
+        row count changes per batch, so this mode runs eagerly (no hipGraph)."""
         import torch.nn as nn
         from . import _lib as LB
         from .losses import FusedLoss
@@ -155,6 +160,14 @@ class FusedTrainer(object):
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.ws_clip = torch.empty(max(self.lib.ltrx_clip_workspace_bytes(n), 64), dtype=torch.uint8, device=dev)
         self.drop_step = torch.zeros(1, dtype=torch.int32, device=dev)       # u32 word folded into every dropout seed
+        self.compact = bool(compact)
+        self.rows = B * L                                                     # rows the row-wise kernels run over
+        self.n_valid = B * L
+        self.cu = torch.zeros(B + 1, dtype=torch.int32, device=dev) if compact else None   # cu_seqlens of the packed batch
+        self.idx = torch.zeros(B * L, dtype=torch.int32, device=dev) if compact else None  # packed row -> padded row
+        if compact:
+            self._cu_ring = [(torch.zeros(B + 1, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+            self._pack_turn = 0
         # gradient buckets for the multi-GPU all-reduce, in the order the backward completes them: the tail of the flat
         # buffer (last encoder layer + final norm + head) first, then one bucket per earlier layer, the FC stack last
         offs_of = {id(p): o for p, o in zip(order, offs)}
@@ -228,6 +241,9 @@ class FusedTrainer(object):
             self.ws_ln = torch.empty(max(self.lib.ltrx_layernorm_bwd_workspace_bytes(M, d), 64), dtype=torch.uint8, device=dev)
             self.ws_mha = torch.empty(max(self.lib.ltrx_mha_bwd_workspace_bytes(B, L, self.h), 64), dtype=torch.uint8, device=dev)
         self.scores = torch.zeros((B, L), **f32)
+        if compact:
+            self.scores_c = torch.zeros(M, **f32)
+            self.dsc_c = torch.zeros(M, **f32)
         self.d_a = torch.zeros((M, d), **f32)                 # gradient w.r.t. the residual stream (ping)
         self.d_b = torch.zeros((M, d), **f32)                 # (pong)
         maxn = max([3 * d, self.dff if self.N else 0] + self.fc_sizes[1:])
@@ -270,7 +286,7 @@ class FusedTrainer(object):
             self._tn, self._ttiles = len(srcs), tstart[-1]
             self._refresh_transposes()
         self.loss = FusedLoss(loss_name, B, L, dev, **(loss_args or {}))
-        self.use_graph = use_graph
+        self.use_graph = use_graph and not compact
         self.graph = None
         self._warm = 0
 
@@ -295,14 +311,14 @@ class FusedTrainer(object):
     def _ln_fwd(self, x, res, a, b, xsum, y, mean, rstd, p=0.0, seed=0):
         """y = LN(x + drop_p(res)); xsum = x + drop_p(res)"""
         P = self.LB.ptr
-        self.LB.check(self.lib.ltrx_layernorm_fwd(P(x), P(res), P(a), P(b), self.M, self.d, float(self.ln_eps), P(xsum), P(y),
+        self.LB.check(self.lib.ltrx_layernorm_fwd(P(x), P(res), P(a), P(b), self.rows, self.d, float(self.ln_eps), P(xsum), P(y),
                                                   P(mean), P(rstd), float(p), seed, P(self.drop_step), self._st()),
                       "layernorm_fwd")
 
     def _drop_apply(self, src, dst, p, seed):
         """dst = src * keep-mask/(1-p) of the site (the backward of a dropped branch)"""
         P = self.LB.ptr
-        self.LB.check(self.lib.ltrx_dropout_apply(P(src), P(dst), src.numel(), float(p), seed, P(self.drop_step), self._st()),
+        self.LB.check(self.lib.ltrx_dropout_apply(P(src), P(dst), self.rows * src.shape[1], float(p), seed, P(self.drop_step), self._st()),
                       "dropout_apply")
 
     def _branch_grad(self, ds, p, seed):
@@ -313,18 +329,18 @@ class FusedTrainer(object):
 
     def _ln_bwd(self, dy, xsum, a, mean, rstd, dres, dx, da, db):
         P = self.LB.ptr
-        self.LB.check(self.lib.ltrx_layernorm_bwd(P(dy), P(xsum), P(a), P(mean), P(rstd), P(dres), self.M, self.d,
+        self.LB.check(self.lib.ltrx_layernorm_bwd(P(dy), P(xsum), P(a), P(mean), P(rstd), P(dres), self.rows, self.d,
                                                   float(self.ln_eps), P(dx), P(da), P(db), P(self.ws_ln), self._st()),
                       "layernorm_bwd")
 
     def _colsum(self, a, out):
         P = self.LB.ptr
-        self.LB.check(self.lib.ltrx_colsum(P(a), a.shape[0], a.shape[1], a.stride(0), P(out), 0, P(self.ws_col), self._st()),
+        self.LB.check(self.lib.ltrx_colsum(P(a), self.rows, a.shape[1], a.stride(0), P(out), 0, P(self.ws_col), self._st()),
                       "colsum")
 
     def _relu_bwd(self, dr, r, p=0.0):
         """dr *= (r > 0) / (1 - p): backward of dropout(relu(z)) given the stored post-dropout activation r"""
-        self.LB.check(self.lib.ltrx_relu_bwd(self.LB.ptr(dr), self.LB.ptr(r), dr.numel(), 1.0 / (1.0 - p), self._st()), "relu_bwd")
+        self.LB.check(self.lib.ltrx_relu_bwd(self.LB.ptr(dr), self.LB.ptr(r), self.rows * dr.shape[1], 1.0 / (1.0 - p), self._st()), "relu_bwd")
 
     def _refresh_transposes(self):
         if self.gemm == "hipblaslt":
@@ -346,14 +362,15 @@ class FusedTrainer(object):
     def _lin_fwd(self, x, w, b, out, act=0, p=0.0, seed=0):
         """out = drop_p(act(x w^T + b))   (nn.Linear forward, act 1 = ReLU; dropout in the epilogue)"""
         if self.gemm == "hipblaslt":
-            torch.addmm(b, x, w.t(), out=out)
+            n = self.rows
+            torch.addmm(b, x[:n], w.t(), out=out[:n])
             if act == 1:
-                torch.relu_(out)
+                torch.relu_(out[:n])
             if p:
                 self._drop_apply(out, out, p, seed)
             return
         P = self.LB.ptr
-        self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), P(out), out.stride(0), x.shape[0], w.shape[0],
+        self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), P(out), out.stride(0), self.rows, w.shape[0],
                                             x.shape[1], P(b), act, None, 0, float(p), seed, P(self.drop_step),
                                             1 if self.gemm == "split_bf16_strict" else 0, self._st()), "gemm_nt(fwd)")
 
@@ -362,14 +379,14 @@ class FusedTrainer(object):
         post-dropout activation that produced the layer input) the ReLU(+dropout p) backward mask is applied in the GEMM
         epilogue; without it, p > 0 re-applies the dropout mask of site ``seed`` (identity activation)."""
         if self.gemm == "hipblaslt":
-            torch.mm(dy, w, out=out)
+            torch.mm(dy[:self.rows], w, out=out[:self.rows])
             if relu_of is not None:
                 self._relu_bwd(out, relu_of, p)
             elif p:
                 self._drop_apply(out, out, p, seed)
             return
         P = self.LB.ptr
-        self.LB.check(self.lib.ltrx_gemm_nt(P(dy), dy.stride(0), P(wT), wT.stride(0), P(out), out.stride(0), dy.shape[0],
+        self.LB.check(self.lib.ltrx_gemm_nt(P(dy), dy.stride(0), P(wT), wT.stride(0), P(out), out.stride(0), self.rows,
                                             wT.shape[0], dy.shape[1], None, 2 if relu_of is not None else 0, P(relu_of),
                                             relu_of.stride(0) if relu_of is not None else 0, float(p), seed, P(self.drop_step),
                                             1 if self.gemm == "split_bf16_strict" else 0, self._st()), "gemm_nt(dgrad)")
@@ -377,18 +394,19 @@ class FusedTrainer(object):
     def _lin_wgrad(self, dy, x, gw, gb):
         """gw = dy^T x, gb = column sums of dy   (weight and bias gradients of nn.Linear)"""
         if self.gemm == "hipblaslt":
-            torch.mm(dy.t(), x, out=gw)
+            torch.mm(dy[:self.rows].t(), x[:self.rows], out=gw)
             self._colsum(dy, gb)
             return
         P = self.LB.ptr
-        self.LB.check(self.lib.ltrx_gemm_tn(P(dy), dy.stride(0), P(x), x.stride(0), P(gw), P(gb), dy.shape[0], dy.shape[1],
+        self.LB.check(self.lib.ltrx_gemm_tn(P(dy), dy.stride(0), P(x), x.stride(0), P(gw), P(gb), self.rows, dy.shape[1],
                                             x.shape[1], 1 if self.gemm == "split_bf16_strict" else 0, P(self.ws_tn), self._st()),
                       "gemm_tn(wgrad)")
 
     # ---- the step body (capturable) ----------------------------------------------------------------------------
     def _body(self):
         P = self.LB.ptr
-        lib, M, d, B, L = self.lib, self.M, self.d, self.B, self.L
+        lib, M, d, B, L = self.lib, self.rows, self.d, self.B, self.L
+        kpm = None if self.compact else self.mask                 # packed rows are all valid keys
         W, G = self.W, self.G
         fc = self.model.input_layer
         # ---------------- forward ----------------
@@ -410,9 +428,9 @@ class FusedTrainer(object):
             st["xin"] = x
             self._lin_fwd(st["xn0"], st["wqkv"], st["bqkv"], st["qkv"])
             qkv = st["qkv"]
-            self.LB.check(lib.ltrx_mha_fwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(self.mask), B, L, self.h,
+            self.LB.check(lib.ltrx_mha_fwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(kpm), B, L, self.h,
                                            d // self.h, 3 * d, P(st["o"]), d, P(st["lse"]), st["p_att"], st["s_att"],
-                                           P(self.drop_step), self._st()), "mha_fwd")
+                                           P(self.drop_step), P(self.cu), self._st()), "mha_fwd")
             lo = lay.self_attn.linears[3]
             self._lin_fwd(st["o"], W(lo.weight), W(lo.bias), self.branch)
             self._ln_fwd(x, self.branch, W(n1.a_2), W(n1.b_2), st["x1"], st["xn1"], st["mean1"], st["rstd1"],
@@ -429,12 +447,20 @@ class FusedTrainer(object):
             feat = self.xf
         else:
             feat = x
-        self.LB.check(lib.ltrx_score_head_fwd(P(feat), P(W(out.w_1.weight)), P(W(out.w_1.bias)), M, d, P(self.scores), self._st()),
-                      "score_head_fwd")
+        self.LB.check(lib.ltrx_score_head_fwd(P(feat), P(W(out.w_1.weight)), P(W(out.w_1.bias)), M, d,
+                                              P(self.scores_c if self.compact else self.scores), self._st()), "score_head_fwd")
+        if self.compact:                                          # packed scores -> the padded [B, L] grid of the loss kernels
+            self.scores.zero_()
+            self.LB.check(lib.ltrx_scatter_rows(P(self.scores_c), 1, P(self.idx), self.n_valid, 1, P(self.scores), 1, self._st()),
+                          "scatter_rows")
         # ---------------- loss (value + d/dscores) ----------------
         loss, dsc = self.loss.run(self.scores, self.y_in, self._divisor)
         # ---------------- backward ----------------
         ga, gb = self.d_a, self.d_b
+        if self.compact:                                          # d loss / d scores of the packed rows (alignment rows: 0)
+            self.LB.check(lib.ltrx_gather_rows(P(dsc), 1, P(self.idx), self.n_valid, M, 1, P(self.dsc_c), 1, self._st()),
+                          "gather_rows")
+            dsc = self.dsc_c
         self.LB.check(lib.ltrx_score_head_bwd(P(dsc), P(feat), P(W(out.w_1.weight)), M, d, P(ga), P(G(out.w_1.weight)),
                                               P(G(out.w_1.bias)), P(self.ws_head), self._st()), "score_head_bwd")
         if self.N:
@@ -461,11 +487,13 @@ class FusedTrainer(object):
                 self._lin_wgrad(db, st["o"], G(lo.weight), G(lo.bias))
                 self._lin_dgrad(db, W(lo.weight), self._wT.get(id(lo.weight)), self.d_o)
                 qkv, dq = st["qkv"], self.dqkv
-                self.LB.check(lib.ltrx_mha_bwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(self.mask), P(st["o"]),
+                self.LB.check(lib.ltrx_mha_bwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(kpm), P(st["o"]),
                                                P(self.d_o), P(st["lse"]), B, L, self.h, d // self.h, 3 * d, d, P(dq),
                                                dq.data_ptr() + 4 * d, dq.data_ptr() + 8 * d, 3 * d, st["p_att"], st["s_att"],
-                                               P(self.drop_step), P(self.ws_mha), self._st()),
+                                               P(self.drop_step), P(self.cu), P(self.ws_mha), self._st()),
                               "mha_bwd")
+                if self.compact and M > self.n_valid:              # alignment rows belong to no slate: no gradient
+                    dq[self.n_valid:M].zero_()
                 self._lin_wgrad(dq, st["xn0"], st["gwqkv"], st["gbqkv"])
                 self._lin_dgrad(dq, st["wqkv"], st.get("wqkvT"), self.tmp_d)
                 self._ln_bwd(self.tmp_d, st["xin"], W(n0.a_2), st["mean0"], st["rstd0"], ds, other, G(n0.a_2), G(n0.b_2))
@@ -518,12 +546,47 @@ class FusedTrainer(object):
             self.lr = float(lr)
             self.graph = None
 
-    def step(self, xb, yb, indices=None, global_batch=None):
+    def _pack(self, xb, lengths):
+        """compact mode: build idx / cu_seqlens for this batch and gather the valid rows of xb into x_in.  ``lengths`` (host
+        ints, one per slate; valid items first, as dataset.py:28-38 pads) avoids the one host sync that counting the
+        valid items on the device costs."""
+        B, L = self.B, self.L
+        if lengths is not None:
+            # only the B+1 prefix sums cross PCIe, from a ring of pinned staging buffers (a slot is reused after its copy
+            # has completed); the packed-row index is derived on the device
+            k = self._pack_turn % len(self._cu_ring)
+            self._pack_turn += 1
+            host, ev = self._cu_ring[k]
+            ev.synchronize()
+            lens = torch.as_tensor(lengths, dtype=torch.int32).reshape(B).clamp(max=L)
+            host[0] = 0
+            torch.cumsum(lens, 0, dtype=torch.int32, out=host[1:])
+            n = int(host[B])
+            self.cu.copy_(host, non_blocking=True)
+            ev.record()
+            self.LB.check(self.lib.ltrx_packed_row_index(self.LB.ptr(self.cu), B, L, n, self.LB.ptr(self.idx), self._st()),
+                          "packed_row_index")
+        else:
+            valid = (self.mask == 0)
+            self.cu[1:] = torch.cumsum(valid.sum(1), 0)
+            idx = torch.nonzero(valid.reshape(-1)).reshape(-1)    # (host sync: the row count sizes every launch)
+            n = int(idx.numel())
+            self.idx[:n] = idx
+        self.n_valid = n
+        self.rows = min(self.M, (n + 31) // 32 * 32)              # alignment rows (zero input, zero gradient) keep M % 32 == 0
+        F = self.x_in.shape[1]
+        self.LB.check(self.lib.ltrx_gather_rows(self.LB.ptr(xb), F, self.LB.ptr(self.idx), n, self.rows, F, self.LB.ptr(self.x_in), F,
+                                                self._st()), "gather_rows")
+
+    def step(self, xb, yb, indices=None, global_batch=None, lengths=None):
         """copy the batch into the static input buffers and run (or replay) the step; returns the device loss [1]."""
         self._divisor = float(global_batch if global_batch is not None else self.B * self.world)
-        self.x_in.copy_(xb.reshape(self.M, -1))
         self.y_in.copy_(yb)
         self.mask.copy_(yb == PADDED_Y_VALUE)
+        if self.compact:
+            self._pack(xb.reshape(self.M, -1).contiguous(), lengths)
+        else:
+            self.x_in.copy_(xb.reshape(self.M, -1))
         if not self.use_graph or self.world > 1:
             with sharding.shard_context(int(self._divisor), self.group) if self.world > 1 else _null():
                 return self._full()
@@ -551,7 +614,7 @@ class _null(object):
 # ------------------------------------------------------------------------------------------------------------------
 def fit_device(model, loss_name, loss_args, train_ds, val_ds, epochs, batch_size, slate_length, metrics=None, lr=1e-3,
                val_metric=None, early_stopping_patience=None, generator=None, use_fused=True, log=None,
-               gradient_clipping_norm=None, lr_schedule=None):
+               gradient_clipping_norm=None, lr_schedule=None, compact=False):
     """Train ``model`` on a DeviceSlates dataset; returns {"epochs", "train_loss", "val_metrics", "history"}.
 
     Per epoch: shuffled batches produced on the device (DeviceSlates.batches), one training step each (FusedTrainer when
@@ -562,7 +625,8 @@ def fit_device(model, loss_name, loss_args, train_ds, val_ds, epochs, batch_size
     scores of the TRAINING forward itself (same mode, no extra model pass): ``train_<metric>_<k>`` in
     the history is the mean over the epoch's training batches, each evaluated with the weights it was scored with.
     ``gradient_clipping_norm``: train_utils.py:24-25; ``lr_schedule(epoch) -> lr`` plays the role of the per-epoch
-    ``scheduler.step()`` (train_utils.py:117-118), e.g. ``lambda e: 1e-3 * 0.1 ** (e // 50)`` for StepLR(50, 0.1)."""
+    ``scheduler.step()`` (train_utils.py:117-118), e.g. ``lambda e: 1e-3 * 0.1 ** (e // 50)`` for StepLR(50, 0.1).
+    ``compact=True`` runs the fused step over the valid items only (FusedTrainer(compact=True))."""
     from . import losses as E
     from . import metrics as EMx
     from .data import evaluate
@@ -571,7 +635,7 @@ def fit_device(model, loss_name, loss_args, train_ds, val_ds, epochs, batch_size
     if use_fused:
         try:
             trainer = FusedTrainer(model, loss_name, loss_args, batch_size, slate_length, lr=lr, use_graph=True,
-                                   gradient_clipping_norm=gradient_clipping_norm)
+                                   gradient_clipping_norm=gradient_clipping_norm, compact=compact)
             fused = True
         except NotImplementedError:
             trainer = None

@@ -186,20 +186,23 @@ int ltrx_layernorm_bwd(const float* dy, const float* xsum, const float* a, const
  * based generator keyed by `seed` (the backward must be given the same p_drop and seed; the stream differs from torch's
  * Philox, equivalence is statistical).  lse_out[B,h,L] = log-sum-exp of the
  * scaled, masked scores (the only tensor saved for backward).  fp32 in/out; contractions on the fp32 MFMA
- * (v_mfma_f32_32x32x2_f32), exact fp32 products.  d_k % 4 == 0, d_k <= 128 (zero-padded to a multiple of 32). */
+ * (v_mfma_f32_32x32x2_f32), exact fp32 products.  d_k % 4 == 0, d_k <= 128 (zero-padded to a multiple of 32).
+ * cu_seqlens (i32[B+1] in device memory, or NULL): variable-length layout -- slate b occupies rows cu[b] .. cu[b+1]-1 of
+ * q/k/v/o (its valid items packed, ltrx_gather_rows), L is then only the maximum slate length (grid size and the stride of
+ * lse / delta); key_pad_mask may be NULL in that layout (every packed row is a valid key). */
 /* precision of the attention contractions: 0 (default) = exact fp32 MFMA (bit-exact fp32 products, error ~5e-7),
  * 1 = split-bf16 on the bf16 MFMA (3 products per fp32 product; error ~1e-5 after the softmax exponential). */
 void ltrx_mha_set_mode(int mode);
 int ltrx_mha_get_mode(void);
 int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L, int h,
                  int d_k, int row_stride, float* o, int o_row_stride, float* lse_out, float p_drop, uint32_t seed,
-                 const uint32_t* seed_step, ltrx_stream_t stream);
+                 const uint32_t* seed_step, const int32_t* cu_seqlens, ltrx_stream_t stream);
 /* backward: dq,dk,dv from do; delta_ws[B,h,L] scratch (rowsum(do*o)). */
 size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h);
 int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, const float* o,
                  const float* dout, const float* lse, int B, int L, int h, int d_k, int row_stride, int o_row_stride,
                  float* dq, float* dk, float* dv, int d_row_stride, float p_drop, uint32_t seed,
-                 const uint32_t* seed_step, void* ws, ltrx_stream_t stream);
+                 const uint32_t* seed_step, const int32_t* cu_seqlens, void* ws, ltrx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-step glue (allrank/training/train_utils.py:18-29 around the model): the pieces between the library
@@ -237,6 +240,16 @@ int ltrx_bump_u32(uint32_t* word, ltrx_stream_t stream);
  * ceil(rows/32)*ceil(cols/32) (all arrays in DEVICE memory except the scalars). */
 int ltrx_transpose_batch(const float* src_base, float* dst_base, const int64_t* desc, const int32_t* tile_start, int n,
                          int total_tiles, ltrx_stream_t stream);
+
+/* Compacted (variable-length) batches: pack the valid items of a padded [B, L] batch (dataset.py:28-38 pads with -1 rows)
+ * into consecutive rows and back.  gather: dst[i,:] = src[idx[i],:] for i < n, zero rows for n <= i < n_pad;
+ * scatter: dst[idx[i],:] = src[i,:] for i < n.  idx in DEVICE memory. */
+int ltrx_gather_rows(const float* src, int ld_src, const int32_t* idx, int n, int n_pad, int cols, float* dst, int ld_dst,
+                     ltrx_stream_t stream);
+/* idx[r] = b*L + (r - cu[b]) for packed row r of slate b (valid items first in every slate); n = cu[B]. */
+int ltrx_packed_row_index(const int32_t* cu_seqlens, int B, int L, int n, int32_t* idx, ltrx_stream_t stream);
+int ltrx_scatter_rows(const float* src, int ld_src, const int32_t* idx, int n, int cols, float* dst, int ld_dst,
+                      ltrx_stream_t stream);
 
 /* y = act(y + bias) in place over a contiguous [M,N] matrix (model.py:42-43); act 0 = identity, 1 = ReLU; N % 4 == 0. */
 int ltrx_bias_act(float* y_inout, const float* bias, int M, int N, int act, ltrx_stream_t stream);

@@ -1059,3 +1059,139 @@ def test_listwise_losses_at_the_maximum_slate_length():
         lo, go = _oracle_loss(kind, kw, s, y)
         assert close(l, lo, rtol=3e-5), (kind, l, lo)
         assert grad_close(g, go, rtol=5e-4), (kind, float(np.abs(g - go).max()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# compacted (variable-length) execution: padded slots skipped, same results
+# ---------------------------------------------------------------------------------------------------------------------
+def test_gather_scatter_rows():
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn((50, 13), generator=g).cuda()
+    idx = torch.tensor([4, 0, 49, 7, 7, 31], dtype=torch.int32).cuda()
+    dst = torch.full((8, 16), 9.0).cuda()
+    st = LB.stream_of(src)
+    LB.check(lib.ltrx_gather_rows(LB.ptr(src), 13, LB.ptr(idx), 6, 8, 13, LB.ptr(dst), 16, st), "gather_rows")
+    assert torch.equal(dst[:6, :13], src[idx.long()]) and (dst[6:8, :13] == 0).all() and (dst[:, 13:] == 9.0).all()
+    back = torch.zeros((50, 13)).cuda()
+    uniq = torch.tensor([4, 0, 49, 7, 31], dtype=torch.int32).cuda()
+    LB.check(lib.ltrx_scatter_rows(LB.ptr(dst), 16, LB.ptr(uniq), 5, 13, LB.ptr(back), 13, st), "scatter_rows")
+    assert torch.equal(back[uniq.long()], dst[:5, :13]) and int((back != 0).any(1).sum().item()) == 5
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.3])
+@pytest.mark.parametrize("B,L,h,dk,lens", [(3, 70, 4, 8, [70, 1, 33]), (4, 240, 8, 64, [240, 100, 129, 17]),
+                                           (2, 300, 2, 32, [257, 300])])
+def test_attention_varlen_matches_padded(B, L, h, dk, lens, p_drop):
+    """cu_seqlens layout (packed valid rows, no mask) == padded layout + key mask on the valid rows: forward output and
+    all three input gradients, bit for bit (same tiles, same order), dropout included (the mask hash is keyed by the
+    position inside the slate)."""
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    d = h * dk
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    qkv = torch.randn((B, L, 3 * d), generator=g).cuda()
+    do = torch.randn((B, L, d), generator=g).cuda()
+    lens_t = torch.tensor(lens)
+    mask = (torch.arange(L)[None, :] >= lens_t[:, None]).to(torch.uint8).cuda()
+    do = do * (mask == 0)[:, :, None]          # padded rows carry no gradient in the step (the loss masks them)
+    valid = (mask == 0).reshape(-1)
+    cu = torch.zeros(B + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens_t, 0)
+    n = int(cu[-1])
+    cu = cu.cuda()
+    st = LB.stream_of(qkv)
+    ws = torch.empty(max(lib.ltrx_mha_bwd_workspace_bytes(B, L, h), 64), dtype=torch.uint8, device="cuda")
+
+    def run(qkv_, do_, kpm, cu_, rows):
+        o = torch.zeros((rows, d), device="cuda")
+        lse = torch.zeros((B, h, L), device="cuda")
+        dqkv = torch.zeros((rows, 3 * d), device="cuda")
+        LB.check(lib.ltrx_mha_fwd(LB.ptr(qkv_), qkv_.data_ptr() + 4 * d, qkv_.data_ptr() + 8 * d, LB.ptr(kpm), B, L, h, dk, 3 * d,
+                                  LB.ptr(o), d, LB.ptr(lse), p_drop, 77, None, LB.ptr(cu_), st), "mha_fwd")
+        LB.check(lib.ltrx_mha_bwd(LB.ptr(qkv_), qkv_.data_ptr() + 4 * d, qkv_.data_ptr() + 8 * d, LB.ptr(kpm), LB.ptr(o), LB.ptr(do_),
+                                  LB.ptr(lse), B, L, h, dk, 3 * d, d, LB.ptr(dqkv), dqkv.data_ptr() + 4 * d, dqkv.data_ptr() + 8 * d,
+                                  3 * d, p_drop, 77, None, LB.ptr(cu_), LB.ptr(ws), st), "mha_bwd")
+        return o, dqkv
+
+    o_p, dqkv_p = run(qkv.reshape(B * L, 3 * d), do.reshape(B * L, d), mask, None, B * L)
+    qkv_c = qkv.reshape(B * L, 3 * d)[valid].contiguous()
+    do_c = do.reshape(B * L, d)[valid].contiguous()
+    o_c, dqkv_c = run(qkv_c, do_c, None, cu, n)
+    assert torch.equal(o_c, o_p[valid])
+    assert torch.equal(dqkv_c, dqkv_p[valid])
+    assert torch.isfinite(o_c).all() and torch.isfinite(dqkv_c).all()
+
+
+@pytest.mark.parametrize("gemm", ["split_bf16", "hipblaslt"])
+@pytest.mark.parametrize("loss_name,loss_args,host_lengths", [("approxNDCGLoss", {}, True), ("listNet", {}, False),
+                                                               ("lambdaLoss", dict(weighing_scheme="ndcgLoss2_scheme"), True),
+                                                               ("rankNet", {}, False)])
+def test_fused_trainer_compact_matches_padded_and_oracle(loss_name, loss_args, host_lengths, gemm):
+    """FusedTrainer(compact=True) (valid items packed, padded slots never computed) == the padded step == the oracle:
+    loss of every step, all gradients of the first step, weights after 4 steps."""
+    import copy
+    from allrank_amd.engine import FusedTrainer
+    cfg = dict(n_features=20, fc_sizes=[32], fc_activation=None, fc_input_norm=False, N=2, d_ff=64, h=4, output_activation=None)
+    params = M.init_params(cfg, seed=21)
+    m1 = _make_engine_model(cfg, params)
+    m2 = copy.deepcopy(m1)
+    rng = np.random.default_rng(22)
+    B, L = 5, 70
+    lens = [70, 3, 41, 1, 64]                   # 179 valid items -> 192 packed rows (13 alignment rows)
+    x = rng.standard_normal((B, L, 20)).astype(np.float32)
+    y = rng.integers(0, 5, (B, L)).astype(np.float32)
+    for b, n in enumerate(lens):
+        y[b, n:] = -1
+        x[b, n:] = 0
+    if not host_lengths:                        # padding need not be at the end when the trainer counts on the device
+        y[2, 5] = -1
+        x[2, 5] = 0
+    xt, yt = _t(x), _t(y)
+    fc = FusedTrainer(m1, loss_name, loss_args, B, L, lr=1e-3, gemm=gemm, compact=True)
+    fp = FusedTrainer(m2, loss_name, loss_args, B, L, lr=1e-3, gemm=gemm, use_graph=False)
+    ofn = {"approxNDCGLoss": lambda s, t: O.approxndcg(s, t), "listNet": lambda s, t: O.listnet(s, t),
+           "lambdaLoss": lambda s, t: O.lambdaloss(s, t, **loss_args), "rankNet": lambda s, t: O.ranknet(s, t)}[loss_name]
+    oopt = M.Adam(params, lr=1e-3)
+    rows = []
+    for step in range(4):
+        lc = float(fc.step(xt, yt, lengths=lens if host_lengths else None).item())
+        lp = float(fp.step(xt, yt).item())
+        lo = float(M.train_step(params, cfg, oopt, x, y, ofn)[0])
+        rows.append((lc, lp, lo))
+        tol = 1e-5 if step == 0 else 2e-3
+        assert abs(lc - lp) <= tol * (1 + abs(lp)) and abs(lc - lo) <= tol * (1 + abs(lo)), rows
+        if step == 0:
+            assert fc.n_valid == int((y != -1).sum()) and fc.rows % 32 == 0 and fc.rows < B * L
+            gscale = float(fp.flat_g.abs().max().item())
+            gerr = float((fc.flat_g - fp.flat_g).abs().max().item())
+            assert gerr <= 2e-5 * gscale + 1e-9, (gerr, gscale)
+            v = (yt != -1)
+            assert (fc.scores[v] - fp.scores[v]).abs().max().item() < 2e-5
+    _log("fused_trainer_compact_%s_%s" % (loss_name, gemm), rows)
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    for k in sd1:
+        assert (sd1[k] - sd2[k]).abs().max().item() <= 8.1e-3, k
+
+
+def test_fused_trainer_compact_dropout_trains():
+    """compact execution with the reference's dropout rates: finite, loss decreases on a fixed batch."""
+    from allrank_amd.engine import FusedTrainer
+    from allrank_amd.model import make_model
+    torch.manual_seed(5)
+    tr = dict(N=2, d_ff=64, h=4, positional_encoding=None, dropout=0.1)
+    fc = dict(sizes=[32], input_norm=False, activation=None, dropout=0.0)
+    model = make_model(fc, tr, dict(d_output=1, output_activation=None), 20).cuda()
+    rng = np.random.default_rng(6)
+    B, L = 8, 60
+    x = rng.standard_normal((B, L, 20)).astype(np.float32)
+    w = rng.standard_normal(20).astype(np.float32)
+    y = np.clip(np.round((x @ w) * 0.6 + 2), 0, 4).astype(np.float32)
+    lens = rng.integers(5, L + 1, B)
+    for b, n in enumerate(lens):
+        y[b, n:] = -1
+        x[b, n:] = 0
+    ft = FusedTrainer(model, "approxNDCGLoss", {}, B, L, lr=3e-3, compact=True, seed=9)
+    ls = [float(ft.step(_t(x), _t(y), lengths=lens.tolist()).item()) for _ in range(60)]
+    assert np.isfinite(ls).all() and np.mean(ls[-10:]) < np.mean(ls[:10]) - 0.02, (ls[:3], ls[-3:])
