@@ -438,6 +438,32 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
 
   ltrx::DropSpec dsp = drop;
   if (drop_step) dsp.seed ^= drop_step[0] * 0x9E3779B9u;
+  if (act == 2) {
+    // ReLU(+dropout) backward: the saved activation is read 16 independent loads at a time (one accumulator block), so
+    // the epilogue pays one memory latency per block instead of one per element
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wc * 64 + j * 32 + l31;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float ax[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wr * 128 + i * 32 + rowmap(r, half);
+          ax[r] = (!TAIL || row < M) ? __builtin_nontemporal_load(&aux[(size_t)row * ldaux + col]) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wr * 128 + i * 32 + rowmap(r, half);
+          if (TAIL && row >= M) continue;
+          const float v = (ax[r] > 0.f) ? (acc[i][j][r] + bv) * drop.inv_keep : 0.f;
+          __builtin_nontemporal_store(v, &C[(size_t)row * ldc + col]);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wc * 64 + j * 32 + l31;
@@ -450,8 +476,7 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
         if (TAIL && row >= M) continue;
         float v = acc[i][j][r] + bv;
         if (act == 1) v = fmaxf(v, 0.f);
-        if (act == 2) v = (aux[(size_t)row * ldaux + col] > 0.f) ? v * drop.inv_keep : 0.f;
-        else if (drop.thresh != 0u) v *= ltrx::drop_keep_scale(dsp, (uint64_t)row * (uint64_t)N + (uint64_t)col);
+        if (drop.thresh != 0u) v *= ltrx::drop_keep_scale(dsp, (uint64_t)row * (uint64_t)N + (uint64_t)col);
         __builtin_nontemporal_store(v, &C[(size_t)row * ldc + col]);
       }
   }
@@ -793,7 +818,7 @@ static int tn_splits(int M, int tiles) {
 static bool tn256_ok(int M, int NP, int KP) { return (NP % 256) == 0 && (KP % 256) == 0 && (M % 32) == 0 && M >= 2048; }
 static void tn256_plan(int M, int NP, int KP, int* splits, int* mps) {
   const int tiles = (NP / 256) * (KP / 256);
-  int sp = (256 + tiles - 1) / tiles;                 // one workgroup per CU
+  int sp = 256 / tiles;                               // one workgroup per CU and ONE round: never more than 256 workgroups
   if (sp > M / 128) sp = M / 128;                     // at least 4 K-steps per split
   if (sp < 1) sp = 1;
   int m = ((M + sp - 1) / sp + 31) / 32 * 32;
