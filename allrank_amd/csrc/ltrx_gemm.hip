@@ -30,6 +30,7 @@
 #include "ltrx_device.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -438,47 +439,62 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
 
   ltrx::DropSpec dsp = drop;
   if (drop_step) dsp.seed ^= drop_step[0] * 0x9E3779B9u;
-  if (act == 2) {
-    // ReLU(+dropout) backward: the saved activation is read 16 independent loads at a time (one accumulator block), so
-    // the epilogue pays one memory latency per block instead of one per element
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wc * 64 + j * 32 + l31;
-      const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float ax[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wr * 128 + i * 32 + rowmap(r, half);
-          ax[r] = (!TAIL || row < M) ? __builtin_nontemporal_load(&aux[(size_t)row * ldaux + col]) : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wr * 128 + i * 32 + rowmap(r, half);
-          if (TAIL && row >= M) continue;
-          const float v = (ax[r] > 0.f) ? (acc[i][j][r] + bv) * drop.inv_keep : 0.f;
-          __builtin_nontemporal_store(v, &C[(size_t)row * ldc + col]);
-        }
-      }
-    }
-    return;
-  }
+  // Epilogue with 16-byte stores.  An accumulator block keeps one COLUMN per lane (16 rows down the registers); a 4x4
+  // transpose inside each lane quad (two DPP butterflies: quad_perm [1,0,3,2] then [2,3,0,1]) turns registers 4g..4g+3 of
+  // the four lanes of a quad into 4 consecutive columns of ONE row per lane, so the tile leaves the CU as 32 dwordx4 stores
+  // per lane instead of 128 dword stores -- the vector-memory issue path is what bounds this kernel, and the saved
+  // activation of the ReLU backward (act 2) and the bias are read as float4 the same way.
+  const int q = lane & 3;
+  const bool b0 = q & 1, b1 = q & 2;
+  const int cq = l31 & ~3;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wc * 64 + j * 32 + l31;
-    const float bv = bias ? bias[col] : 0.f;
+    const int col = n0 + wc * 64 + j * 32 + cq;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      f32x4 ax[4];
+      if (act == 2) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 128 + i * 32 + rowmap(r, half);
-        if (TAIL && row >= M) continue;
-        float v = acc[i][j][r] + bv;
-        if (act == 1) v = fmaxf(v, 0.f);
-        if (drop.thresh != 0u) v *= ltrx::drop_keep_scale(dsp, (uint64_t)row * (uint64_t)N + (uint64_t)col);
-        __builtin_nontemporal_store(v, &C[(size_t)row * ldc + col]);
+        for (int g = 0; g < 4; ++g) {
+          const int row = m0 + wr * 128 + i * 32 + 8 * g + 4 * half + q;
+          ax[g] = (!TAIL || row < M) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(aux + (size_t)row * ldaux + col))
+                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float a0 = acc[i][j][4 * g + 0], a1 = acc[i][j][4 * g + 1], a2 = acc[i][j][4 * g + 2], a3 = acc[i][j][4 * g + 3];
+        // stage 1: exchange across lane bit 0
+        const float r_lo = LTRX_DPP_F(0.f, b0 ? a0 : a1, 0xB1, 0xF, true);
+        const float r_hi = LTRX_DPP_F(0.f, b0 ? a2 : a3, 0xB1, 0xF, true);
+        const float c0 = b0 ? r_lo : a0, c1 = b0 ? a1 : r_lo, c2 = b0 ? r_hi : a2, c3 = b0 ? a3 : r_hi;
+        // stage 2: exchange across lane bit 1
+        const float r_a = LTRX_DPP_F(0.f, b1 ? c0 : c2, 0x4E, 0xF, true);
+        const float r_b = LTRX_DPP_F(0.f, b1 ? c1 : c3, 0x4E, 0xF, true);
+        f32x4 v = {b1 ? r_a : c0, b1 ? r_b : c1, b1 ? c2 : r_a, b1 ? c3 : r_b};   // row q, columns col..col+3
+        const int row = m0 + wr * 128 + i * 32 + 8 * g + 4 * half + q;
+        if (TAIL && row >= M) continue;
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (act == 1) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (act == 2) {
+          v.x = (ax[g].x > 0.f) ? v.x * drop.inv_keep : 0.f;
+          v.y = (ax[g].y > 0.f) ? v.y * drop.inv_keep : 0.f;
+          v.z = (ax[g].z > 0.f) ? v.z * drop.inv_keep : 0.f;
+          v.w = (ax[g].w > 0.f) ? v.w * drop.inv_keep : 0.f;
+        } else if (drop.thresh != 0u) {
+          const uint64_t e = (uint64_t)row * (uint64_t)N + (uint64_t)col;
+          v.x *= ltrx::drop_keep_scale(dsp, e);
+          v.y *= ltrx::drop_keep_scale(dsp, e + 1);
+          v.z *= ltrx::drop_keep_scale(dsp, e + 2);
+          v.w *= ltrx::drop_keep_scale(dsp, e + 3);
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(C + (size_t)row * ldc + col));
+      }
+    }
   }
 }
 
@@ -757,7 +773,9 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
     ldb = 0;
   }
   // large-tile kernel: exact multiples only, and enough tiles to cover the 256 CUs at least ~1.4 times
-  if (v == 0 && !strict && (N % 256) == 0 && (K % 32) == 0) {
+  const bool vec_epi = (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
+                       (!aux || ((ldaux & 3) == 0 && ((uintptr_t)aux & 15) == 0));      // 16-byte epilogue accesses
+  if (v == 0 && !strict && (N % 256) == 0 && (K % 32) == 0 && vec_epi) {
     // one workgroup per CU: a grid that fills 3/4 .. 1 round, or at least ~1.4 rounds (measured, tools/gemm_variants.py:
     // 240 tiles 53 vs 77 us, 360 tiles parity, 120 tiles parity, 480 tiles 102 vs 132 us)
     const size_t t = (size_t)((M + 255) / 256) * (N / 256);
@@ -765,7 +783,7 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
   }
   if (v == 0) v = 1;
   if (v == 6) {
-    if ((N % 256) || (K % 32) || strict) return LTRX_EUNSUPPORTED;
+    if ((N % 256) || (K % 32) || strict || !vec_epi) return LTRX_EUNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
       if (hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
