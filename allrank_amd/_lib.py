@@ -45,7 +45,7 @@ SIGNATURES = {
     "ltrx_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_mha_set_mode": (None, [_i]),
     "ltrx_mha_get_mode": (_i, []),
-    "ltrx_mha_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _f, ctypes.c_uint32, _vp, _vp, _vp]),
+    "ltrx_mha_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _f, ctypes.c_uint32, _vp, _vp, _vp, _vp]),
     "ltrx_mha_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltrx_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp, _f, _vp, _vp]),
     "ltrx_clip_workspace_bytes": (_sz, [_sz]),
@@ -68,7 +68,7 @@ SIGNATURES = {
     "ltrx_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltrx_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ltrx_selftest_mfma32x32x2": (_i, [_vp, _vp, _vp, _vp]),
-    "ltrx_mha_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, ctypes.c_uint32, _vp, _vp, _vp, _vp]),
+    "ltrx_mha_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -226,12 +226,14 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
                                                               int rs, float* __restrict__ o, int ors,
                                                               float* __restrict__ lse, float scale, DropCfg drop,
                                                               const uint32_t* __restrict__ drop_step,
-                                                              const int* __restrict__ cu) {
+                                                              const int* __restrict__ cu, const int* __restrict__ order) {
   if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   __shared__ __attribute__((aligned(16))) float ktile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float vtile[Tile<DKP>::FLOATS];
   __shared__ float kmask[32];
-  const int b = blockIdx.y / h, head = blockIdx.y % h;
+  const int head = blockIdx.y % h;
+  const int b = order ? order[blockIdx.y / h] : (int)(blockIdx.y / h);   // launch order (longest slates first) -> slate
+  const int bh = b * h + head;
   const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
   const int q0 = blockIdx.x * 128 + wave * 32;
   // variable-length (compacted) batches: cu[b] = first row of slate b, cu[b+1] - cu[b] its item count; L stays the stride of
@@ -249,7 +251,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
   f32x16 oacc[DKP / 32];
   zero_acc<DKP>(oacc);
   float m = -INFINITY, l = 0.f;        // running max (log2 domain) and normaliser
-  const uint32_t drow = DROP ? drop_row_seed(drop, blockIdx.y, Lmax, q0 + (lane & 31)) : 0u;
+  const uint32_t drow = DROP ? drop_row_seed(drop, bh, Lmax, q0 + (lane & 31)) : 0u;
   const float sl2 = scale * kLog2e;
 
   const int nkt = (L + 31) / 32;
@@ -315,14 +317,16 @@ __global__ void __launch_bounds__(256, (DKP <= 64) ? 3 : 2) ltrx_mha_bwd_dq_kern
     const uint8_t* __restrict__ kpm, const float* __restrict__ o, const float* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ delta, int L, int h, int dk, int rs, int ors,
     float* __restrict__ dq, int drs, float scale, DropCfg drop, const uint32_t* __restrict__ drop_step,
-    const int* __restrict__ cu) {
+    const int* __restrict__ cu, const int* __restrict__ order) {
   if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   __shared__ __attribute__((aligned(16))) float ktile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float vtile[Tile<DKP>::FLOATS];
   __shared__ float kmask[32];
   // dO rows of the workgroup's 128 queries (the fixed operand of dP = dO V^T), one 32-row image per wave
   __shared__ __attribute__((aligned(16))) float doimg[4 * Tile<DKP>::FLOATS];
-  const int b = blockIdx.y / h, head = blockIdx.y % h;
+  const int head = blockIdx.y % h;
+  const int b = order ? order[blockIdx.y / h] : (int)(blockIdx.y / h);   // launch order (longest slates first) -> slate
+  const int bh = b * h + head;
   const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
   const int q0 = blockIdx.x * 128 + wave * 32;
   // variable-length (compacted) batches: cu[b] = first row of slate b, cu[b+1] - cu[b] its item count; L stays the stride of
@@ -339,7 +343,7 @@ __global__ void __launch_bounds__(256, (DKP <= 64) ? 3 : 2) ltrx_mha_bwd_dq_kern
   const int qrow = q0 + (lane & 31);
   const size_t stat = ((size_t)b * h + head) * Lmax + qrow;
   const float lse_q = (qrow < L) ? lse[stat] * kLog2e : 0.f;          // log2 domain
-  const uint32_t drow = DROP ? drop_row_seed(drop, blockIdx.y, Lmax, qrow) : 0u;
+  const uint32_t drow = DROP ? drop_row_seed(drop, bh, Lmax, qrow) : 0u;
   const float sl2 = scale * kLog2e;
   // delta_q = <dO_q, O_q> (rowsum(dP * P)); each half-wave holds half of the head dimension.  Published for the
   // dK/dV kernel, which is launched after this one on the same stream.
@@ -399,14 +403,16 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dkdv_kernel(
     const uint8_t* __restrict__ kpm, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, int L, int h, int dk, int rs, int ors, float* __restrict__ dkout,
     float* __restrict__ dvout, int drs, float scale, DropCfg drop, const uint32_t* __restrict__ drop_step,
-    const int* __restrict__ cu) {
+    const int* __restrict__ cu, const int* __restrict__ order) {
   if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   __shared__ __attribute__((aligned(16))) float qtile[Tile<DKP>::FLOATS];
   __shared__ __attribute__((aligned(16))) float dotile[Tile<DKP>::FLOATS];
   __shared__ float lse_t[32];
   __shared__ float del_t[32];
   __shared__ uint32_t drow_t[32];
-  const int b = blockIdx.y / h, head = blockIdx.y % h;
+  const int head = blockIdx.y % h;
+  const int b = order ? order[blockIdx.y / h] : (int)(blockIdx.y / h);   // launch order (longest slates first) -> slate
+  const int bh = b * h + head;
   const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
   const int k0 = blockIdx.x * 128 + wave * 32;
   // variable-length (compacted) batches: cu[b] = first row of slate b, cu[b+1] - cu[b] its item count; L stays the stride of
@@ -440,7 +446,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dkdv_kernel(
       const int qrow = qt * 32 + threadIdx.x;
       lse_t[threadIdx.x] = (qrow < L) ? lse[statb + qrow] * kLog2e : INFINITY;   // +inf -> P = exp2(-inf) = 0 for rows >= L
       del_t[threadIdx.x] = (qrow < L) ? delta[statb + qrow] : 0.f;
-      if (DROP) drow_t[threadIdx.x] = drop_row_seed(drop, blockIdx.y, Lmax, qrow);
+      if (DROP) drow_t[threadIdx.x] = drop_row_seed(drop, bh, Lmax, qrow);
     }
     __syncthreads();
     if (qt + 1 < nqt) {
@@ -522,12 +528,13 @@ static DropCfg make_drop(float p_drop, uint32_t seed) { return ltrx_make_drop(p_
 
 extern "C" int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L,
                             int h, int d_k, int row_stride, float* o, int o_row_stride, float* lse_out, float p_drop,
-                            uint32_t seed, const uint32_t* seed_step, const int32_t* cu_seqlens, ltrx_stream_t stream) {
+                            uint32_t seed, const uint32_t* seed_step, const int32_t* cu_seqlens, const int32_t* slate_order,
+                            ltrx_stream_t stream) {
   if (!q || !k || !v || (!key_pad_mask && !cu_seqlens) || !o || !lse_out || !(p_drop >= 0.f) || p_drop >= 1.f) return LTRX_EINVAL;
   int rc = mha_check(B, L, h, d_k, row_stride, o_row_stride);
   if (rc != LTRX_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (g_mha_mode == 1 && p_drop == 0.f && !cu_seqlens)      // (dropout / variable-length batches: exact-fp32 kernels only)
+  if (g_mha_mode == 1 && p_drop == 0.f && !cu_seqlens && !slate_order)      // (dropout / variable-length batches: exact-fp32 kernels only)
     return ltrx_mha_fwd_bf16_launch(q, k, v, key_pad_mask, B, L, h, d_k, row_stride, o, o_row_stride, lse_out, s);
   const DropCfg drop = make_drop(p_drop, seed);
   const dim3 grid((L + 127) / 128, B * h);
@@ -535,10 +542,10 @@ extern "C" int ltrx_mha_fwd(const float* q, const float* k, const float* v, cons
 #define CALL(DKP)                                                                                                 \
   if (drop.thresh != 0u)                                                                                          \
     hipLaunchKernelGGL((ltrx_mha_fwd_kernel<DKP, true>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, L, h, d_k, row_stride, \
-                       o, o_row_stride, lse_out, scale, drop, seed_step, cu_seqlens);                              \
+                       o, o_row_stride, lse_out, scale, drop, seed_step, cu_seqlens, slate_order);                              \
   else                                                                                                            \
     hipLaunchKernelGGL((ltrx_mha_fwd_kernel<DKP, false>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, L, h, d_k, row_stride, \
-                       o, o_row_stride, lse_out, scale, drop, seed_step, cu_seqlens)
+                       o, o_row_stride, lse_out, scale, drop, seed_step, cu_seqlens, slate_order)
   LTRX_DKP_DISPATCH(d_k, CALL);
 #undef CALL
   LTRX_LAUNCH_CHECK();
@@ -553,8 +560,8 @@ extern "C" size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h) {
 extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, const float* o,
                             const float* dout, const float* lse, int B, int L, int h, int d_k, int row_stride,
                             int o_row_stride, float* dq, float* dk, float* dv, int d_row_stride, float p_drop,
-                            uint32_t seed, const uint32_t* seed_step, const int32_t* cu_seqlens, void* ws,
-                            ltrx_stream_t stream) {
+                            uint32_t seed, const uint32_t* seed_step, const int32_t* cu_seqlens, const int32_t* slate_order,
+                            void* ws, ltrx_stream_t stream) {
   if (!q || !k || !v || (!key_pad_mask && !cu_seqlens) || !o || !dout || !lse || !dq || !dk || !dv || !ws) return LTRX_EINVAL;
   if (!(p_drop >= 0.f) || p_drop >= 1.f) return LTRX_EINVAL;
   int rc = mha_check(B, L, h, d_k, row_stride, o_row_stride);
@@ -562,7 +569,7 @@ extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, cons
   if (d_row_stride % 4 != 0 || d_row_stride < h * d_k) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* delta = (float*)ws;
-  if (g_mha_mode == 1 && p_drop == 0.f && !cu_seqlens)
+  if (g_mha_mode == 1 && p_drop == 0.f && !cu_seqlens && !slate_order)
     return ltrx_mha_bwd_bf16_launch(q, k, v, key_pad_mask, o, dout, lse, B, L, h, d_k, row_stride, o_row_stride, dq, dk, dv,
                                     d_row_stride, delta, s);
   const DropCfg drop = make_drop(p_drop, seed);
@@ -571,20 +578,20 @@ extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, cons
 #define CALLQ(DKP)                                                                                                   \
   if (drop.thresh != 0u)                                                                                             \
     hipLaunchKernelGGL((ltrx_mha_bwd_dq_kernel<DKP, true>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, o, dout, lse, delta, \
-                       L, h, d_k, row_stride, o_row_stride, dq, d_row_stride, scale, drop, seed_step, cu_seqlens);    \
+                       L, h, d_k, row_stride, o_row_stride, dq, d_row_stride, scale, drop, seed_step, cu_seqlens, slate_order);    \
   else                                                                                                               \
     hipLaunchKernelGGL((ltrx_mha_bwd_dq_kernel<DKP, false>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, o, dout, lse, delta, \
-                       L, h, d_k, row_stride, o_row_stride, dq, d_row_stride, scale, drop, seed_step, cu_seqlens)
+                       L, h, d_k, row_stride, o_row_stride, dq, d_row_stride, scale, drop, seed_step, cu_seqlens, slate_order)
   LTRX_DKP_DISPATCH(d_k, CALLQ);
 #undef CALLQ
   LTRX_LAUNCH_CHECK();
 #define CALLK(DKP)                                                                                                     \
   if (drop.thresh != 0u)                                                                                               \
     hipLaunchKernelGGL((ltrx_mha_bwd_dkdv_kernel<DKP, true>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, dout, lse, delta, L, \
-                       h, d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale, drop, seed_step, cu_seqlens);      \
+                       h, d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale, drop, seed_step, cu_seqlens, slate_order);      \
   else                                                                                                                 \
     hipLaunchKernelGGL((ltrx_mha_bwd_dkdv_kernel<DKP, false>), grid, dim3(256), 0, s, q, k, v, key_pad_mask, dout, lse, delta, L, \
-                       h, d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale, drop, seed_step, cu_seqlens)
+                       h, d_k, row_stride, o_row_stride, dk, dv, d_row_stride, scale, drop, seed_step, cu_seqlens, slate_order)
   LTRX_DKP_DISPATCH(d_k, CALLK);
 #undef CALLK
   LTRX_LAUNCH_CHECK();

@@ -163,10 +163,13 @@ class FusedTrainer(object):
         self.compact = bool(compact)
         self.rows = B * L                                                     # rows the row-wise kernels run over
         self.n_valid = B * L
-        self.cu = torch.zeros(B + 1, dtype=torch.int32, device=dev) if compact else None   # cu_seqlens of the packed batch
+        # cu_seqlens of the packed batch and the attention launch order (longest slate first), one buffer / one copy
+        self._cuord = torch.zeros(2 * B + 1, dtype=torch.int32, device=dev) if compact else None
+        self.cu = self._cuord[:B + 1] if compact else None
+        self.order = self._cuord[B + 1:] if compact else None
         self.idx = torch.zeros(B * L, dtype=torch.int32, device=dev) if compact else None  # packed row -> padded row
         if compact:
-            self._cu_ring = [(torch.zeros(B + 1, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+            self._cu_ring = [(torch.zeros(2 * B + 1, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(4)]
             self._pack_turn = 0
         # gradient buckets for the multi-GPU all-reduce, in the order the backward completes them: the tail of the flat
         # buffer (last encoder layer + final norm + head) first, then one bucket per earlier layer, the FC stack last
@@ -430,7 +433,7 @@ class FusedTrainer(object):
             qkv = st["qkv"]
             self.LB.check(lib.ltrx_mha_fwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(kpm), B, L, self.h,
                                            d // self.h, 3 * d, P(st["o"]), d, P(st["lse"]), st["p_att"], st["s_att"],
-                                           P(self.drop_step), P(self.cu), self._st()), "mha_fwd")
+                                           P(self.drop_step), P(self.cu), P(self.order), self._st()), "mha_fwd")
             lo = lay.self_attn.linears[3]
             self._lin_fwd(st["o"], W(lo.weight), W(lo.bias), self.branch)
             self._ln_fwd(x, self.branch, W(n1.a_2), W(n1.b_2), st["x1"], st["xn1"], st["mean1"], st["rstd1"],
@@ -490,7 +493,7 @@ class FusedTrainer(object):
                 self.LB.check(lib.ltrx_mha_bwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(kpm), P(st["o"]),
                                                P(self.d_o), P(st["lse"]), B, L, self.h, d // self.h, 3 * d, d, P(dq),
                                                dq.data_ptr() + 4 * d, dq.data_ptr() + 8 * d, 3 * d, st["p_att"], st["s_att"],
-                                               P(self.drop_step), P(self.cu), P(self.ws_mha), self._st()),
+                                               P(self.drop_step), P(self.cu), P(self.order), P(self.ws_mha), self._st()),
                               "mha_bwd")
                 if self.compact and M > self.n_valid:              # alignment rows belong to no slate: no gradient
                     dq[self.n_valid:M].zero_()
@@ -560,15 +563,18 @@ class FusedTrainer(object):
             ev.synchronize()
             lens = torch.as_tensor(lengths, dtype=torch.int32).reshape(B).clamp(max=L)
             host[0] = 0
-            torch.cumsum(lens, 0, dtype=torch.int32, out=host[1:])
+            torch.cumsum(lens, 0, dtype=torch.int32, out=host[1:B + 1])
+            host[B + 1:] = torch.argsort(lens, descending=True, stable=True)
             n = int(host[B])
-            self.cu.copy_(host, non_blocking=True)
+            self._cuord.copy_(host, non_blocking=True)
             ev.record()
             self.LB.check(self.lib.ltrx_packed_row_index(self.LB.ptr(self.cu), B, L, n, self.LB.ptr(self.idx), self._st()),
                           "packed_row_index")
         else:
             valid = (self.mask == 0)
-            self.cu[1:] = torch.cumsum(valid.sum(1), 0)
+            cnt = valid.sum(1)
+            self.cu[1:] = torch.cumsum(cnt, 0)
+            self.order.copy_(torch.argsort(cnt, descending=True, stable=True))
             idx = torch.nonzero(valid.reshape(-1)).reshape(-1)    # (host sync: the row count sizes every launch)
             n = int(idx.numel())
             self.idx[:n] = idx

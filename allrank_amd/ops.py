@@ -83,7 +83,7 @@ class _AttentionFn(torch.autograd.Function):
         o = torch.empty((B, SL, d), dtype=torch.float32, device=q.device)
         lse = torch.empty((B, h, SL), dtype=torch.float32, device=q.device)
         L.check(L.lib().ltrx_mha_fwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), B, SL, h, dk, rs, L.ptr(o), d, L.ptr(lse),
-                                     float(p_drop), int(seed) & 0xFFFFFFFF, None, None, L.stream_of(q)), "mha_fwd")
+                                     float(p_drop), int(seed) & 0xFFFFFFFF, None, None, None, L.stream_of(q)), "mha_fwd")
         ctx.save_for_backward(q, k, v, mask, o, lse)
         ctx.h = h
         ctx.p_drop, ctx.seed = float(p_drop), int(seed) & 0xFFFFFFFF
@@ -102,7 +102,7 @@ class _AttentionFn(torch.autograd.Function):
         lib = L.lib()
         ws = L.workspace(lib.ltrx_mha_bwd_workspace_bytes(B, SL, h), o)
         L.check(lib.ltrx_mha_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), L.ptr(o), L.ptr(do), L.ptr(lse), B, SL, h, dk_,
-                                 q.stride(1), d, L.ptr(dq), L.ptr(dkk), L.ptr(dv), 3 * d, ctx.p_drop, ctx.seed, None, None, L.ptr(ws),
+                                 q.stride(1), d, L.ptr(dq), L.ptr(dkk), L.ptr(dv), 3 * d, ctx.p_drop, ctx.seed, None, None, None, L.ptr(ws),
                                  L.stream_of(o)), "mha_bwd")
         return dq, dkk, dv, None, None, None, None
 

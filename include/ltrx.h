@@ -189,20 +189,23 @@ int ltrx_layernorm_bwd(const float* dy, const float* xsum, const float* a, const
  * (v_mfma_f32_32x32x2_f32), exact fp32 products.  d_k % 4 == 0, d_k <= 128 (zero-padded to a multiple of 32).
  * cu_seqlens (i32[B+1] in device memory, or NULL): variable-length layout -- slate b occupies rows cu[b] .. cu[b+1]-1 of
  * q/k/v/o (its valid items packed, ltrx_gather_rows), L is then only the maximum slate length (grid size and the stride of
- * lse / delta); key_pad_mask may be NULL in that layout (every packed row is a valid key). */
+ * lse / delta); key_pad_mask may be NULL in that layout (every packed row is a valid key).
+ * slate_order (i32[B] in device memory, or NULL): a permutation of the slates giving the order in which their workgroups are
+ * launched -- longest first balances the CUs on ragged batches; results do not depend on it. */
 /* precision of the attention contractions: 0 (default) = exact fp32 MFMA (bit-exact fp32 products, error ~5e-7),
  * 1 = split-bf16 on the bf16 MFMA (3 products per fp32 product; error ~1e-5 after the softmax exponential). */
 void ltrx_mha_set_mode(int mode);
 int ltrx_mha_get_mode(void);
 int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L, int h,
                  int d_k, int row_stride, float* o, int o_row_stride, float* lse_out, float p_drop, uint32_t seed,
-                 const uint32_t* seed_step, const int32_t* cu_seqlens, ltrx_stream_t stream);
+                 const uint32_t* seed_step, const int32_t* cu_seqlens, const int32_t* slate_order, ltrx_stream_t stream);
 /* backward: dq,dk,dv from do; delta_ws[B,h,L] scratch (rowsum(do*o)). */
 size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h);
 int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, const float* o,
                  const float* dout, const float* lse, int B, int L, int h, int d_k, int row_stride, int o_row_stride,
                  float* dq, float* dk, float* dv, int d_row_stride, float p_drop, uint32_t seed,
-                 const uint32_t* seed_step, const int32_t* cu_seqlens, void* ws, ltrx_stream_t stream);
+                 const uint32_t* seed_step, const int32_t* cu_seqlens, const int32_t* slate_order, void* ws,
+                 ltrx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-step glue (allrank/training/train_utils.py:18-29 around the model): the pieces between the library

@@ -46,7 +46,7 @@ def test_workspace_queries_and_argument_validation_run_without_a_gpu(libpath):
     assert lib.ltrx_mha_bwd_workspace_bytes(64, 240, 8) == 64 * 240 * 8 * 4
     # NULL pointers / bad shapes are rejected before any HIP call
     assert lib.ltrx_listnet_fwd_bwd(None, None, 1, 1, 1e-10, -1.0, 1.0, None, None, None, None, None) == -1
-    assert lib.ltrx_mha_fwd(None, None, None, None, 1, 1, 1, 64, 64, None, 64, None, 0.0, 0, None, None, None) == -1
+    assert lib.ltrx_mha_fwd(None, None, None, None, 1, 1, 1, 64, 64, None, 64, None, 0.0, 0, None, None, None, None) == -1
 
 
 def test_loss_signatures_mirror_reference():

@@ -1104,15 +1104,15 @@ def test_attention_varlen_matches_padded(B, L, h, dk, lens, p_drop):
     st = LB.stream_of(qkv)
     ws = torch.empty(max(lib.ltrx_mha_bwd_workspace_bytes(B, L, h), 64), dtype=torch.uint8, device="cuda")
 
-    def run(qkv_, do_, kpm, cu_, rows):
+    def run(qkv_, do_, kpm, cu_, rows, order_=None):
         o = torch.zeros((rows, d), device="cuda")
         lse = torch.zeros((B, h, L), device="cuda")
         dqkv = torch.zeros((rows, 3 * d), device="cuda")
         LB.check(lib.ltrx_mha_fwd(LB.ptr(qkv_), qkv_.data_ptr() + 4 * d, qkv_.data_ptr() + 8 * d, LB.ptr(kpm), B, L, h, dk, 3 * d,
-                                  LB.ptr(o), d, LB.ptr(lse), p_drop, 77, None, LB.ptr(cu_), st), "mha_fwd")
+                                  LB.ptr(o), d, LB.ptr(lse), p_drop, 77, None, LB.ptr(cu_), LB.ptr(order_), st), "mha_fwd")
         LB.check(lib.ltrx_mha_bwd(LB.ptr(qkv_), qkv_.data_ptr() + 4 * d, qkv_.data_ptr() + 8 * d, LB.ptr(kpm), LB.ptr(o), LB.ptr(do_),
                                   LB.ptr(lse), B, L, h, dk, 3 * d, d, LB.ptr(dqkv), dqkv.data_ptr() + 4 * d, dqkv.data_ptr() + 8 * d,
-                                  3 * d, p_drop, 77, None, LB.ptr(cu_), LB.ptr(ws), st), "mha_bwd")
+                                  3 * d, p_drop, 77, None, LB.ptr(cu_), LB.ptr(order_), LB.ptr(ws), st), "mha_bwd")
         return o, dqkv
 
     o_p, dqkv_p = run(qkv.reshape(B * L, 3 * d), do.reshape(B * L, d), mask, None, B * L)
@@ -1122,6 +1122,11 @@ def test_attention_varlen_matches_padded(B, L, h, dk, lens, p_drop):
     assert torch.equal(o_c, o_p[valid])
     assert torch.equal(dqkv_c, dqkv_p[valid])
     assert torch.isfinite(o_c).all() and torch.isfinite(dqkv_c).all()
+    order = torch.argsort(lens_t, descending=True).to(torch.int32).cuda()        # launch order: results unchanged
+    o_s, dqkv_s = run(qkv_c, do_c, None, cu, n, order)
+    assert torch.equal(o_s, o_c) and torch.equal(dqkv_s, dqkv_c)
+    o_s, dqkv_s = run(qkv.reshape(B * L, 3 * d), do.reshape(B * L, d), mask, None, B * L, order)
+    assert torch.equal(o_s, o_p) and torch.equal(dqkv_s, dqkv_p)
 
 
 @pytest.mark.parametrize("gemm", ["split_bf16", "hipblaslt"])
