@@ -290,6 +290,7 @@ class FusedTrainer(object):
             self._refresh_transposes()
         self.loss = FusedLoss(loss_name, B, L, dev, **(loss_args or {}))
         self.use_graph = use_graph and not compact
+        self.probe = None                                     # list collecting (start, end) events of the FFN1 GEMM (eager steps only)
         self.graph = None
         self._warm = 0
 
@@ -439,7 +440,13 @@ class FusedTrainer(object):
             self._ln_fwd(x, self.branch, W(n1.a_2), W(n1.b_2), st["x1"], st["xn1"], st["mean1"], st["rstd1"],
                          st["p_s0"], st["s_s0"])
             ff = lay.feed_forward
+            if self.probe is not None:                            # bench.py: HIP events around the roofline kernel, in the step
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             self._lin_fwd(st["xn1"], W(ff.w_1.weight), W(ff.w_1.bias), st["r"], 1, st["p_ff"], st["s_ff"])
+            if self.probe is not None:
+                ev1.record()
+                self.probe.append((ev0, ev1))
             self._lin_fwd(st["r"], W(ff.w_2.weight), W(ff.w_2.bias), self.branch)
             x = st["x1"]
             p_prev, s_prev = st["p_s1"], st["s_s1"]
