@@ -1200,3 +1200,71 @@ def test_fused_trainer_compact_dropout_trains():
     ft = FusedTrainer(model, "approxNDCGLoss", {}, B, L, lr=3e-3, compact=True, seed=9)
     ls = [float(ft.step(_t(x), _t(y), lengths=lens.tolist()).item()) for _ in range(60)]
     assert np.isfinite(ls).all() and np.mean(ls[-10:]) < np.mean(ls[:10]) - 0.02, (ls[:3], ls[-3:])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the whole training step at BASELINE.json's full size (config 3, 256 slates x 240 items): size-independent properties
+# ---------------------------------------------------------------------------------------------------------------------
+def test_full_size_step_properties():
+    """The numpy oracle needs minutes at this size, so the full-size step is checked through properties the domain offers:
+    (1) slates are independent -- the batch loss is the mean of the losses of its four 64-slate quarters and the gradient
+    the mean of theirs; (2) shuffling the slates of the batch changes neither; (3) with no positional encoding the model is
+    equivariant and ApproxNDCG invariant under a permutation of the items of each slate; (4) padded slots contribute
+    nothing -- the variable-length step on a ragged version of the batch equals the padded step."""
+    import copy
+    import bench
+    from allrank_amd.engine import FusedTrainer
+    w = bench.WORKLOADS["attn_approxndcg"]
+    B, L, F = 256, 240, w["n_features"]
+    dev = torch.device(DEV)
+    GT = 5e-4          # gradients: sums over 61440 rows of fp32-class products in a different order, relative to the largest entry
+    x, y, _ = bench.synth_batch(B, L, F, 123, dev)
+    model0 = bench.build_model(w, dev, 0.0)
+
+    def first_step(xb, yb, nb, **kw):
+        """loss, flat gradient and scores of ONE step from the common initial weights"""
+        m = copy.deepcopy(model0)
+        tr = FusedTrainer(m, w["loss"], {}, nb, L, lr=1e-3, use_graph=False, **kw)
+        lengths = kw.pop("lengths", None)
+        loss = tr.step(xb, yb) if not tr.compact else tr.step(xb, yb, lengths=(yb != -1).sum(1).cpu())
+        out = (float(loss.item()), tr.flat_g.clone(), tr.scores.clone())
+        del tr, m
+        return out
+
+    l_all, g_all, s_all = first_step(x, y, B)
+    gscale = float(g_all.abs().max().item())
+    assert np.isfinite(l_all) and gscale > 0
+    # (1) quarters
+    lq, gq = [], []
+    for i in range(4):
+        l_i, g_i, s_i = first_step(x[64 * i:64 * i + 64], y[64 * i:64 * i + 64], 64)
+        lq.append(l_i)
+        gq.append(g_i)
+        assert (s_i - s_all[64 * i:64 * i + 64]).abs().max().item() < 2e-5
+    assert abs(np.mean(lq) - l_all) <= 1e-5 * (1 + abs(l_all)), (lq, l_all)
+    gmean = torch.stack(gq).mean(0)
+    assert (gmean - g_all).abs().max().item() <= GT * gscale, ((gmean - g_all).abs().max().item(), gscale)
+    # (2) slate shuffle
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5)).to(dev)
+    l_p, g_p, s_p = first_step(x[perm], y[perm], B)
+    assert abs(l_p - l_all) <= 1e-5 * (1 + abs(l_all))
+    assert (s_p - s_all[perm]).abs().max().item() < 2e-5
+    assert (g_p - g_all).abs().max().item() <= GT * gscale
+    # (3) item permutation inside every slate
+    ip = torch.argsort(torch.rand((B, L), generator=torch.Generator().manual_seed(6)), dim=1).to(dev)
+    xi = torch.gather(x, 1, ip[:, :, None].expand(B, L, F))
+    yi = torch.gather(y, 1, ip)
+    l_i, g_i, s_i = first_step(xi, yi, B)
+    assert abs(l_i - l_all) <= 1e-5 * (1 + abs(l_all)), (l_i, l_all)
+    assert (s_i - torch.gather(s_all, 1, ip)).abs().max().item() < 2e-5
+    assert (g_i - g_all).abs().max().item() <= GT * gscale
+    # (4) ragged batch: variable-length execution == padded execution
+    xr, yr, _ = bench.synth_batch(B, L, F, 124, dev, ragged=True)
+    l_pad, g_pad, s_pad = first_step(xr, yr, B)
+    l_c, g_c, s_c = first_step(xr, yr, B, compact=True)
+    v = yr != -1
+    assert abs(l_c - l_pad) <= 1e-5 * (1 + abs(l_pad)), (l_c, l_pad)
+    assert (s_c[v] - s_pad[v]).abs().max().item() < 2e-5
+    gs = float(g_pad.abs().max().item())
+    assert (g_c - g_pad).abs().max().item() <= GT * gs
+    _log("full_size_step_properties", dict(loss=l_all, quarter_losses=lq, shuffled=l_p, item_permuted=l_i, padded=l_pad, compact=l_c))
