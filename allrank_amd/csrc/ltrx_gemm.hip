@@ -333,18 +333,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // the chip (a ragged last row tile is handled by clamped loads and guarded stores); everything else (and the strict
 // 3-term mode, whose LDS images do not fit twice) stays on the kernel above.
 // ------------------------------------------------------------------------------------------------------------------
-struct Smem256 {
-  __bf16 a[2][256 * 32];
-  __bf16 b[2][256 * 32];
-};
-
 __device__ __forceinline__ void lds_only_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <bool TAIL>
+// BM = 256 (wave tile 128 x 64) or 128 (wave tile 64 x 64, 96 KB of LDS): the 128-row variant is for shapes whose 256-row
+// tiling would leave half of the CUs without a tile (M 15360 x N 512: 120 tiles of 256 x 256, 240 of 128 x 256)
+template <int BM>
+struct SmemNT {
+  __bf16 a[2][BM * 32];
+  __bf16 b[2][256 * 32];
+};
+
+template <bool TAIL, int BM>
 __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                               int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
                                                               const float* __restrict__ bias, int act,
@@ -352,13 +355,15 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
                                                               ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step) {
   constexpr int BK_ = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  Smem256* s = reinterpret_cast<Smem256*>(smem_raw);
+  typedef SmemNT<BM> SmemT;
+  constexpr int RI = BM / 64;          // 32-row accumulator blocks per wave (two wave rows)
+  SmemT* s = reinterpret_cast<SmemT*>(smem_raw);
   const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (id / tiles_n) * 256, n0 = (id % tiles_n) * 256;
+  const int m0 = (id / tiles_n) * BM, n0 = (id % tiles_n) * 256;
   const int wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
   const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
   const int srow = threadIdx.x >> 3, sc4 = (threadIdx.x & 7) * 4;        // staging: 64 rows x 8 float4 per pass, 4 passes
-  float4 ra[4], rb[4];
+  float4 ra[RI], rb[4];
   // rows of A beyond M (the last row tile of a batch whose size is not a multiple of 256) are clamped to row M-1: they
   // are read but their results are never stored
   // (TAIL: only instantiated for a batch whose row count is not a multiple of 256 -- the extra address registers cost the
@@ -368,49 +373,52 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
   const float* Bp = B + (size_t)(n0 + srow) * ldb + sc4;
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < RI; ++p) {
       if constexpr (TAIL)
         ra[p] = *reinterpret_cast<const float4*>(Ap + (size_t)min(64 * p, M - 1 - ar0) * lda + k0);
       else
         ra[p] = *reinterpret_cast<const float4*>(Ap + (size_t)(64 * p) * lda + k0);
-      rb[p] = *reinterpret_cast<const float4*>(Bp + (size_t)(64 * p) * ldb + k0);
     }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) rb[p] = *reinterpret_cast<const float4*>(Bp + (size_t)(64 * p) * ldb + k0);
   };
-  auto sstore = [&](Smem256& d) {
+  auto sstore = [&](SmemT& d) {
     bf16x4 h, l, l2;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int o = swz_off<BK_>(srow + 64 * p, sc4);
-      split4<2>(ra[p], h, l, l2);
-      *reinterpret_cast<bf16x4*>(&d.a[0][o]) = h;
-      *reinterpret_cast<bf16x4*>(&d.a[1][o]) = l;
+      if (p < RI) {
+        split4<2>(ra[p < RI ? p : 0], h, l, l2);
+        *reinterpret_cast<bf16x4*>(&d.a[0][o]) = h;
+        *reinterpret_cast<bf16x4*>(&d.a[1][o]) = l;
+      }
       split4<2>(rb[p], h, l, l2);
       *reinterpret_cast<bf16x4*>(&d.b[0][o]) = h;
       *reinterpret_cast<bf16x4*>(&d.b[1][o]) = l;
     }
   };
-  f32x16 acc[4][2];
+  f32x16 acc[RI][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  auto mma = [&](const Smem256& t) {
+  auto mma = [&](const SmemT& t) {
 #pragma unroll
     for (int ks = 0; ks < BK_ / 16; ++ks) {
-      bf16x8 af[2][4], bfr[2][2];
+      bf16x8 af[2][RI], bfr[2][2];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           bfr[tt][j] = *reinterpret_cast<const bf16x8*>(&t.b[tt][swz_off<BK_>(wc * 64 + j * 32 + l31, ks * 16 + 8 * half)]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          af[tt][i] = *reinterpret_cast<const bf16x8*>(&t.a[tt][swz_off<BK_>(wr * 128 + i * 32 + l31, ks * 16 + 8 * half)]);
+        for (int i = 0; i < RI; ++i)
+          af[tt][i] = *reinterpret_cast<const bf16x8*>(&t.a[tt][swz_off<BK_>(wr * (BM / 2) + i * 32 + l31, ks * 16 + 8 * half)]);
       }
 #define LTRX_MMA256(TA, TB)                                                                                       \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                     \
+  _Pragma("unroll") for (int i = 0; i < RI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                    \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA][i], bfr[TB][j], acc[i][j], 0, 0, 0);
       LTRX_MMA256(0, 1)
       LTRX_MMA256(1, 0)
@@ -453,12 +461,12 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RI; ++i) {
       f32x4 ax[4];
       if (act == 2) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int row = m0 + wr * 128 + i * 32 + 8 * g + 4 * half + q;
+          const int row = m0 + wr * (BM / 2) + i * 32 + 8 * g + 4 * half + q;
           ax[g] = (!TAIL || row < M) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(aux + (size_t)row * ldaux + col))
                                      : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -474,7 +482,7 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
         const float r_a = LTRX_DPP_F(0.f, b1 ? c0 : c2, 0x4E, 0xF, true);
         const float r_b = LTRX_DPP_F(0.f, b1 ? c1 : c3, 0x4E, 0xF, true);
         f32x4 v = {b1 ? r_a : c0, b1 ? r_b : c1, b1 ? c2 : r_a, b1 ? c3 : r_b};   // row q, columns col..col+3
-        const int row = m0 + wr * 128 + i * 32 + 8 * g + 4 * half + q;
+        const int row = m0 + wr * (BM / 2) + i * 32 + 8 * g + 4 * half + q;
         if (TAIL && row >= M) continue;
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         if (act == 1) {
@@ -620,7 +628,7 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __res
                                                               int M, int NP, int KP, int tiles_k, int m_per_split) {
   constexpr int BK_ = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  Smem256* s = reinterpret_cast<Smem256*>(smem_raw);
+  SmemNT<256>* s = reinterpret_cast<SmemNT<256>*>(smem_raw);
   const int tile = blockIdx.x, split = blockIdx.y;
   const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 256;
   const int wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
@@ -639,7 +647,7 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __res
   };
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool want_bias = bias_slabs != nullptr && (tile % tiles_k) == 0;      // column sums of A = the bias gradient
-  auto sstore = [&](Smem256& d) {
+  auto sstore = [&](SmemNT<256>& d) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       __bf16* img0 = g ? d.b[0] : d.a[0];
@@ -664,7 +672,7 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __res
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-  auto mma = [&](const Smem256& t) {
+  auto mma = [&](const SmemNT<256>& t) {
 #pragma unroll
     for (int ks = 0; ks < BK_ / 16; ++ks) {
       bf16x8 af[2][4], bfr[2][2];
@@ -744,7 +752,7 @@ __global__ void __launch_bounds__(256) ltrx_gemm_slab_reduce_kernel(const float*
 // host side
 // ------------------------------------------------------------------------------------------------------------------
 // tile variant: 0 = auto; 1 = 128x128x32 (4 waves); 2 = 128x128x64; 3 = 256x128x32 (8 waves); 4 = 256x128x64; 5 = pipelined
-// 128x128x32; 6 = 256x256x32 large-tile kernel (auto picks it for exact multiples with >= 360 tiles)
+// 128x128x32; 6 = 256x256x32 large-tile kernel (auto picks it for exact multiples with >= 360 tiles); 7 = its 128x256x32 form
 static int g_nt_variant = 0;
 extern "C" void ltrx_gemm_set_variant(int v) { g_nt_variant = v; }
 
@@ -780,27 +788,39 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
     // 240 tiles 53 vs 77 us, 360 tiles parity, 120 tiles parity, 480 tiles 102 vs 132 us)
     const size_t t = (size_t)((M + 255) / 256) * (N / 256);
     if (t >= 360 || (t >= 192 && t <= 256)) v = 6;
+    else {                                           // 128-row tiles when they make exactly one well-filled round
+      const size_t t128 = (size_t)((M + 127) / 128) * (N / 256);
+      if (t128 >= 176 && t128 <= 256) v = 7;
+    }
   }
   if (v == 0) v = 1;
-  if (v == 6) {
+  if (v == 6 || v == 7) {
     if ((N % 256) || (K % 32) || strict || !vec_epi) return LTRX_EUNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(2 * sizeof(Smem256))) != hipSuccess ||
-          hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(2 * sizeof(Smem256))) != hipSuccess)
+      if (hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(2 * sizeof(SmemNT<256>))) != hipSuccess ||
+          hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(2 * sizeof(SmemNT<256>))) != hipSuccess ||
+          hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(2 * sizeof(SmemNT<128>))) != hipSuccess ||
+          hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(2 * sizeof(SmemNT<128>))) != hipSuccess)
         return LTRX_EHIP;
       attr_set = true;
     }
     const int tiles_n = N / 256;
-    const dim3 grid(((M + 255) / 256) * tiles_n);
-    if (M % 256)
-      hipLaunchKernelGGL(ltrx_gemm_nt256_kernel<true>, grid, dim3(512), 2 * sizeof(Smem256), s, A, lda, B, ldb, C, ldc, M, N, K,
-                         bias, act, aux, ldaux, tiles_n, drop, drop_step);
-    else
-      hipLaunchKernelGGL(ltrx_gemm_nt256_kernel<false>, grid, dim3(512), 2 * sizeof(Smem256), s, A, lda, B, ldb, C, ldc, M, N, K,
-                         bias, act, aux, ldaux, tiles_n, drop, drop_step);
+    const int bm = (v == 6) ? 256 : 128;
+    const dim3 grid(((M + bm - 1) / bm) * tiles_n);
+#define LTRX_NT256(TAIL_, BM_)                                                                                              \
+  hipLaunchKernelGGL((ltrx_gemm_nt256_kernel<TAIL_, BM_>), grid, dim3(512), 2 * sizeof(SmemNT<BM_>), s, A, lda, B, ldb, C, ldc, M, \
+                     N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step)
+    if (v == 6) {
+      if (M % 256) LTRX_NT256(true, 256); else LTRX_NT256(false, 256);
+    } else {
+      if (M % 128) LTRX_NT256(true, 128); else LTRX_NT256(false, 128);
+    }
+#undef LTRX_NT256
     LTRX_LAUNCH_CHECK();
     return LTRX_OK;
   }
@@ -867,12 +887,12 @@ extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, fl
     static bool attr_set = false;
     if (!attr_set) {
       if (hipFuncSetAttribute((const void*)ltrx_gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(2 * sizeof(Smem256))) != hipSuccess)
+                              (int)(2 * sizeof(SmemNT<256>))) != hipSuccess)
         return LTRX_EHIP;
       attr_set = true;
     }
     float* bslabs = bias_out ? (float*)ws + (size_t)splits * NP * KP : nullptr;
-    hipLaunchKernelGGL(ltrx_gemm_tn256_kernel, dim3((NP / 256) * (KP / 256), splits), dim3(512), 2 * sizeof(Smem256), s, A, lda, B,
+    hipLaunchKernelGGL(ltrx_gemm_tn256_kernel, dim3((NP / 256) * (KP / 256), splits), dim3(512), 2 * sizeof(SmemNT<256>), s, A, lda, B,
                        ldb, (float*)ws, bslabs, M, NP, KP, KP / 256, mps);
     LTRX_LAUNCH_CHECK();
     if (bias_out) {

@@ -902,15 +902,17 @@ def test_large_tile_gemm_matches_fp64_and_the_small_tile_kernel():
     rng = np.random.default_rng(11)
     step = torch.tensor([3], dtype=torch.int32, device=DEV)
     try:
-        for (Mm, N, K, forced) in [(512, 256, 32, True), (256, 768, 544, True), (1024, 512, 96, True), (6144, 4096, 64, False),
-                                   (700, 512, 64, True), (33, 256, 160, True), (24000, 1536, 64, False)]:      # ragged last row tile
+        # forced: 6 = the 256-row tile, 7 = its 128-row form, 0 = whatever the dispatch picks (15360 x 512 -> 128-row tiles)
+        for (Mm, N, K, forced) in [(512, 256, 32, 6), (256, 768, 544, 6), (1024, 512, 96, 6), (6144, 4096, 64, 0),
+                                   (700, 512, 64, 6), (33, 256, 160, 6), (24000, 1536, 64, 0),       # ragged last row tile
+                                   (384, 512, 96, 7), (200, 256, 64, 7), (15360, 512, 64, 0), (15300, 512, 32, 0)]:
             A = rng.standard_normal((Mm, K)).astype(np.float32)
             Bw = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
             bias = rng.standard_normal(N).astype(np.float32)
             aux = rng.standard_normal((Mm, N)).astype(np.float32)
             At, Bt, bt, auxt = _t(A), _t(Bw), _t(bias), _t(aux)
             outs = {}
-            for variant in (1, 6 if forced else 0):
+            for variant in (1, forced):
                 lib.ltrx_gemm_set_variant(variant)
                 res = []
                 for (b_, act, ax, p) in ((bt, 1, None, 0.0), (None, 0, None, 0.0), (None, 2, auxt, 0.25), (bt, 1, None, 0.3), (bt, 0, None, 0.3)):
@@ -919,7 +921,7 @@ def test_large_tile_gemm_matches_fp64_and_the_small_tile_kernel():
                                               N if ax is not None else 0, p, 77, LB.ptr(step), 0, None), "gemm_nt")
                     res.append(C)
                 outs[variant] = res
-            v_new = 6 if forced else 0
+            v_new = forced
             ref = np.maximum(A.astype(np.float64) @ Bw.astype(np.float64).T + bias, 0)
             scale = (np.abs(A).astype(np.float64) @ np.abs(Bw).astype(np.float64).T).max()
             err = float(np.abs(outs[v_new][0].cpu().numpy() - ref).max() / scale)
