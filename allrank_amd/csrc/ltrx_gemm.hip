@@ -737,15 +737,36 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __res
   }
 }
 
-// C[i] = sum_s slabs[s][i]   (fixed order; 16-byte accesses when n % 4 == 0, scalar otherwise)
+// C[i] = sum_s slabs[s][i] in a fixed order.  One launch serves the weight gradient (workgroups 0 .. main_blocks-1) and,
+// when given, the bias gradient's column-sum slabs (the remaining workgroups).
 __global__ void __launch_bounds__(256) ltrx_gemm_slab_reduce_kernel(const float* __restrict__ slabs, int splits,
-                                                                    size_t n, float* __restrict__ C) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
+                                                                    size_t n, float* __restrict__ C, int main_blocks,
+                                                                    const float* __restrict__ slabs2, int splits2, size_t n2,
+                                                                    float* __restrict__ C2) {
+  if ((int)blockIdx.x >= main_blocks) {
+    const size_t stride = (size_t)(gridDim.x - main_blocks) * blockDim.x;
+    for (size_t i = (size_t)(blockIdx.x - main_blocks) * blockDim.x + threadIdx.x; i < n2; i += stride) {
+      float a = 0.f;
+      for (int sidx = 0; sidx < splits2; ++sidx) a += slabs2[(size_t)sidx * n2 + i];
+      C2[i] = a;
+    }
+    return;
+  }
+  const size_t stride = (size_t)main_blocks * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float a = 0.f;
     for (int sidx = 0; sidx < splits; ++sidx) a += slabs[(size_t)sidx * n + i];
     C[i] = a;
   }
+}
+
+static void launch_slab_reduce(const float* slabs, int splits, size_t n, float* C, const float* bslabs, int bsplits, size_t nb,
+                               float* bias_out, hipStream_t s) {
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  const size_t bblocks = bias_out ? (nb + 255) / 256 : 0;
+  hipLaunchKernelGGL(ltrx_gemm_slab_reduce_kernel, dim3((unsigned)(blocks + bblocks)), dim3(256), 0, s, slabs, splits, n, C,
+                     (int)blocks, bslabs, bsplits, nb, bias_out);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -895,15 +916,7 @@ extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, fl
     hipLaunchKernelGGL(ltrx_gemm_tn256_kernel, dim3((NP / 256) * (KP / 256), splits), dim3(512), 2 * sizeof(SmemNT<256>), s, A, lda, B,
                        ldb, (float*)ws, bslabs, M, NP, KP, KP / 256, mps);
     LTRX_LAUNCH_CHECK();
-    if (bias_out) {
-      hipLaunchKernelGGL(ltrx_gemm_slab_reduce_kernel, dim3((NP + 255) / 256), dim3(256), 0, s, (const float*)bslabs, splits,
-                         (size_t)NP, bias_out);
-      LTRX_LAUNCH_CHECK();
-    }
-    const size_t n = (size_t)NP * KP;
-    size_t blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(ltrx_gemm_slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)ws, splits, n, C);
+    launch_slab_reduce((const float*)ws, splits, (size_t)NP * KP, C, bslabs, splits, (size_t)NP, bias_out, s);
     LTRX_LAUNCH_CHECK();
     return LTRX_OK;
   }
@@ -920,15 +933,7 @@ extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, fl
   else
     hipLaunchKernelGGL(ltrx_gemm_tn_kernel<2>, grid, dim3(256), 0, s, A, lda, B, ldb, (float*)ws, bslabs, M, NP, KP, tiles_k, mps);
   LTRX_LAUNCH_CHECK();
-  if (bias_out) {
-    hipLaunchKernelGGL(ltrx_gemm_slab_reduce_kernel, dim3((NP + 255) / 256), dim3(256), 0, s, (const float*)bslabs, 2 * splits,
-                       (size_t)NP, bias_out);
-    LTRX_LAUNCH_CHECK();
-  }
-  const size_t n = (size_t)NP * KP;
-  size_t blocks = (n + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(ltrx_gemm_slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)ws, splits, n, C);
+  launch_slab_reduce((const float*)ws, splits, (size_t)NP * KP, C, bslabs, 2 * splits, (size_t)NP, bias_out, s);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }
