@@ -645,18 +645,20 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __res
   const float* PA = A + n0 + (size_t)(4 * mg) * lda + 4 * cg;
   const float* PB = B + k0 + (size_t)(4 * mg) * ldb + 4 * cg;
   float4 r[2][4];                    // [operand][m row]
-  auto gload = [&](int mt) {
+  auto gload1 = [&](int mt, int g) {          // operand g of the m-slab starting at row mt
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      r[0][e] = *reinterpret_cast<const float4*>(PA + (size_t)(mt + e) * lda);
-      r[1][e] = *reinterpret_cast<const float4*>(PB + (size_t)(mt + e) * ldb);
-    }
+    for (int e = 0; e < 4; ++e)
+      r[g][e] = g ? *reinterpret_cast<const float4*>(PB + (size_t)(mt + e) * ldb)
+                  : *reinterpret_cast<const float4*>(PA + (size_t)(mt + e) * lda);
+  };
+  auto gload = [&](int mt) {
+    gload1(mt, 0);
+    gload1(mt, 1);
   };
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool want_bias = bias_slabs != nullptr && (tile % tiles_k) == 0;      // column sums of A = the bias gradient
-  auto sstore = [&](SmemNT<256>& d) {
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
+  auto sstore1 = [&](SmemNT<256>& d, int g) {
+    {
       __bf16* img0 = g ? d.b[0] : d.a[0];
       __bf16* img1 = g ? d.b[1] : d.a[1];
       const float cx[4][4] = {{r[g][0].x, r[g][1].x, r[g][2].x, r[g][3].x}, {r[g][0].y, r[g][1].y, r[g][2].y, r[g][3].y},
@@ -672,6 +674,10 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __res
       }
     }
   };
+  auto sstore = [&](SmemNT<256>& d) {
+    sstore1(d, 0);
+    sstore1(d, 1);
+  };
   f32x16 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -679,9 +685,8 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __res
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-  auto mma = [&](const SmemNT<256>& t) {
-#pragma unroll
-    for (int ks = 0; ks < BK_ / 16; ++ks) {
+  auto mma1 = [&](const SmemNT<256>& t, int ks) {
+    {
       bf16x8 af[2][4], bfr[2][2];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
@@ -701,6 +706,10 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __res
 #undef LTRX_MMA256
     }
   };
+  auto mma = [&](const SmemNT<256>& t) {
+    mma1(t, 0);
+    mma1(t, 1);
+  };
   const int nk = (mend - mbeg) / BK_;            // M and m_per_split are multiples of 32 (host)
   if (nk > 0) {
     gload(mbeg);
@@ -710,7 +719,11 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __res
     int kt = 0;
     for (; kt + 2 < nk; ++kt) {
       sstore(s[(kt + 1) & 1]);
+      // pinned: left to itself the scheduler sinks these loads below the MFMA block (shorter live ranges), i.e. to a few
+      // hundred cycles before the wait at the top of the next iteration, and every K-step eats the full memory latency
+      __builtin_amdgcn_sched_barrier(0);
       gload(mbeg + (kt + 2) * BK_);
+      __builtin_amdgcn_sched_barrier(0);
       mma(s[kt & 1]);
       lds_only_barrier();
     }
