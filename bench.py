@@ -132,19 +132,21 @@ def time_kernels(w, B, L, device):
         dk = d // h
         qkv = torch.randn(B, L, 3 * d, device=device)
         mask = torch.zeros(B, L, dtype=torch.bool, device=device)
-        q, k, v = qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:]
-        with torch.no_grad():
-            t_f = ev(lambda: ops.attention(q, k, v, mask, h))
         fl = 4.0 * B * h * L * L * dk
-        res["ltrx_mha_fwd_kernel"] = dict(sec=t_f, flops=fl, launches_per_step=w["N"])
-        qkv.requires_grad_(True)
         go = torch.randn(B, L, d, device=device)
-
-        def fb():
-            qkv.grad = None
-            ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], mask, h).backward(go)
-        t_fb = ev(fb)
-        res["ltrx_mha_bwd(dq+dkdv+delta)"] = dict(sec=max(t_fb - t_f, 1e-9), flops=2.5 * fl, launches_per_step=w["N"])
+        o_ = torch.empty(B, L, d, device=device)
+        lse_ = torch.empty(B, h, L, device=device)
+        dqkv = torch.empty(B, L, 3 * d, device=device)
+        m8 = mask.to(torch.uint8)
+        ws_ = torch.empty(max(lib.ltrx_mha_bwd_workspace_bytes(B, L, h), 64), dtype=torch.uint8, device=device)
+        st2 = LB.stream_of(qkv)
+        t_f = ev(lambda: LB.check(lib.ltrx_mha_fwd(LB.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, LB.ptr(m8), B, L, h, dk,
+                                                   3 * d, LB.ptr(o_), d, LB.ptr(lse_), 0.0, 0, None, None, None, st2), "mha_fwd"))
+        res["ltrx_mha_fwd_kernel"] = dict(sec=t_f, flops=fl, launches_per_step=w["N"])
+        t_b = ev(lambda: LB.check(lib.ltrx_mha_bwd(LB.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, LB.ptr(m8), LB.ptr(o_),
+                                                   LB.ptr(go), LB.ptr(lse_), B, L, h, dk, 3 * d, d, LB.ptr(dqkv), dqkv.data_ptr() + 4 * d,
+                                                   dqkv.data_ptr() + 8 * d, 3 * d, 0.0, 0, None, None, None, LB.ptr(ws_), st2), "mha_bwd"))
+        res["ltrx_mha_bwd(dq+dkdv+delta)"] = dict(sec=t_b, flops=2.5 * fl, launches_per_step=w["N"])
         x = torch.randn(B * L, d, device=device)
         r = torch.randn(B * L, d, device=device)
         a = torch.ones(d, device=device)
