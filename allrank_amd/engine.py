@@ -568,7 +568,10 @@ class FusedTrainer(object):
             self._pack_turn += 1
             host, ev = self._cu_ring[k]
             ev.synchronize()
-            lens = torch.as_tensor(lengths, dtype=torch.int32).reshape(B).clamp(max=L)
+            lens = torch.as_tensor(lengths, dtype=torch.int32)
+            if lens.is_cuda:                                      # (a device tensor costs the sync the host lengths are meant to avoid)
+                lens = lens.cpu()
+            lens = lens.reshape(B).clamp(min=0, max=L)
             host[0] = 0
             torch.cumsum(lens, 0, dtype=torch.int32, out=host[1:B + 1])
             host[B + 1:] = torch.argsort(lens, descending=True, stable=True)
@@ -585,6 +588,8 @@ class FusedTrainer(object):
             idx = torch.nonzero(valid.reshape(-1)).reshape(-1)    # (host sync: the row count sizes every launch)
             n = int(idx.numel())
             self.idx[:n] = idx
+        if n == 0:
+            raise ValueError("FusedTrainer(compact=True): the batch has no valid item")
         self.n_valid = n
         self.rows = min(self.M, (n + 31) // 32 * 32)              # alignment rows (zero input, zero gradient) keep M % 32 == 0
         F = self.x_in.shape[1]

@@ -594,6 +594,17 @@ def test_end_to_end_training_on_device_resident_libsvm_data(tmp_path):
     assert res["fused"] and np.isfinite(after) and after > before + 0.03, (before, res["history"])
     h = res["history"]
     assert "train_ndcg_5" in h[-1] and 0.0 < h[-1]["train_ndcg_5"] <= 1.0 and h[-1]["train_ndcg_5"] > h[0]["train_ndcg_5"]
+    # the same run with variable-length execution (padded slots skipped): same data order (same generator seed), same result
+    torch.manual_seed(42)
+    model_c = make_model(dict(sizes=[32], input_norm=False, activation=None, dropout=0.0),
+                         dict(N=1, d_ff=64, h=2, positional_encoding=None, dropout=0.0),
+                         dict(d_output=1, output_activation=None), 20).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    res_c = fit_device(model_c, "approxNDCGLoss", {}, train, vali, epochs=6, batch_size=32, slate_length=24, metrics={"ndcg": [5, 10]},
+                       lr=2e-3, generator=g, gradient_clipping_norm=5.0, lr_schedule=lambda e: 2e-3 * (0.5 ** (e // 4)), compact=True)
+    assert res_c["fused"]
+    assert abs(res_c["history"][0]["train_loss"] - h[0]["train_loss"]) < 2e-3        # epoch 0: round-off level differences only
+    assert abs(res_c["val_metrics"]["ndcg_5"] - after) < 0.03, (res_c["val_metrics"], after)
 
 
 # ------------------------------------------------------------------------------------------------------------------
