@@ -671,8 +671,10 @@ def _dropout_model(p, fc_act, fc_drop, N=2):
                       dict(d_output=1, output_activation=None), 20).to(DEV)
 
 
-@pytest.mark.parametrize("gemm,fc_act", [("split_bf16_strict", None), ("hipblaslt", "ReLU"), ("split_bf16_strict", "ReLU")])
-def test_fused_step_dropout_gradients_match_finite_differences(gemm, fc_act):
+@pytest.mark.parametrize("gemm,fc_act,compact", [("split_bf16_strict", None, False), ("hipblaslt", "ReLU", False),
+                                                 ("split_bf16_strict", "ReLU", False), ("split_bf16_strict", "ReLU", True),
+                                                 ("hipblaslt", None, True)])
+def test_fused_step_dropout_gradients_match_finite_differences(gemm, fc_act, compact):
     """with the masks frozen (fixed seed and step word) the explicit backward must be the gradient of the explicit forward:
     for every parameter tensor, the central difference of the loss along that tensor's own gradient direction equals the
     gradient norm.  A forward/backward mask mismatch at any of the dropout sites breaks this by O(1)."""
@@ -684,11 +686,17 @@ def test_fused_step_dropout_gradients_match_finite_differences(gemm, fc_act):
     x = rng.standard_normal((B, L, 20)).astype(np.float32)
     y = rng.integers(0, 5, (B, L)).astype(np.float32)
     y[0, 15:] = -1
-    ft = FusedTrainer(model, "listNet", {}, B, L, use_graph=False, gemm=gemm, seed=1234)
+    if compact:                                # variable-length execution: packed rows, cu_seqlens attention (same mask algebra)
+        y[3, 4:] = -1
+        y[5, 19:] = -1
+    ft = FusedTrainer(model, "listNet", {}, B, L, use_graph=False, gemm=gemm, seed=1234, compact=compact)
     ft._divisor = float(B)
-    ft.x_in.copy_(_t(x).reshape(B * L, -1))
     ft.y_in.copy_(_t(y))
     ft.mask.copy_(_t(y) == -1)
+    if compact:
+        ft._pack(_t(x).reshape(B * L, -1).contiguous(), [int(v) for v in (y != -1).sum(1)])
+    else:
+        ft.x_in.copy_(_t(x).reshape(B * L, -1))
     base = float(ft._body().item())
     again = float(ft._body().item())
     assert base == again                                     # same step word -> same masks -> same loss
@@ -713,12 +721,12 @@ def test_fused_step_dropout_gradients_match_finite_differences(gemm, fc_act):
         if abs(fd - gn) > 0.04 * gn + 5e-4:       # ReLU kinks along a bias direction cost ~2%
             bad.append(rows[-1])
     ft.flat_p.copy_(p0)
-    _log("dropout_fd_%s_%s" % (gemm, fc_act), rows)
+    _log("dropout_fd_%s_%s_%s" % (gemm, fc_act, compact), rows)
     assert len(rows) >= 10 and not bad, bad
     # and the dropout is really on: a no-dropout trainer on the same weights gives a different loss
     ft2 = FusedTrainer(model, "listNet", {}, B, L, use_graph=False, gemm=gemm, dropout=False)
     ft2._divisor = float(B)
-    ft2.x_in.copy_(ft.x_in); ft2.y_in.copy_(ft.y_in); ft2.mask.copy_(ft.mask)
+    ft2.x_in.copy_(_t(x).reshape(B * L, -1)); ft2.y_in.copy_(ft.y_in); ft2.mask.copy_(ft.mask)
     assert abs(float(ft2._body().item()) - base) > 1e-4
 
 
