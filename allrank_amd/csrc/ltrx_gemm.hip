@@ -828,6 +828,17 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
     // one workgroup per CU: a grid that fills 3/4 .. 1 round, or at least ~1.4 rounds (measured, tools/gemm_variants.py:
     // 240 tiles 53 vs 77 us, 360 tiles parity, 120 tiles parity, 480 tiles 102 vs 132 us)
     const size_t t = (size_t)((M + 255) / 256) * (N / 256);
+    if (t > 256 && t < 380 && (drop.thresh == 0u || act == 2) && N / 256 <= 256) {
+      // between one and ~1.5 rounds of 256-row tiles: a second round for a handful of tiles costs as much as the first
+      // (M 33000 x N 512: 95 us against 54 us for M 30720).  One exact round of large tiles first, the remaining rows as
+      // their own (smaller) problem: 5-25 % faster over that range (tools/gemm_split_probe.py).  Only without dropout
+      // generated in the epilogue -- its hash is indexed by the row of THIS launch.
+      const int m1 = (256 / (N / 256)) * 256;
+      int rc = ltrx_gemm_nt(A, lda, B, ldb, C, ldc, m1, N, K, bias, act, aux, ldaux, drop_p, drop_seed, drop_step, strict, stream);
+      if (rc != LTRX_OK) return rc;
+      return ltrx_gemm_nt(A + (size_t)m1 * lda, lda, B, ldb, C + (size_t)m1 * ldc, ldc, M - m1, N, K, bias, act,
+                          aux ? aux + (size_t)m1 * ldaux : nullptr, ldaux, drop_p, drop_seed, drop_step, strict, stream);
+    }
     if (t >= 360 || (t >= 192 && t <= 256)) v = 6;
     else {                                           // 128-row tiles when they make exactly one well-filled round
       const size_t t128 = (size_t)((M + 127) / 128) * (N / 256);

@@ -924,7 +924,8 @@ def test_large_tile_gemm_matches_fp64_and_the_small_tile_kernel():
         # forced: 6 = the 256-row tile, 7 = its 128-row form, 0 = whatever the dispatch picks (15360 x 512 -> 128-row tiles)
         for (Mm, N, K, forced) in [(512, 256, 32, 6), (256, 768, 544, 6), (1024, 512, 96, 6), (6144, 4096, 64, 0),
                                    (700, 512, 64, 6), (33, 256, 160, 6), (24000, 1536, 64, 0),       # ragged last row tile
-                                   (384, 512, 96, 7), (200, 256, 64, 7), (15360, 512, 64, 0), (15300, 512, 32, 0)]:
+                                   (384, 512, 96, 7), (200, 256, 64, 7), (15360, 512, 64, 0), (15300, 512, 32, 0),
+                                   (40000, 512, 64, 0)]:      # one round of large tiles + the remaining rows (two launches)
             A = rng.standard_normal((Mm, K)).astype(np.float32)
             Bw = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
             bias = rng.standard_normal(N).astype(np.float32)
