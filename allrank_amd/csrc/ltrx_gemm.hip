@@ -839,7 +839,7 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
       return ltrx_gemm_nt(A + (size_t)m1 * lda, lda, B, ldb, C + (size_t)m1 * ldc, ldc, M - m1, N, K, bias, act,
                           aux ? aux + (size_t)m1 * ldaux : nullptr, ldaux, drop_p, drop_seed, drop_step, strict, stream);
     }
-    if (t >= 360 || (t >= 192 && t <= 256)) v = 6;
+    if (t >= 360 || (t >= 168 && t <= 256)) v = 6;
     else {                                           // 128-row tiles when they make exactly one well-filled round
       const size_t t128 = (size_t)((M + 127) / 128) * (N / 256);
       if (t128 >= 176 && t128 <= 256) v = 7;

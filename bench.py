@@ -119,7 +119,7 @@ def time_kernels(w, B, L, device):
                                                    None, 0, 0.0, 0, None, 0, st), "gemm_nt"))
         n_nt = 1 + 8 * w["N"] - 1          # fwd: fc + 4/layer; dgrad: 4/layer  (head GEMV is a separate kernel)
         _t256 = ((Mrows + 255) // 256) * (Nn // 256)
-        big = (Nn % 256 == 0 and Kk % 32 == 0 and (_t256 >= 360 or 192 <= _t256 <= 256))   # ltrx_gemm.hip dispatch
+        big = (Nn % 256 == 0 and Kk % 32 == 0 and (_t256 >= 360 or 168 <= _t256 <= 256))   # ltrx_gemm.hip dispatch
         res["%s @FFN1" % ("ltrx_gemm_nt256_kernel" if big else "ltrx_gemm_nt_kernel<2,128,32>")] = dict(
             sec=t_g, flops=2.0 * Mrows * Nn * Kk, launches_per_step=n_nt, shape=[Mrows, Nn, Kk])
         del A_, W_, b_, C_
