@@ -840,6 +840,7 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
                           aux ? aux + (size_t)m1 * ldaux : nullptr, ldaux, drop_p, drop_seed, drop_step, strict, stream);
     }
     if (t >= 360 || (t >= 168 && t <= 256)) v = 6;
+    else if (t >= 136 && t < 168 && (size_t)((M + 127) / 128) * (N / 256) > 256) v = 6;   // one partial round still beats two rounds of smaller tiles
     else {                                           // 128-row tiles when they make exactly one well-filled round
       const size_t t128 = (size_t)((M + 127) / 128) * (N / 256);
       if (t128 >= 176 && t128 <= 256) v = 7;
