@@ -2,6 +2,7 @@
 kernels fails loudly (the product path never routes through a CPU implementation)."""
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -66,12 +67,34 @@ SIGNATURES = {
     "ltrx_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _f, ctypes.c_uint32, _vp, _i, _vp]),
     "ltrx_gemm_set_variant": (None, [_i]),
     "ltrx_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ltrx_gemm_tn_splits": (_i, [_i, _i, _i]),
     "ltrx_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ltrx_selftest_mfma32x32x2": (_i, [_vp, _vp, _vp, _vp]),
     "ltrx_mha_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None
+_tls = threading.local()
+
+
+class _Bound(object):
+    """namespace of the bound entry points (attribute access like a ctypes.CDLL)"""
+
+
+def _on_stream_device(fn):
+    """Entry points that take a stream launch on it; HIP requires the stream's device to be the CURRENT device.  The
+    stream argument is produced by ``stream_of`` / ``launch_stream`` right before the call, which records the tensor's
+    device; if that is not the current device (explicit cuda:1 tensors while cuda:0 is current -- plain user code after
+    the reference's DataParallel gather) the launch is wrapped in a device guard.  A NULL stream is left alone."""
+    def call(*args):
+        dev = getattr(_tls, "dev", None)
+        _tls.dev = None
+        if dev is None or not args or args[-1] is None or dev == torch.cuda.current_device():
+            return fn(*args)
+        with torch.cuda.device(dev):
+            return fn(*args)
+    call.__name__ = fn.__name__
+    return call
 
 
 def lib():
@@ -83,11 +106,14 @@ def lib():
                 "allrank_amd: %s is missing -- build it with `python -m allrank_amd.build` "
                 "(there is no CPU fallback for the HIP kernels)" % LIB_PATH)
         h = ctypes.CDLL(LIB_PATH)
+        b = _Bound()
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)     # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        _lib = h
+            launches = res is _i and args and args[-1] is _vp and not name.endswith("_bytes")
+            setattr(b, name, _on_stream_device(fn) if launches else fn)
+        _lib = b
     return _lib
 
 
@@ -105,15 +131,29 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def launch_stream(device):
+    """torch's current stream on ``device`` as a hipStream_t; remembers the device for the launch guard of ``lib()``."""
+    device = torch.device(device)
+    _tls.dev = device.index if device.index is not None else torch.cuda.current_device()
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
 def stream_of(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return launch_stream(t.device)
 
 
 def require_device(*tensors):
+    dev = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("allrank_amd kernels run on the MI355X only: got a %s tensor (no CPU fallback; "
                                "use the reference implementation on CPU)" % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("allrank_amd kernels need all tensors of a call on one device: got %s and %s" % (dev, t.device))
 
 
 def workspace(nbytes, like):

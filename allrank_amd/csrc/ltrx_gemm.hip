@@ -917,13 +917,29 @@ static void tn256_plan(int M, int NP, int KP, int* splits, int* mps) {
   *splits = (M + m - 1) / m;
 }
 
+// splits the dispatch below will use for (M, NP, KP) (exported for the sizing test: the workspace must cover every row count
+// <= the M it was sized for, because variable-length batches call ltrx_gemm_tn with a different M every step)
+extern "C" int ltrx_gemm_tn_splits(int M, int NP, int KP) {
+  if (M <= 0 || NP <= 0 || KP <= 0) return 0;
+  if (tn256_ok(M, NP, KP)) {
+    int s2, mps;
+    tn256_plan(M, NP, KP, &s2, &mps);
+    return s2;
+  }
+  return tn_splits(M, ((NP + 127) / 128) * ((KP + BN - 1) / BN));
+}
+
+// Upper bound over ALL row counts m <= M (not only M itself): the small-tile plan is monotone in m (tn_splits), the
+// large-tile plan never uses more than min(256 / tiles256, m / 128) splits but is not monotone (m is rounded to 32-row
+// slabs and the kernel switches on at m >= 2048, m % 32 == 0), so its bound is taken whenever the shape could select it.
 extern "C" size_t ltrx_gemm_tn_workspace_bytes(int M, int NP, int KP) {
   if (M <= 0 || NP <= 0 || KP <= 0) return 0;
   const int tiles = ((NP + 127) / 128) * ((KP + BN - 1) / BN);
   size_t sp = (size_t)tn_splits(M, tiles);
-  if (tn256_ok(M, NP, KP)) {
-    int s2, mps;
-    tn256_plan(M, NP, KP, &s2, &mps);
+  if ((NP % 256) == 0 && (KP % 256) == 0 && M >= 2048) {
+    int s2 = 256 / ((NP / 256) * (KP / 256));
+    if (s2 > M / 128) s2 = M / 128;
+    if (s2 < 1) s2 = 1;
     if ((size_t)s2 > sp) sp = (size_t)s2;
   }
   return (sp * NP * KP + 2 * sp * NP) * sizeof(float);

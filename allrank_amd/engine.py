@@ -28,6 +28,7 @@ class Trainer(object):
     def step(self, xb, yb, indices=None, global_batch=None):
         """one training step on this rank's slates; returns the (device) loss tensor -- this rank's share of the
         global loss when sharded."""
+        self.flat.check()         # .grad must still alias the flat buffer (an external zero_grad(set_to_none=True) detaches it)
         mask = (yb == PADDED_Y_VALUE)
         gb = global_batch if global_batch is not None else xb.shape[0] * self.world
         if self.world > 1:
@@ -182,7 +183,9 @@ class FusedTrainer(object):
             prev_hi = st_
         self._buckets.append((0, prev_hi))
         self._works = []
-        self._pv, self._gv = {}, {}
+        self.comm_enabled = True      # bench.py measures the exposed part of the collective by switching it off
+        self._pv, self._wv, self._gv = {}, {}, {}
+        self._order = order
         with torch.no_grad():
             for p, o in zip(order, offs):
                 view = self.flat_p[o:o + p.numel()].view_as(p)
@@ -190,12 +193,16 @@ class FusedTrainer(object):
                 p.data = view
                 p.grad = self.flat_g[o:o + p.numel()].view_as(p)
                 self._pv[id(p)] = (o, p.shape)
+                self._wv[id(p)] = view
+                self._gv[id(p)] = p.grad
 
+        # the kernels address the flat buffers through these views, never through p.data / p.grad: an external
+        # zero_grad(set_to_none=True) or .to() cannot redirect the step (step() re-attaches the module's views)
         def W(p):
-            return p.data
+            return self._wv[id(p)]
 
         def G(p):
-            return p.grad
+            return self._gv[id(p)]
 
         self.W, self.G = W, G
 
@@ -289,6 +296,12 @@ class FusedTrainer(object):
             self._tn, self._ttiles = len(srcs), tstart[-1]
             self._refresh_transposes()
         self.loss = FusedLoss(loss_name, B, L, dev, **(loss_args or {}))
+        # ListMLE: the reference draws torch.randperm(L) on every call (listMLE.py:17).  shuffle_ties=True (default) does
+        # the same with a device generator; tests that compare with the oracle set shuffle_ties=False and an explicit
+        # permutation via ``trainer.loss.set_perm``.
+        self.shuffle_ties = True
+        self._perm_gen = torch.Generator(device=dev)
+        self._perm_gen.manual_seed(int(seed) & 0x7FFFFFFF)
         self.use_graph = use_graph and not compact
         self.probe = None                                     # list collecting (start, end) events of the FFN1 GEMM (eager steps only)
         self.graph = None
@@ -296,7 +309,7 @@ class FusedTrainer(object):
 
     # ---- thin launch helpers -----------------------------------------------------------------------------------
     def _st(self):
-        return self.LB.ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        return self.LB.launch_stream(self.dev)
 
     @staticmethod
     def _rank(group, world_size):
@@ -357,7 +370,7 @@ class FusedTrainer(object):
     def _bucket_done(self, k):
         """gradient bucket k is final: start its all-reduce(SUM) now, behind the rest of the backward (the collective runs
         on the process group's own stream; ``_full`` waits for all of them before the optimizer step)"""
-        if self.world > 1:
+        if self.world > 1 and self.comm_enabled:
             import torch.distributed as dist
             lo, hi = self._buckets[k]
             if hi > lo:
@@ -596,8 +609,23 @@ class FusedTrainer(object):
         self.LB.check(self.lib.ltrx_gather_rows(self.LB.ptr(xb), F, self.LB.ptr(self.idx), n, self.rows, F, self.LB.ptr(self.x_in), F,
                                                 self._st()), "gather_rows")
 
+    def _reattach(self):
+        """the module's parameters / gradients must alias the flat buffers (state_dict(), score() and external readers of
+        .grad see what the kernels wrote): re-point anything an external zero_grad(set_to_none=True) / .to() detached."""
+        for p in self._order:
+            w, g = self._wv[id(p)], self._gv[id(p)]
+            if p.data.data_ptr() != w.data_ptr():
+                p.data = w
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
     def step(self, xb, yb, indices=None, global_batch=None, lengths=None):
         """copy the batch into the static input buffers and run (or replay) the step; returns the device loss [1]."""
+        self._reattach()
+        if self.loss.name == "listMLE" and self.shuffle_ties:
+            # listMLE.py:17: a fresh random column order per call breaks ties among equal labels at random; the
+            # permutation lives in a persistent device buffer, so the refresh is safe under hipGraph replay
+            self.loss.perm.copy_(torch.randperm(self.L, device=self.dev, generator=self._perm_gen))
         self._divisor = float(global_batch if global_batch is not None else self.B * self.world)
         self.y_in.copy_(yb)
         self.mask.copy_(yb == PADDED_Y_VALUE)
@@ -661,6 +689,8 @@ def fit_device(model, loss_name, loss_args, train_ds, val_ds, epochs, batch_size
         lossfn = (lambda s, t: getattr(E, loss_name)(s, t, **(loss_args or {})))
         trainer = Trainer(model, lossfn, torch.optim.Adam(model.parameters(), lr=lr), gradient_clipping_norm)
     history, best, best_epoch = [], -1.0, 0
+    if epochs <= 0:
+        return dict(epochs=0, train_loss=float("nan"), val_metrics=evaluate(model, val_ds, metrics), history=[], fused=fused)
     for epoch in range(epochs):
         if lr_schedule is not None:
             new_lr = float(lr_schedule(epoch))
@@ -673,12 +703,23 @@ def fit_device(model, loss_name, loss_args, train_ds, val_ds, epochs, batch_size
         tot = torch.zeros(1, device=train_ds.device)
         nb = 0
         tm = {name: None for name in metrics} if fused else {}
-        for xb, yb, idx in train_ds.batches(batch_size, slate_length, shuffle=True, generator=generator, drop_last=fused):
-            loss = trainer.step(xb, yb, idx)
-            tot += loss.detach().view(1) * xb.shape[0]
-            nb += xb.shape[0]
+        for xb, yb, idx in train_ds.batches(batch_size, slate_length, shuffle=True, generator=generator, drop_last=False):
+            real = xb.shape[0]
+            if fused and real < batch_size:
+                # the last batch of an epoch (DataLoader drop_last=False, dataset_loading.py:245): the fused step has static
+                # shapes, so the batch is topped up with fully padded slates (label -1, features 0: no loss, no gradient) and
+                # the loss is normalised by the REAL slate count, exactly what the reference computes on the short batch
+                padn = batch_size - real
+                xb = torch.cat([xb, xb.new_zeros((padn,) + tuple(xb.shape[1:]))])
+                yb = torch.cat([yb, yb.new_full((padn, yb.shape[1]), float(PADDED_Y_VALUE))])
+                idx = torch.cat([idx, idx.new_full((padn, idx.shape[1]), -1)])
+                loss = trainer.step(xb, yb, idx, global_batch=real)
+            else:
+                loss = trainer.step(xb, yb, idx)
+            tot += loss.detach().view(1) * real
+            nb += real
             for name in tm:                                   # metrics of the training forward (scores of this very step)
-                v = getattr(EMx, name)(trainer.scores, trainer.y_in, ats=metrics[name]).sum(0)
+                v = getattr(EMx, name)(trainer.scores[:real], trainer.y_in[:real], ats=metrics[name]).sum(0)
                 tm[name] = v if tm[name] is None else tm[name] + v
         train_loss = float(tot.item()) / max(nb, 1)
         val = evaluate(model, val_ds, metrics)

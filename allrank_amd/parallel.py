@@ -22,15 +22,34 @@ class FlatGradients(object):
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._offs = []
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self._offs.append(off)
             off += p.numel()
+
+    def check(self):
+        """``.grad`` must still alias the flat buffer: an external ``optimizer.zero_grad()`` (set_to_none=True is torch's
+        default), ``model.zero_grad()`` or ``model.to()`` silently detaches the views -- after that the collective and the
+        optimizer would work on a stale buffer while autograd fills fresh tensors.  Detached views are re-pointed (their
+        content, if any, is kept); callers should use ``zero()`` instead of zero_grad()."""
+        base = self.flat.data_ptr()
+        for p, off in zip(self.params, self._offs):
+            g = p.grad
+            if g is None or g.data_ptr() != base + 4 * off:
+                view = self.flat[off:off + p.numel()].view_as(p)
+                if g is not None and g.device == view.device:
+                    view.copy_(g)
+                else:
+                    view.zero_()
+                p.grad = view
 
     def zero(self):
         self.flat.zero_()
 
     def all_reduce(self):
+        self.check()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 

@@ -158,8 +158,10 @@ def time_kernels(w, B, L, device):
 
 
 def cpu_baseline(w, L, seconds_budget=20.0):
-    """numpy oracle training step (fp32, BLAS threads = all cores) on a bounded sample of the same workload."""
-    from oracle import ltr_oracle as O, model_oracle as M
+    """the reference training step on this box's host cores, on a bounded sample of the same workload.  For the workloads
+    whose loss it covers this is oracle/torch_port.py -- the same computation stated with the torch CPU operators the
+    reference itself calls (kind "port", torch threads = all cores); otherwise the numpy oracle (oracle/model_oracle.py)."""
+    from oracle import ltr_oracle as O, model_oracle as M, torch_port as TP
     cfg = dict(n_features=w["n_features"], fc_sizes=list(w["fc_sizes"]), fc_activation=None, fc_input_norm=False, N=w["N"],
                d_ff=w["d_ff"], h=w["h"], output_activation=None)
     Bs = 16 if w["N"] else 64
@@ -167,24 +169,97 @@ def cpu_baseline(w, L, seconds_budget=20.0):
     x = rng.standard_normal((Bs, L, w["n_features"])).astype(np.float32)
     y = rng.choice(5, size=(Bs, L), p=[0.52, 0.32, 0.13, 0.02, 0.01]).astype(np.float32)
     params = M.init_params(cfg, seed=0)
-    opt = M.Adam(params, lr=1e-3)
-    la = dict(w.get("loss_args", {}))
-    la.pop("stochastic", None)
-    lossfn = {"approxNDCGLoss": lambda s, t: O.approxndcg(s, t), "listNet": lambda s, t: O.listnet(s, t),
-              "neuralNDCG": lambda s, t: O.neuralndcg(s, t, **la), "lambdaLoss": lambda s, t: O.lambdaloss(s, t, **la),
-              "listMLE": lambda s, t: O.listmle(s, t, np.arange(L))}[w["loss"]]
-    M.train_step(params, cfg, opt, x, y, lossfn)        # warm-up
+    used = os.cpu_count()
+    if w["loss"] in TP.LOSSES:
+        stp = TP.Stepper(params, cfg, w["loss"], lr=1e-3)
+        xt, yt = torch.tensor(x), torch.tensor(y)
+        step = lambda: stp.step(xt, yt)  # noqa: E731
+        # torch's intra-op pool does not scale to every core of a big host (256 threads on this workload run 200x slower
+        # than 8): take the best of a few pool sizes, each timed on a couple of steps, and report the one used
+        best = None
+        for nt in sorted({min(8, used), min(16, used), min(32, used), min(64, used)}):
+            torch.set_num_threads(nt)
+            step()
+            t0 = time.perf_counter()
+            k = 0
+            while k < 8 and time.perf_counter() - t0 < 2.5:
+                step()
+                k += 1
+            rate = k / (time.perf_counter() - t0)
+            if best is None or rate > best[0]:
+                best = (rate, nt)
+        used = best[1]
+        torch.set_num_threads(used)
+        seconds_budget = 12.0
+        what = "torch CPU port of the reference step (oracle/torch_port.py), fp32, %d torch threads (best of 8/16/32/64)" % used
+    else:
+        opt = M.Adam(params, lr=1e-3)
+        la = dict(w.get("loss_args", {}))
+        la.pop("stochastic", None)
+        lossfn = {"neuralNDCG": lambda s, t: O.neuralndcg(s, t, **la), "lambdaLoss": lambda s, t: O.lambdaloss(s, t, **la),
+                  "listMLE": lambda s, t: O.listmle(s, t, np.arange(L))}[w["loss"]]
+        step = lambda: M.train_step(params, cfg, opt, x, y, lossfn)  # noqa: E731
+        what = "numpy oracle (oracle/model_oracle.py), fp32, BLAS on all cores"
+    step()        # warm-up
     t0 = time.perf_counter()
     n = 0
     while True:
-        M.train_step(params, cfg, opt, x, y, lossfn)
+        step()
         n += 1
         el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 50:
+        if el > seconds_budget or n >= 200:
             break
-    return dict(value=round(n * Bs * L / el, 1), unit="slate-items/s", cores=os.cpu_count(), kind="port",
-                sample="%d training steps of %d slates x %d items, numpy oracle (oracle/model_oracle.py), fp32, BLAS on all cores"
-                       % (n, Bs, L))
+    out = dict(value=round(n * Bs * L / el, 1), unit="slate-items/s", cores=used, host_cores=os.cpu_count(), kind="port",
+               sample="%d training steps of %d slates x %d items, %s" % (n, Bs, L, what))
+    # the REAL reference (allegro/allRank's own loss_batch on CPU torch) cannot run on the GPU box; its timing on the build
+    # container's cores is committed next to the script that produced it (tests/golden/make_ref_cpu_timing.py)
+    try:
+        ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_cpu_timing.json")))
+        if w["N"] == 2 and w["d_ff"] == 2048 and w["n_features"] == 136 and L == 240 and w["loss"] == "approxNDCGLoss":
+            out["reference_build_box"] = dict(value=ref["value"], unit=ref["unit"], cores=ref["cores"], cpu=ref.get("cpu"),
+                                              kind="reference (allrank loss_batch on CPU torch %s, build container)" % ref.get("torch"),
+                                              points=ref["points"])
+    except Exception:
+        pass
+    return out
+
+
+def _self_spawn(n):
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL peer buffers) -- see the environment notes
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def gemm_error_vs_fp64(w, B, L, device, gemm):
+    """max |C - C_fp64| / max(|A| |W|^T) of the FFN-1 projection at the benchmarked shape (full launch, so the kernel the
+    step uses is the one measured; the fp64 reference covers a 4096-row sample of it)."""
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    g = torch.Generator(device=device).manual_seed(1234)
+    Mrows, Nn, Kk = B * L, w["d_ff"], w["fc_sizes"][-1]
+    A_ = torch.randn(Mrows, Kk, device=device, generator=g)
+    W_ = torch.randn(Nn, Kk, device=device, generator=g) / Kk ** 0.5
+    b_ = torch.randn(Nn, device=device, generator=g)
+    C_ = torch.empty(Mrows, Nn, device=device)
+    if gemm == "hipblaslt":
+        torch.addmm(b_, A_, W_.t(), out=C_)
+    else:
+        LB.check(lib.ltrx_gemm_nt(LB.ptr(A_), Kk, LB.ptr(W_), Kk, LB.ptr(C_), Nn, Mrows, Nn, Kk, LB.ptr(b_), 0, None, 0, 0.0, 0, None,
+                                  1 if gemm == "split_bf16_strict" else 0, LB.stream_of(A_)), "gemm_nt")
+    rows = torch.linspace(0, Mrows - 1, min(4096, Mrows), device=device).long()
+    ref = A_[rows].double() @ W_.double().t() + b_.double()
+    scale = (A_[rows].abs().double() @ W_.abs().double().t()).max()
+    return float(((C_[rows].double() - ref).abs().max() / scale).item())
 
 
 def main():
@@ -208,6 +283,11 @@ def main():
     ap.add_argument("--engine", default="fused", choices=["fused", "autograd"],
                     help="fused: explicit hipGraph-captured step (engine.FusedTrainer); autograd: nn.Module + torch autograd/Adam")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RCCL), exactly
+        # the command the docstring shows; rank 0 of the child job prints the JSON line
+        raise SystemExit(_self_spawn(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -286,6 +366,27 @@ def main():
         probe_us = 1e3 * sum(ts) / len(ts)
         trainer.use_graph, trainer.probe = use_graph, None
 
+    # multi-rank: how much of the gradient all-reduce is exposed = timed step - the same step with the collective skipped
+    comm = None
+    if world > 1 and args.engine == "fused":
+        trainer.comm_enabled = False
+        for i in range(2):
+            one_step(i)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(i)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_nocomm = float(t.item()) / args.steps * 1e3
+        ms = dt / args.steps * 1e3
+        comm = dict(allreduce_bytes_per_step=int(4 * trainer.nflat), buckets=len(trainer._buckets), backend=dist.get_backend(),
+                    ms_per_step_without_allreduce=round(ms_nocomm, 4), exposed_ms=round(max(ms - ms_nocomm, 0.0), 4),
+                    overlapped=bool(ms - ms_nocomm < 0.05 * ms))      # "overlapped" = less than 5 % of the step is exposed
+
     if rank == 0:
         items = args.steps * B * L * world
         value = items / dt
@@ -298,15 +399,11 @@ def main():
         name, k = max(kern.items(), key=lambda kv: kv[1]["sec"] * kv[1]["launches_per_step"])
         if name.startswith("ltrx_gemm"):
             alg = k["flops"] / k["sec"] / 1e12            # algorithmic: the 2*M*N*K flop of the fp32 GEMM it replaces
-            traffic = None
-            try:                                           # HBM bytes per launch from the committed PMC passes (same shape only)
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_gemm256.json" if "nt256" in name else "r01_pmc_gemm.json")))
-                if [pm["shape"]["M"], pm["shape"]["N"], pm["shape"]["K"]] == k["shape"]:
-                    traffic = pm["derived"]["nt_hbm_read_bytes_corrected"] + pm["derived"]["nt_hbm_write_bytes"]
-            except Exception:
-                traffic = None
+            traffic = None       # PMC counters need their own rocprofv3 passes (never inside a timed run): see traffic_source
             roof = dict(kernel=name, bound="mfma", achieved=round(alg, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(alg / PEAK_BF16_MFMA_TFLOPS, 4), traffic=traffic, avg_launch_us=round(k["sec"] * 1e6, 1),
+                        frac=round(alg / PEAK_BF16_MFMA_TFLOPS, 4), traffic=traffic,
+                        traffic_source="profiles/ (rocprofv3 --pmc passes of tools/lab/pmc_gemm2.sh; not collected inside bench.py)",
+                        avg_launch_us=round(k["sec"] * 1e6, 1),
                         timing="HIP events around the %d FFN-1 launches of 5 eager training steps after the timed region" % (5 * w["N"]),
                         back_to_back_launch_us=round(k.get("sec_back_to_back", k["sec"]) * 1e6, 1),
                         algorithmic_flops_per_launch=k["flops"], arithmetic="bf16 MFMA, fp32 accumulate, 3 products per fp32 product (split-bf16)",
@@ -327,7 +424,10 @@ def main():
             "metric": "slate-items/sec training (WEB30K synth, slate 240)", "value": round(value, 1),
             "unit": "slate-items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": ("f32 (split-bf16x3 GEMMs)" if (args.engine == "fused" and args.gemm == "split_bf16") else
+                      "f32 (split-bf16x6 GEMMs)" if (args.engine == "fused" and args.gemm == "split_bf16_strict") else "f32"),
+            "data": "synthetic",
             "config": {"workload": w["desc"], "slates_per_gpu": B, "slate_len": L, "global_batch": B * world,
                        "optimizer": "Adam lr=1e-3", "dropout": args.dropout, "slates": ("ragged (lognormal lengths)" + (", compact execution" if args.compact else "") if args.ragged else "dense"),
                        "arithmetic": ("fp32 storage and accumulation; dense projections as fp32-accurate split-bf16 (3 bf16 MFMA products per fp32 product); attention on the exact fp32 MFMA" if (args.engine == "fused" and args.gemm != "hipblaslt") else "fp32 (hipBLASLt GEMMs, fp32 MFMA attention)"), "engine": args.engine, "gemm": args.gemm if args.engine == "fused" else "hipblaslt", "parallelism": "slate-sharded dp%d" % world,
@@ -354,6 +454,31 @@ def main():
                 out["value_at_64_slates_per_gpu"] = round(20 * 64 * L / (time.perf_counter() - t0), 1)
             except Exception as e:      # never let the side measurement break the contract line
                 out["value_at_64_slates_per_gpu"] = "failed: %r" % (e,)
+        out["comm"] = comm
+        if w["N"] and args.engine == "fused":
+            try:                               # measured arithmetic error of the benchmarked GEMM (and of the alternatives)
+                out["gemm_max_rel_err_vs_fp64"] = {g_: gemm_error_vs_fp64(w, B, L, device, g_) for g_ in
+                                                   sorted({args.gemm, "split_bf16_strict", "hipblaslt"})}
+            except Exception as e:
+                out["gemm_max_rel_err_vs_fp64"] = "failed: %r" % (e,)
+        if world == 1 and args.engine == "fused" and w["N"] and not args.no_side_pass and not args.compact:
+            for key, gm in (("value_strict_fp32", "split_bf16_strict"), ("value_hipblaslt_fp32", "hipblaslt")):
+                if gm == args.gemm:
+                    continue
+                try:
+                    m2 = build_model(w, device, args.dropout)
+                    t2 = FusedTrainer(m2, w["loss"], w.get("loss_args", {}), B, L, lr=1e-3, world_size=1, use_graph=True, gemm=gm)
+                    for i in range(4):
+                        t2.step(x[:B], y[:B], idx[:B])
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(10):
+                        t2.step(x[:B], y[:B], idx[:B])
+                    torch.cuda.synchronize()
+                    out[key] = round(10 * B * L / (time.perf_counter() - t0), 1)
+                    del t2, m2
+                except Exception as e:
+                    out[key] = "failed: %r" % (e,)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, L)
         else:

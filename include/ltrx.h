@@ -280,7 +280,11 @@ int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int
                  ltrx_stream_t stream);
 /* tuning hook: tile variant of ltrx_gemm_nt (0 auto, 1 128x128x32, 2 128x128x64, 3 256x128x32, 4 256x128x64) */
 void ltrx_gemm_set_variant(int variant);
+/* workspace for ltrx_gemm_tn sized for M rows: sufficient for EVERY call with the same NP, KP and any row count <= M
+ * (variable-length batches re-use one workspace); ltrx_gemm_tn_splits = the split count a call with exactly M rows uses
+ * (each split owns an [NP,KP] slab + 2 bias rows of the workspace). */
 size_t ltrx_gemm_tn_workspace_bytes(int M, int NP, int KP);
+int ltrx_gemm_tn_splits(int M, int NP, int KP);
 int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, float* bias_out, int M, int NP, int KP, int strict,
                  void* ws, ltrx_stream_t stream);
 

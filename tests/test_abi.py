@@ -49,6 +49,22 @@ def test_workspace_queries_and_argument_validation_run_without_a_gpu(libpath):
     assert lib.ltrx_mha_fwd(None, None, None, None, 1, 1, 1, 64, 64, None, 64, None, 0.0, 0, None, None, None, None) == -1
 
 
+def test_wgrad_workspace_covers_every_smaller_row_count(libpath):
+    """a variable-length batch calls ltrx_gemm_tn with a different row count every step against a
+    workspace sized once for B*L rows; the split plan is not monotone in the row count, so the size query must be an
+    upper bound over all row counts <= M."""
+    from allrank_amd import _lib
+    lib = _lib.lib()
+    for (M, NP, KP) in [(16 * 240, 2048, 512), (16 * 240, 512, 2048), (64 * 240, 1024, 256), (64 * 240, 256, 1024),
+                        (100 * 50, 512, 512), (256 * 240, 1536, 512), (5000, 96, 136), (4096, 768, 256)]:
+        have = lib.ltrx_gemm_tn_workspace_bytes(M, NP, KP)
+        step = 1 if M <= 6000 else 7
+        for m in list(range(1, M + 1, step)) + [M]:
+            sp = lib.ltrx_gemm_tn_splits(m, NP, KP)
+            need = (sp * NP * KP + 2 * sp * NP) * 4
+            assert need <= have, (M, NP, KP, m, sp, need, have)
+
+
 def test_loss_signatures_mirror_reference():
     """same parameter names and defaults as allrank/models/losses/*.py"""
     from allrank_amd import losses, metrics

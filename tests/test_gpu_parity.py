@@ -460,6 +460,22 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 16 and rec["value"] > 0 and np.isfinite(rec["last_loss"])
 
 
+def test_bench_spawns_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no torchrun around it (the form the driver uses) must start two ranks itself and
+    print a line with n_gpus == 2 (gloo here: the test box has one GPU; on a multi-GPU node the backend is RCCL)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["LTRX_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--slates-per-gpu", "8",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 16 and rec["value"] > 0 and np.isfinite(rec["last_loss"])
+    assert rec["comm"]["allreduce_bytes_per_step"] > 0 and rec["comm"]["exposed_ms"] >= 0.0
+
+
 def test_sharded_step_equals_single_rank_step():
     """slate-sharded data parallelism reproduces the single-process step: 2 ranks x 4 slates (gloo, one GPU) vs
     1 rank x 8 slates -- same loss (sum of rank shares) and same updated weights."""

@@ -208,3 +208,25 @@ def test_row4_kats_from_the_reference_tests():
     # test_loss_ordinal.py:20-24
     t = (np.asarray([[2.0, 1.0, 0.0]])[:, :, None] >= np.arange(1, 3)[None, None, :]).astype(float).tolist()
     assert t == [[[1.0, 1.0], [1.0, 0.0], [0.0, 0.0]]]
+
+
+def test_torch_port_matches_numpy_oracle():
+    """oracle/torch_port.py (bench.py's cpu_baseline leg: the reference step on CPU torch operators) == the numpy oracle,
+    which the tests above pin to the reference's own golden vectors: three training steps, losses and updated weights."""
+    import torch
+    from oracle import model_oracle as M, torch_port as T
+    cfg = dict(n_features=20, fc_sizes=[32], fc_activation=None, fc_input_norm=False, N=2, d_ff=64, h=4, output_activation=None)
+    for loss, ofn in (("approxNDCGLoss", lambda s, t: O.approxndcg(s, t)), ("listNet", lambda s, t: O.listnet(s, t))):
+        p = M.init_params(cfg, seed=3)
+        rng = np.random.default_rng(0)
+        B, L = 4, 30
+        x = rng.standard_normal((B, L, 20)).astype(np.float32)
+        y = rng.integers(0, 5, (B, L)).astype(np.float32)
+        y[1, 20:] = -1
+        x[1, 20:] = 0
+        st = T.Stepper(p, cfg, loss)
+        opt = M.Adam(p, lr=1e-3)
+        for i in range(3):
+            lt = st.step(torch.tensor(x), torch.tensor(y))
+            lo = float(M.train_step(p, cfg, opt, x, y, ofn)[0])
+            assert abs(lt - lo) <= (1e-6 if i == 0 else 1e-4) * (1 + abs(lo)), (loss, i, lt, lo)
