@@ -69,10 +69,6 @@ SIGNATURES = {
     "ltrx_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltrx_gemm_tn_splits": (_i, [_i, _i, _i]),
     "ltrx_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "ltrx_to_image": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
-    "ltrx_to_image_batch": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
-    "ltrx_gemm_nt_img": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _f, ctypes.c_uint32, _vp, _vp]),
-    "ltrx_gemm_tn_img": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ltrx_selftest_mfma32x32x2": (_i, [_vp, _vp, _vp, _vp]),
     "ltrx_mha_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp]),
 }

@@ -288,27 +288,6 @@ int ltrx_gemm_tn_splits(int M, int NP, int KP);
 int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, float* bias_out, int M, int NP, int KP, int strict,
                  void* ws, ltrx_stream_t stream);
 
-/* The same projections with operands that ARRIVE PRE-SPLIT ("HL16 images", allrank_amd/csrc/ltrx_gemm_img.hip): an image of an
- * fp32 matrix X[R][K] (K % 16 == 0) has X's byte size and row pitch; per row and 16-column block b, bytes [64b, 64b+32) hold
- * bf16 hi = bf16(x) of the 16 elements and [64b+32, 64b+64) hold bf16 lo = bf16(x - hi).  Producers (LayerNorm, GEMM
- * epilogues, attention, the post-Adam weight refresh) write the split once; the GEMMs stage tiles with LDS-DMA and run the
- * same three-product bf16 MFMA arithmetic as ltrx_gemm_nt / ltrx_gemm_tn (nn.Linear of model.py:35-44, transformer.py:193-203,
- * 221-227 and their input / weight gradients).  Leading dimensions are in 4-byte units like the fp32 tensors they replace.
- *   ltrx_to_image / ltrx_to_image_batch: fp32 -> image (the batch form converts a descriptor table of {src offset, dst offset,
- *       rows, K} in one launch: the weights and their transposes after every optimizer step).
- *   ltrx_gemm_nt_img: C[M,N] = epi(A[M,K] B[N,K]^T + bias); N % 256 == 0, K % 16 == 0, any M; C is fp32 or (c_is_image) an
- *       image; act / aux / dropout as ltrx_gemm_nt, aux (act 2) being the IMAGE of the saved post-activation tensor.
- *   ltrx_gemm_tn_img: C[NP,KP] = A[M,NP]^T B[M,KP] (+ bias_out = column sums of A); NP, KP % 256 == 0, M % 16 == 0;
- *       workspace: ltrx_gemm_tn_workspace_bytes(M, NP, KP). */
-int ltrx_to_image(const float* X, int ldx, int rows, int K, void* image, int ld_image, ltrx_stream_t stream);
-int ltrx_to_image_batch(const float* src, void* dst, const long long* desc, const int* unit_start, int n, int total_units,
-                        ltrx_stream_t stream);
-int ltrx_gemm_nt_img(const void* A_image, int lda, const void* B_image, int ldb, void* C, int ldc, int c_is_image, int M, int N,
-                     int K, const float* bias, int act, const void* aux_image, int ldaux, float drop_p, uint32_t drop_seed,
-                     const uint32_t* drop_step, ltrx_stream_t stream);
-int ltrx_gemm_tn_img(const void* A_image, int lda, const void* B_image, int ldb, float* C, float* bias_out, int M, int NP, int KP,
-                     void* ws, ltrx_stream_t stream);
-
 /* Test hook: D[32x32] = A[32x2] * B[2x32] with ONE v_mfma_f32_32x32x2_f32, written through the operand / result
  * lane layout the attention kernels assume.  Lets the parity suite tell a layout bug from a logic bug. */
 int ltrx_selftest_mfma32x32x2(const float* A, const float* B, float* D, ltrx_stream_t stream);
