@@ -69,6 +69,12 @@ SIGNATURES = {
     "ltrx_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltrx_gemm_tn_splits": (_i, [_i, _i, _i]),
     "ltrx_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ltrx_layernorm_torch_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "ltrx_posenc_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
+    "ltrx_posenc_table_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ltrx_scale_inplace": (_i, [_vp, _sz, _f, _vp]),
+    "ltrx_out_act_fwd": (_i, [_vp, _sz, _i, _vp, _vp]),
+    "ltrx_out_act_bwd": (_i, [_vp, _vp, _sz, _i, _vp, _vp]),
     "ltrx_selftest_mfma32x32x2": (_i, [_vp, _vp, _vp, _vp]),
     "ltrx_mha_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp]),
 }

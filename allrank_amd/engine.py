@@ -33,9 +33,13 @@ class Trainer(object):
         gb = global_batch if global_batch is not None else xb.shape[0] * self.world
         if self.world > 1:
             with sharding.shard_context(gb, self.group):
-                loss = self.loss_func(self.model(xb, mask, indices), yb)
+                out = self.model(xb, mask, indices)
+                loss = self.loss_func(out, yb)
         else:
-            loss = self.loss_func(self.model(xb, mask, indices), yb)
+            out = self.model(xb, mask, indices)
+            loss = self.loss_func(out, yb)
+        # scores of THIS forward (model.py:82-92: d_output > 1 sums the last axis), for train metrics without a second pass
+        self.last_scores = out.detach() if out.dim() == 2 else out.detach().sum(-1)
         loss.backward()
         if self.world > 1:
             self.flat.all_reduce()
@@ -68,9 +72,9 @@ class FusedTrainer(object):
       (site seed ^ per-step device word, element index), generated inside the producing kernel's epilogue (GEMM bias+
       ReLU+dropout, the residual add of the LayerNorm kernel, the attention probabilities) and REGENERATED in the backward
       -- no mask tensors, and a replayed hipGraph draws fresh masks because the step word lives in device memory.
-    Supported model family = what the hot path names: FCModel (no input_norm, activation None/ReLU) -> optional encoder
-    (no positional encoding) -> OutputLayer(d_output=1, no activation).  Anything else raises NotImplementedError (use
-    ``Trainer``).
+    Supported model family: FCModel (optional input_norm = nn.LayerNorm, activation None/ReLU) -> optional encoder with
+    optional fixed / learned positional encoding (positional.py:15-77) -> OutputLayer(d_output=1, activation None / Sigmoid /
+    Tanh).  Anything else (d_output > 1, other FC activations) raises NotImplementedError (use ``Trainer``).
     """
 
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
@@ -87,7 +91,7 @@ class FusedTrainer(object):
         import torch.nn as nn
         from . import _lib as LB
         from .losses import FusedLoss
-        from .model import FCModel, Encoder, LTRModel
+        from .model import FCModel, Encoder, LTRModel, LearnedPositionalEncoding
         self.LB = LB
         self.lib = LB.lib()
         if gemm not in ("split_bf16", "split_bf16_strict", "hipblaslt"):
@@ -101,8 +105,7 @@ class FusedTrainer(object):
         if not isinstance(model, LTRModel) or not isinstance(model.input_layer, FCModel):
             raise NotImplementedError("FusedTrainer needs an allrank_amd LTRModel with an FCModel input block")
         fc = model.input_layer
-        if not isinstance(fc.input_norm, nn.Identity):
-            raise NotImplementedError("FusedTrainer: FCModel.input_norm is not on the fused path")
+        self.in_norm = None if isinstance(fc.input_norm, nn.Identity) else fc.input_norm      # nn.LayerNorm (model.py:27)
         self.p_fc = float(fc.dropout.p) if dropout else 0.0
         if seed is None:
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
@@ -114,11 +117,19 @@ class FusedTrainer(object):
         else:
             raise NotImplementedError("FusedTrainer: FC activation %r" % (fc.activation,))
         enc = model.encoder if isinstance(model.encoder, Encoder) else None
-        if enc is not None and enc.position is not None:
-            raise NotImplementedError("positional encoding")
+        self.pos = enc.position if (enc is not None and enc.position is not None) else None
+        self.pos_learned = isinstance(self.pos, LearnedPositionalEncoding)
         out = model.output_layer
-        if out.d_output != 1 or not isinstance(out.activation, nn.Identity):
-            raise NotImplementedError("FusedTrainer: OutputLayer must have d_output == 1 and no activation")
+        if out.d_output != 1:
+            raise NotImplementedError("FusedTrainer: OutputLayer must have d_output == 1")
+        if isinstance(out.activation, nn.Identity):
+            self.out_act = 0
+        elif isinstance(out.activation, nn.Sigmoid):
+            self.out_act = 1
+        elif isinstance(out.activation, nn.Tanh):
+            self.out_act = 2
+        else:
+            raise NotImplementedError("FusedTrainer: output activation %r" % (out.activation,))
         dev = next(model.parameters()).device
         self.dev = dev
         self.enc = enc
@@ -134,8 +145,12 @@ class FusedTrainer(object):
 
         # ---- flat parameter layout (16-byte aligned segments; q,k,v weights and biases adjacent) ----
         order = []
+        if self.in_norm is not None:
+            order += [self.in_norm.weight, self.in_norm.bias]
         for lyr in fc.layers:
             order += [lyr.weight, lyr.bias]
+        if self.pos_learned:
+            order += [self.pos.pe.weight]
         if enc is not None:
             for lay in enc.layers:
                 lin = lay.self_attn.linears
@@ -215,6 +230,20 @@ class FusedTrainer(object):
         M, d = self.M, self.d
         f32 = dict(dtype=torch.float32, device=dev)
         self.x_in = torch.zeros((M, self.fc_sizes[0]), **f32)
+        if self.in_norm is not None:
+            F_ = self.fc_sizes[0]
+            self.x_norm = torch.zeros((M, F_), **f32)
+            self.mean_in = torch.zeros(M, **f32)
+            self.rstd_in = torch.zeros(M, **f32)
+            self.d_in = torch.zeros((M, F_), **f32)
+            self.ws_ln_in = torch.empty(max(self.lib.ltrx_layernorm_bwd_workspace_bytes(M, F_), 64), dtype=torch.uint8, device=dev)
+        if self.pos is not None:
+            self.x_pe = torch.zeros((M, d), **f32)
+            self.idx_rows = torch.full((M,), -1, dtype=torch.int64, device=dev)      # original rank of every row (-1: none)
+            if self.pos_learned:
+                self.pos_pad = int(self.pos.pe.padding_idx)
+            else:
+                self.pos_pad = int(self.pos.padding_idx)
         self.y_in = torch.zeros((B, L), **f32)
         self.mask = torch.zeros((B, L), dtype=torch.uint8, device=dev)
         self.fc_out = [torch.zeros((M, s), **f32) for s in self.fc_sizes[1:]]
@@ -271,7 +300,7 @@ class FusedTrainer(object):
             self.ws_tn = torch.empty(max(nb, 64), dtype=torch.uint8, device=dev)
             # transposed weight copies for the input-gradient GEMMs (refreshed after every optimizer step by ONE batched
             # transpose launch): all copies live in one flat buffer, the descriptor table is built once
-            tw = [l.weight for l in fc.layers[1:]]
+            tw = [l.weight for l in (fc.layers if self.in_norm is not None else fc.layers[1:])]
             srcs = [(self._pv[id(p)][0], p.shape[0], p.shape[1], ("w", id(p))) for p in tw]
             if enc is not None:
                 for li, st in enumerate(self.layers):
@@ -428,9 +457,18 @@ class FusedTrainer(object):
         fc = self.model.input_layer
         # ---------------- forward ----------------
         h = self.x_in
+        if self.in_norm is not None:                              # FCModel.input_norm (model.py:39)
+            self.LB.check(lib.ltrx_layernorm_torch_fwd(P(h), P(W(self.in_norm.weight)), P(W(self.in_norm.bias)), M, self.fc_sizes[0],
+                                                       float(self.in_norm.eps), P(self.x_norm), P(self.mean_in), P(self.rstd_in),
+                                                       self._st()), "layernorm_torch_fwd")
+            h = self.x_norm
         for i, lyr in enumerate(fc.layers):
             self._lin_fwd(h, W(lyr.weight), W(lyr.bias), self.fc_out[i], self.fc_act, self.p_fc, self._site(1000 + i))
             h = self.fc_out[i]
+        if self.pos is not None:                                  # transformer.py:51-52: x = sqrt(d) x + pe[rank]
+            self.LB.check(lib.ltrx_posenc_fwd(P(h), P(self._pos_table()), P(self.idx_rows), P(kpm), M, d, self.pos_pad, float(d) ** 0.5,
+                                              P(self.x_pe), self._st()), "posenc_fwd")
+            h = self.x_pe
         x = h                                                     # residual stream
         p_prev, s_prev = 0.0, 0                                   # dropout of the pending FFN branch (sublayer[1] of layer i-1)
         for i, st in enumerate(self.layers):
@@ -470,8 +508,11 @@ class FusedTrainer(object):
             feat = self.xf
         else:
             feat = x
-        self.LB.check(lib.ltrx_score_head_fwd(P(feat), P(W(out.w_1.weight)), P(W(out.w_1.bias)), M, d,
-                                              P(self.scores_c if self.compact else self.scores), self._st()), "score_head_fwd")
+        sc_rows = self.scores_c if self.compact else self.scores
+        self.LB.check(lib.ltrx_score_head_fwd(P(feat), P(W(out.w_1.weight)), P(W(out.w_1.bias)), M, d, P(sc_rows), self._st()),
+                      "score_head_fwd")
+        if self.out_act:                                          # OutputLayer activation (model.py:117), in place
+            self.LB.check(lib.ltrx_out_act_fwd(P(sc_rows), M, self.out_act, P(sc_rows), self._st()), "out_act_fwd")
         if self.compact:                                          # packed scores -> the padded [B, L] grid of the loss kernels
             self.scores.zero_()
             self.LB.check(lib.ltrx_scatter_rows(P(self.scores_c), 1, P(self.idx), self.n_valid, 1, P(self.scores), 1, self._st()),
@@ -484,6 +525,8 @@ class FusedTrainer(object):
             self.LB.check(lib.ltrx_gather_rows(P(dsc), 1, P(self.idx), self.n_valid, M, 1, P(self.dsc_c), 1, self._st()),
                           "gather_rows")
             dsc = self.dsc_c
+        if self.out_act:                                          # d loss / d pre-activation = d loss / d score * act'(score)
+            self.LB.check(lib.ltrx_out_act_bwd(P(dsc), P(sc_rows), M, self.out_act, P(dsc), self._st()), "out_act_bwd")
         self.LB.check(lib.ltrx_score_head_bwd(P(dsc), P(feat), P(W(out.w_1.weight)), M, d, P(ga), P(G(out.w_1.weight)),
                                               P(G(out.w_1.bias)), P(self.ws_head), self._st()), "score_head_bwd")
         if self.N:
@@ -524,6 +567,11 @@ class FusedTrainer(object):
                 self._bucket_done(self.N - 1 - i)
         else:
             ds, other = ga, gb
+        if self.pos is not None:                                  # backward of x = sqrt(d) fc_out + pe[rank]
+            if self.pos_learned:
+                self.LB.check(lib.ltrx_posenc_table_bwd(P(ds), P(self.idx_rows), P(kpm), M, d, self.pos_pad, P(G(self.pos.pe.weight)),
+                                                        self._st()), "posenc_table_bwd")
+            self.LB.check(lib.ltrx_scale_inplace(P(ds), M * d, float(d) ** 0.5, self._st()), "scale_inplace")
         # FC stack
         for i in range(self.nfc - 1, -1, -1):
             lyr = fc.layers[i]
@@ -532,8 +580,16 @@ class FusedTrainer(object):
                     self._relu_bwd(ds, self.fc_out[i], self.p_fc)
                 elif self.p_fc:
                     self._drop_apply(ds, ds, self.p_fc, self._site(1000 + i))
-            inp = self.x_in if i == 0 else self.fc_out[i - 1]
+            inp = (self.x_norm if self.in_norm is not None else self.x_in) if i == 0 else self.fc_out[i - 1]
             self._lin_wgrad(ds, inp, G(lyr.weight), G(lyr.bias))
+            if i == 0 and self.in_norm is not None:
+                # nn.LayerNorm parameter gradients: dw = sum dy * xhat, db = sum dy with dy = ds W_0 (the input itself needs no
+                # gradient; ltrx_layernorm_bwd's da / db formulas only use the saved mean and rstd, its dx output is scratch)
+                self._lin_dgrad(ds, W(lyr.weight), self._wT.get(id(lyr.weight)), self.d_in)
+                self.LB.check(lib.ltrx_layernorm_bwd(P(self.d_in), P(self.x_in), P(W(self.in_norm.weight)), P(self.mean_in), P(self.rstd_in),
+                                                     None, M, self.fc_sizes[0], float(self.in_norm.eps), P(self.d_in),
+                                                     P(G(self.in_norm.weight)), P(G(self.in_norm.bias)), P(self.ws_ln_in), self._st()),
+                              "layernorm_bwd(input_norm)")
             if i > 0:
                 self._lin_dgrad(ds, W(lyr.weight), self._wT.get(id(lyr.weight)), self.fc_dgrad[i - 1],
                                 relu_of=self.fc_out[i - 1] if self.fc_act == 1 else None, p=self.p_fc,
@@ -541,6 +597,9 @@ class FusedTrainer(object):
                 ds = self.fc_dgrad[i - 1]
         self._bucket_done(len(self._buckets) - 1)
         return loss
+
+    def _pos_table(self):
+        return self.W(self.pos.pe.weight) if self.pos_learned else self.pos.pe
 
     def _adam(self):
         P = self.LB.ptr
@@ -633,6 +692,14 @@ class FusedTrainer(object):
             self._pack(xb.reshape(self.M, -1).contiguous(), lengths)
         else:
             self.x_in.copy_(xb.reshape(self.M, -1))
+        if self.pos is not None:
+            if indices is None:
+                raise ValueError("FusedTrainer: the model has a positional encoding, step() needs `indices`")
+            if self.compact:                                      # rank of every packed row; alignment rows -> padding row
+                self.idx_rows.fill_(-1)
+                self.idx_rows[:self.n_valid] = indices.reshape(-1)[self.idx[:self.n_valid].long()]
+            else:
+                self.idx_rows.copy_(indices.reshape(-1))
         if not self.use_graph or self.world > 1:
             with sharding.shard_context(int(self._divisor), self.group) if self.world > 1 else _null():
                 return self._full()

@@ -1,0 +1,217 @@
+"""The epoch loop of allRank with the reference's own signature -- ``fit`` of allrank/training/train_utils.py:78-147 -- so that
+``allrank_amd.install(fit=True)`` puts the explicit MI355X training step (engine.FusedTrainer) behind an UNMODIFIED
+``allrank/main.py`` (main.py:90 calls ``fit(model=..., loss_func=..., optimizer=..., scheduler=..., train_dl=..., valid_dl=...,
+config=..., device=..., output_dir=..., tensorboard_output_path=..., **asdict(config.training))``).
+
+What is kept from the reference loop: the arguments and their meaning, per-epoch order (train pass, validation pass, scheduler
+step incl. ReduceLROnPlateau on ``config.val_metric``, early stopping with EarlyStop's rule, early_stop.py:7-19), gradient clipping,
+the ``model.pkl`` state_dict written to ``output_dir`` (loadable by the reference: same keys and shapes), tensorboard scalars when the
+reference's writer is importable, and the returned dict {"epochs", "train_metrics", "val_metrics", "num_params"}.
+
+What changes (all outside the arithmetic of a step):
+  * a training step is ``FusedTrainer.step`` (hand-written HIP forward/backward/Adam, hipGraph replay) when the model family, the
+    loss and the optimizer allow it -- an allrank_amd LTRModel, a loss from allrank_amd.losses bound with functools.partial (what
+    main.py:83 builds once install() has rebound the names), torch.optim.Adam with default betas / eps / no weight decay -- and the
+    autograd ``Trainer`` (same kernels for attention / LayerNorm / loss, torch autograd + the given optimizer) otherwise;
+  * no ``loss.item()`` per step: the running loss is accumulated on the device, one host sync per epoch (train_utils.py:29);
+  * train metrics come from the scores of the training forward itself instead of a second full pass over ``train_dl`` in train()
+    mode (train_utils.py:99; same mode, same data);
+  * the last, short batch of an epoch (DataLoader drop_last=False) is topped up with fully padded slates for the static-shape step
+    and its loss is normalised by the real slate count;
+  * under an initialised ``torch.distributed`` group every rank takes its contiguous block of each global batch (the reference
+    wraps the model in nn.DataParallel instead, main.py:76-78; a DataParallel wrapper passed in is unwrapped).
+"""
+import functools
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import losses as E
+from . import metrics as EM
+from .engine import FusedTrainer, Trainer, PADDED_Y_VALUE
+from .parallel import shard_slates
+
+log = logging.getLogger("allrank_amd.fit")
+
+last_run = {}          # what the most recent fit() used: {"engine": "fused" | "autograd", "compact": bool, "reason": str}
+
+
+class _EarlyStop(object):
+    """allrank/training/early_stop.py:7-19"""
+
+    def __init__(self, patience):
+        self.patience, self.best_value, self.best_epoch = patience, 0.0, 0
+
+    def step(self, current_value, current_epoch):
+        if current_value > self.best_value:
+            self.best_value, self.best_epoch = current_value, current_epoch
+
+    def stop_training(self, current_epoch):
+        return current_epoch - self.best_epoch > self.patience
+
+
+def _tensorboard(path):
+    try:
+        from allrank.utils.tensorboard_utils import TensorboardSummaryWriter
+        return TensorboardSummaryWriter(path)
+    except Exception:
+        return None
+
+
+def _fused_spec(model, loss_func, optimizer):
+    """(loss_name, loss_args, lr) if the explicit step can run this job, else (None, reason)"""
+    from .model import LTRModel
+    if not isinstance(model, LTRModel):
+        return None, "model is not an allrank_amd LTRModel"
+    if not isinstance(loss_func, functools.partial) or getattr(E, getattr(loss_func.func, "__name__", ""), None) is not loss_func.func:
+        return None, "loss is not a functools.partial of an allrank_amd loss"
+    if loss_func.args:
+        return None, "positional loss arguments"
+    if type(optimizer) is not torch.optim.Adam or len(optimizer.param_groups) != 1:
+        return None, "optimizer is not a single-group torch.optim.Adam"
+    g = optimizer.param_groups[0]
+    if tuple(g.get("betas", (0.9, 0.999))) != (0.9, 0.999) or g.get("eps", 1e-8) != 1e-8 or g.get("weight_decay", 0) != 0 \
+            or g.get("amsgrad", False) or g.get("maximize", False):
+        return None, "non-default Adam hyper-parameters"
+    return (loss_func.func.__name__, dict(loss_func.keywords or {}), float(g["lr"])), ""
+
+
+def _pad_batch(xb, yb, idx, B):
+    n = B - xb.shape[0]
+    if n <= 0:
+        return xb, yb, idx
+    return (torch.cat([xb, xb.new_zeros((n,) + tuple(xb.shape[1:]))]),
+            torch.cat([yb, yb.new_full((n, yb.shape[1]), float(PADDED_Y_VALUE))]),
+            torch.cat([idx, idx.new_full((n, idx.shape[1]), -1)]))
+
+
+def _evaluate(model, loss_func, dl, device, metrics):
+    """validation pass of train_utils.py:101-107: mean loss (weighted by batch size) and metric means, no autograd"""
+    tot, num = torch.zeros((), device=device), 0
+    acc = {name: [] for name in metrics}
+    with torch.no_grad():
+        for xb, yb, idx in dl:
+            xb, yb, idx = xb.to(device), yb.to(device), idx.to(device)
+            mask = yb == PADDED_Y_VALUE
+            tot += loss_func(model(xb, mask, idx), yb).detach().float() * xb.shape[0]
+            num += xb.shape[0]
+            sc = model.score(xb, mask, idx)
+            for name, ats in metrics.items():
+                acc[name].append(getattr(EM, name)(sc, yb, ats=ats))
+    out = {}
+    for name, ats in metrics.items():
+        vals = torch.cat(acc[name]).mean(0).cpu().numpy()
+        out.update({"%s_%d" % (name, at): v for at, v in zip(ats, vals)})
+    return float(tot.item()) / max(num, 1), out
+
+
+def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, config, gradient_clipping_norm, early_stopping_patience,
+        device, output_dir, tensorboard_output_path, use_fused=True, compact=None):
+    """Same positional / keyword arguments as the reference ``fit``; ``use_fused`` / ``compact`` are extensions (compact=None:
+    variable-length execution when less than 80 % of the first batch's slots are valid items)."""
+    import torch.distributed as dist
+    device = torch.device(device)
+    if isinstance(model, torch.nn.DataParallel):
+        model = model.module
+    metrics = dict(config.metrics)
+    val_metric = getattr(config, "val_metric", None)
+    writer = _tensorboard(tensorboard_output_path) if tensorboard_output_path else None
+    num_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    early_stop = _EarlyStop(early_stopping_patience)
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 else 0
+
+    spec, reason = _fused_spec(model, loss_func, optimizer) if use_fused else (None, "use_fused=False")
+    trainer, fused = None, False
+    first = next(iter(train_dl))
+    B_glob, L = int(first[0].shape[0]), int(first[0].shape[1])
+    lo, hi = shard_slates(B_glob, rank, world)
+    if spec is not None:
+        if compact is None:
+            compact = float((first[1] != PADDED_Y_VALUE).float().mean()) < 0.8
+        try:
+            trainer = FusedTrainer(model, spec[0], spec[1], hi - lo, L, lr=spec[2], world_size=world, use_graph=True,
+                                   gradient_clipping_norm=gradient_clipping_norm, compact=bool(compact))
+            fused = True
+        except (NotImplementedError, KeyError) as e:
+            reason = "FusedTrainer: %s" % (e,)
+    if trainer is None:
+        trainer = Trainer(model, loss_func, optimizer, gradient_clipping_norm, world, None)
+    last_run.clear()
+    last_run.update(engine="fused" if fused else "autograd", compact=bool(compact) if fused else False, reason=reason)
+    log.info("allrank_amd.fit: %s step%s", last_run["engine"], (" (" + reason + ")") if reason else "")
+
+    epoch, train_metrics, val_metrics = -1, {}, {}
+    for epoch in range(epochs):
+        model.train()
+        tot, num = torch.zeros((), device=device), 0
+        tm = {name: None for name in metrics}
+        for xb, yb, idx in train_dl:
+            real_glob = int(xb.shape[0])
+            xb, yb, idx = xb.to(device), yb.to(device), idx.to(device)
+            if world > 1:
+                a, b = shard_slates(real_glob, rank, world)
+                xb, yb, idx = xb[a:b], yb[a:b], idx[a:b]
+            real = int(xb.shape[0])
+            if fused:
+                xs, ys, ids = _pad_batch(xb, yb, idx, trainer.B)
+                loss = trainer.step(xs, ys, ids, global_batch=real_glob)
+                scores, labels = trainer.scores[:real], trainer.y_in[:real]
+            else:
+                loss = trainer.step(xb, yb, idx, global_batch=real_glob)
+                scores, labels = trainer.last_scores, yb
+            tot += loss.detach().float().reshape(()) * real_glob          # (sharded: this rank's share of the global-batch loss)
+            num += real
+            for name, ats in metrics.items():
+                v = getattr(EM, name)(scores, labels, ats=ats).sum(0)
+                tm[name] = v if tm[name] is None else tm[name] + v
+        stats = torch.cat([tot.reshape(1), torch.tensor([float(num)], device=device)] + [tm[n].float() for n in metrics if tm[n] is not None])
+        if world > 1:
+            dist.all_reduce(stats)
+        stats = stats.cpu().numpy()
+        n_all = max(stats[1], 1.0)
+        train_loss = float(stats[0]) / n_all
+        train_metrics, off = {}, 2
+        for name, ats in metrics.items():
+            if tm[name] is None:
+                continue
+            for at in ats:
+                train_metrics["%s_%d" % (name, at)] = float(stats[off]) / n_all
+                off += 1
+
+        model.eval()
+        val_loss, val_metrics = _evaluate(model, loss_func, valid_dl, device, metrics)
+
+        lr_now = optimizer.param_groups[0]["lr"]
+        if writer is not None:
+            tb = {("train", "loss"): train_loss, ("val", "loss"): val_loss, ("train", "lr"): lr_now}
+            tb.update({("train", k): v for k, v in train_metrics.items()})
+            tb.update({("val", k): v for k, v in val_metrics.items()})
+            writer.save_to_tensorboard(tb, epoch)
+        log.info("Epoch : %d Train loss: %s Val loss: %s %s %s", epoch, train_loss, val_loss,
+                 " ".join("Train %s %s" % kv for kv in train_metrics.items()), " ".join("Val %s %s" % kv for kv in val_metrics.items()))
+
+        current = val_metrics.get(val_metric)
+        if scheduler:                                              # train_utils.py:117-122
+            if fused:
+                optimizer._opt_called = True                       # (torch's "scheduler.step() before optimizer.step()" check: in
+                #                                                     the fused run the optimizer object only carries the learning rate)
+            if type(scheduler) is torch.optim.lr_scheduler.ReduceLROnPlateau:
+                scheduler.step(val_metrics[val_metric])
+            else:
+                scheduler.step()
+            if fused:                                              # the scheduler edits optimizer.param_groups; the fused Adam follows
+                trainer.set_lr(float(optimizer.param_groups[0]["lr"]))
+        early_stop.step(current, epoch)
+        if early_stop.stop_training(epoch):
+            log.info("early stopping at epoch %d since %s didn't improve from epoch no %d. Best value %s, current value %s",
+                     epoch, val_metric, early_stop.best_epoch, early_stop.best_value, current)
+            break
+
+    if rank == 0:
+        torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, os.path.join(output_dir, "model.pkl"))
+    if writer is not None:
+        writer.close_all_writers()
+    return {"epochs": epoch, "train_metrics": train_metrics, "val_metrics": val_metrics, "num_params": num_params}

@@ -5,9 +5,10 @@ allRank resolves its plugins by name at run time (SURVEY.md §5 "Config / flags"
     main.py:83   getattr(allrank.models.losses, config.loss.name)
     train_utils.py:50   getattr(allrank.models.metrics, metric_name)
 ``install()`` rebinds exactly those attributes to the MI355X implementations; everything else of the reference
-(config parsing, data loading, fit(), early stopping, logging) keeps running as is.  ``uninstall()`` restores them.
+(config parsing, data loading, fit(), early stopping, logging) keeps running as is.  ``install(fit=True)`` additionally puts
+``allrank_amd.fit.fit`` (reference signature, explicit HIP training step inside) behind main.py:90.  ``uninstall()`` restores all.
 
-    import allrank_amd; allrank_amd.install()      # then: from allrank.main import run; run()
+    import allrank_amd; allrank_amd.install(fit=True)      # then: from allrank.main import run; run()
 """
 import importlib
 import sys
@@ -24,8 +25,10 @@ def _set(mod, name, value):
     setattr(mod, name, value)
 
 
-def install(losses=True, metrics=True, model=True):
-    """Rebind the hot-path names inside the importable ``allrank`` package.  Returns the list of rebound names."""
+def install(losses=True, metrics=True, model=True, fit=False):
+    """Rebind the hot-path names inside the importable ``allrank`` package.  Returns the list of rebound names.
+    ``fit=True`` also rebinds the epoch loop (train_utils.py:78; imported into main.py's namespace at main.py:18) to
+    ``allrank_amd.fit.fit`` -- same signature and return value, the explicit MI355X step inside."""
     from . import losses as E, metrics as EM, model as EMod
     done = []
     if losses:
@@ -47,6 +50,15 @@ def install(losses=True, metrics=True, model=True):
             if m is not None and hasattr(m, "make_model"):
                 _set(m, "make_model", EMod.make_model)
                 done.append(modname + ".make_model")
+    if fit:
+        from . import fit as EF
+        rt = importlib.import_module("allrank.training.train_utils")
+        _set(rt, "fit", EF.fit)
+        done.append("allrank.training.train_utils.fit")
+        m = sys.modules.get("allrank.main")                         # `from allrank.training.train_utils import fit`
+        if m is not None and hasattr(m, "fit"):
+            _set(m, "fit", EF.fit)
+            done.append("allrank.main.fit")
     return done
 
 

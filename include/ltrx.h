@@ -288,6 +288,24 @@ int ltrx_gemm_tn_splits(int M, int NP, int KP);
 int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, float* bias_out, int M, int NP, int KP, int strict,
                  void* ws, ltrx_stream_t stream);
 
+/* Model options around the encoder on the explicit step (allrank_amd/csrc/ltrx_extras.hip):
+ *   ltrx_layernorm_torch_fwd: FCModel.input_norm = nn.LayerNorm(n_features) (model.py:27,39): biased variance, eps inside the
+ *       sqrt; saves mean and rstd.  Its parameter gradients come from ltrx_layernorm_bwd called with these statistics.
+ *   ltrx_posenc_fwd: positional encoding (positional.py:15-77, transformer.py:51-52): y = scale * x + table[row(m)],
+ *       row = padding_idx for masked items and ranks outside [0, padding_idx), else indices[m]; mask may be NULL.
+ *   ltrx_posenc_table_bwd: gradient of a LEARNED table: dtable[r] = sum of dx[m] over the rows m with row(m) == r; the padding
+ *       row gets 0 (nn.Embedding(padding_idx)); deterministic.      ltrx_scale_inplace: x *= s (the sqrt(d_model) factor).
+ *   ltrx_out_act_fwd / _bwd: OutputLayer activation (model.py:106-117), kind 1 = Sigmoid, 2 = Tanh; bwd: dz = dy * act'(y). */
+int ltrx_layernorm_torch_fwd(const float* x, const float* w, const float* b, int rows, int D, float eps, float* y, float* mean_out,
+                             float* rstd_out, ltrx_stream_t stream);
+int ltrx_posenc_fwd(const float* x, const float* table, const int64_t* indices, const uint8_t* mask, int M, int D, int padding_idx,
+                    float scale, float* y, ltrx_stream_t stream);
+int ltrx_posenc_table_bwd(const float* dx, const int64_t* indices, const uint8_t* mask, int M, int D, int padding_idx, float* dtable,
+                          ltrx_stream_t stream);
+int ltrx_scale_inplace(float* x, size_t n, float s, ltrx_stream_t stream);
+int ltrx_out_act_fwd(const float* z, size_t n, int kind, float* y, ltrx_stream_t stream);
+int ltrx_out_act_bwd(const float* dy, const float* y, size_t n, int kind, float* dz, ltrx_stream_t stream);
+
 /* Test hook: D[32x32] = A[32x2] * B[2x32] with ONE v_mfma_f32_32x32x2_f32, written through the operand / result
  * lane layout the attention kernels assume.  Lets the parity suite tell a layout bug from a logic bug. */
 int ltrx_selftest_mfma32x32x2(const float* A, const float* B, float* D, ltrx_stream_t stream);

@@ -1,0 +1,135 @@
+"""-m gpu: the drop-in epoch loop (allrank_amd.fit.fit, reference signature of train_utils.py:78-147) and the epoch metrics
+pass (allrank_amd.data.evaluate vs compute_metrics, train_utils.py:47-56 as restated by the oracle)."""
+import os
+import types
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ltr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _data(n, L, F, seed, ragged=True):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, L, F)).astype(np.float32)
+    w = rng.standard_normal(F).astype(np.float32)
+    y = np.clip(np.round((x @ w) / np.sqrt(F) + 1.5), 0, 4).astype(np.float32)      # learnable labels
+    idx = np.tile(np.arange(L, dtype=np.int64), (n, 1))
+    if ragged:
+        for b in range(n):
+            k = int(rng.integers(L // 3, L + 1))
+            y[b, k:] = -1
+            x[b, k:] = 0
+            idx[b, k:] = -1
+    return torch.tensor(x), torch.tensor(y), torch.tensor(idx)
+
+
+def _model(F, dropout=0.0, pe=None):
+    from allrank_amd.model import make_model
+    torch.manual_seed(7)
+    return make_model(dict(sizes=[32], input_norm=False, activation=None, dropout=0.0),
+                      dict(N=2, d_ff=64, h=4, positional_encoding=pe, dropout=dropout), dict(d_output=1, output_activation=None), F).to(DEV)
+
+
+def _loaders(n_train=40, n_val=24, L=30, F=20, bs=16):
+    from torch.utils.data import DataLoader, TensorDataset
+    tr = TensorDataset(*_data(n_train, L, F, 1))
+    va = TensorDataset(*_data(n_val, L, F, 2))
+    return DataLoader(tr, batch_size=bs, shuffle=False), DataLoader(va, batch_size=bs, shuffle=False)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_fit_has_the_reference_contract_and_runs_the_fused_step(tmp_path, compact):
+    from allrank_amd import losses as E, fit as EF
+    cfg = types.SimpleNamespace(metrics={"ndcg": [5, 10]}, val_metric="ndcg_5")
+    train_dl, val_dl = _loaders()
+    model = _model(20, dropout=0.1, pe=dict(strategy="fixed", max_indices=24))
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.5)
+    res = EF.fit(epochs=4, model=model, loss_func=partial(E.approxNDCGLoss, alpha=1.0), optimizer=opt, scheduler=sched, train_dl=train_dl,
+                 valid_dl=val_dl, config=cfg, gradient_clipping_norm=1.0, early_stopping_patience=10, device=torch.device(DEV),
+                 output_dir=str(tmp_path), tensorboard_output_path=None, compact=compact)
+    assert EF.last_run["engine"] == "fused" and EF.last_run["compact"] == compact, EF.last_run
+    assert set(res) == {"epochs", "train_metrics", "val_metrics", "num_params"} and res["epochs"] == 3
+    assert set(res["val_metrics"]) == {"ndcg_5", "ndcg_10"} and set(res["train_metrics"]) == {"ndcg_5", "ndcg_10"}
+    assert all(0.0 < float(v) <= 1.0 for v in list(res["val_metrics"].values()) + list(res["train_metrics"].values()))
+    assert res["num_params"] == sum(p.numel() for p in model.parameters())
+    assert abs(opt.param_groups[0]["lr"] - 2e-3 * 0.5 ** 4) < 1e-12          # the scheduler ran once per epoch
+    sd = torch.load(os.path.join(str(tmp_path), "model.pkl"))
+    fresh = _model(20, dropout=0.1, pe=dict(strategy="fixed", max_indices=24))
+    assert not fresh.load_state_dict(sd, strict=True).missing_keys
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k].cpu()), k
+
+
+def test_fit_fused_and_autograd_paths_agree_and_learn(tmp_path):
+    from allrank_amd import losses as E, fit as EF
+    cfg = types.SimpleNamespace(metrics={"ndcg": [5]}, val_metric="ndcg_5")
+    out = {}
+    for fused in (True, False):
+        train_dl, val_dl = _loaders(n_train=48, bs=16)
+        model = _model(20)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        hist = []
+        # one epoch at a time so that the per-epoch numbers can be compared
+        res = EF.fit(epochs=1, model=model, loss_func=partial(E.listNet), optimizer=opt, scheduler=None, train_dl=train_dl, valid_dl=val_dl,
+                     config=cfg, gradient_clipping_norm=None, early_stopping_patience=5, device=torch.device(DEV),
+                     output_dir=str(tmp_path), tensorboard_output_path=None, use_fused=fused, compact=False)
+        assert EF.last_run["engine"] == ("fused" if fused else "autograd")
+        out[fused] = (res["train_metrics"]["ndcg_5"], res["val_metrics"]["ndcg_5"])
+    # same data order, same initial weights, no dropout: the two engines run the same three training steps
+    assert abs(out[True][0] - out[False][0]) < 2e-3 and abs(out[True][1] - out[False][1]) < 5e-3, out
+    # early stopping: patience 0 stops as soon as the validation metric fails to improve
+    train_dl, val_dl = _loaders()
+    model = _model(20)
+    res = EF.fit(epochs=30, model=model, loss_func=partial(E.listNet), optimizer=torch.optim.Adam(model.parameters(), lr=0.05), scheduler=None,
+                 train_dl=train_dl, valid_dl=val_dl, config=cfg, gradient_clipping_norm=None, early_stopping_patience=0,
+                 device=torch.device(DEV), output_dir=str(tmp_path), tensorboard_output_path=None)
+    assert res["epochs"] < 29
+
+
+def test_fit_falls_back_to_the_autograd_trainer(tmp_path):
+    from allrank_amd import losses as E, fit as EF
+    cfg = types.SimpleNamespace(metrics={"ndcg": [5]}, val_metric="ndcg_5")
+    train_dl, val_dl = _loaders()
+    model = _model(20)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01)
+    res = EF.fit(2, model, partial(E.listNet), opt, None, train_dl, val_dl, cfg, None, 5, torch.device(DEV), str(tmp_path), None)
+    assert EF.last_run["engine"] == "autograd" and "Adam" in EF.last_run["reason"] and res["epochs"] == 1
+
+
+def test_evaluate_equals_compute_metrics_of_the_oracle():
+    """epoch NDCG@{5,10,30,60} of allrank_amd.data.evaluate == mean over all slates of the reference's
+    metrics.ndcg (train_utils.py:32-56) as restated by oracle/ltr_oracle.py, on the SAME scores, for slates of very different
+    lengths batched to the longest one (the validation transform, dataset_loading.py:185-194)."""
+    from allrank_amd.data import DeviceSlates, evaluate
+    rng = np.random.default_rng(3)
+    F = 20
+    lens = rng.integers(1, 90, 70)
+    lens[5] = 1
+    X = rng.standard_normal((int(lens.sum()), F)).astype(np.float32)
+    y = rng.choice(5, size=int(lens.sum()), p=[0.5, 0.3, 0.15, 0.03, 0.02]).astype(np.float32)
+    qid = np.repeat(np.arange(len(lens)), lens)
+    y[qid == 7] = 0.0                                             # a slate without any relevant item -> NDCG 1.0 (metrics.py:24)
+    ds = DeviceSlates(X, y, qid, device=DEV)
+    model = _model(F)
+    ats = [5, 10, 30, 60]
+    got = evaluate(model, ds, {"ndcg": ats, "mrr": [10]}, batch_size=16)
+    # the same scores through the oracle, slate by slate padded to the longest
+    Lmax = int(lens.max())
+    vals = []
+    model.eval()
+    with torch.no_grad():
+        for xb, yb, idx in ds.batches(16, None):
+            sc = model.score(xb, yb == -1, idx).cpu().numpy()
+            vals.append(O.ndcg(sc, yb.cpu().numpy(), ats=ats)[0])
+            assert xb.shape[1] == Lmax
+    ref = np.concatenate(vals).mean(0)
+    for at, r in zip(ats, ref):
+        assert abs(got["ndcg_%d" % at] - float(r)) <= 1e-5, (at, got["ndcg_%d" % at], r)
+    assert 0.0 <= got["mrr_10"] <= 1.0

@@ -27,3 +27,27 @@ def test_install_rebinds_hot_path_names_and_uninstall_restores():
     finally:
         allrank_amd.uninstall()
     assert (RL.approxNDCGLoss, RM.ndcg, RMod.make_model, RL.rankNet) == orig
+
+
+def test_install_fit_rebinds_the_epoch_loop_with_the_reference_signature():
+    """main.py:90 must reach the explicit step; here (no GPU): names and signature only"""
+    import inspect
+    from oracle.ref_loader import load_reference
+    load_reference()
+    import allrank.training.train_utils as RT
+    import allrank_amd
+    from allrank_amd import fit as EF
+    ref_fit = RT.fit
+    ref_params = list(inspect.signature(ref_fit).parameters)
+    ours = list(inspect.signature(EF.fit).parameters)
+    assert ours[:len(ref_params)] == ref_params, (ours, ref_params)          # same names, same order (extensions come after)
+    assert all(inspect.signature(EF.fit).parameters[p].default is not inspect.Parameter.empty for p in ours[len(ref_params):])
+    done = allrank_amd.install(fit=True)
+    try:
+        assert RT.fit is EF.fit and "allrank.training.train_utils.fit" in done
+        import importlib
+        main = importlib.import_module("allrank.main")      # imports `fit` from train_utils -> gets the rebound one
+        assert main.fit is EF.fit
+    finally:
+        allrank_amd.uninstall()
+    assert RT.fit is ref_fit
