@@ -75,6 +75,9 @@ SIGNATURES = {
     "ltrx_scale_inplace": (_i, [_vp, _sz, _f, _vp]),
     "ltrx_out_act_fwd": (_i, [_vp, _sz, _i, _vp, _vp]),
     "ltrx_out_act_bwd": (_i, [_vp, _vp, _sz, _i, _vp, _vp]),
+    "ltrx_fixlength_positions": (_i, [_vp, _vp, _vp, _i, _i, _i, ctypes.c_uint64, _vp, _vp]),
+    "ltrx_assemble_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ltrx_libsvm_parse": (_i, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ltrx_selftest_mfma32x32x2": (_i, [_vp, _vp, _vp, _vp]),
     "ltrx_mha_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp]),
 }

@@ -7,7 +7,9 @@ dataset lives in HBM in CSR form (WEB30K fold 1: 2.27 M items x 136 fp32 = 1.2 G
 
     x_items [n_items, F] f32,  y_items [n_items] f32,  offsets [n_slates + 1] i64,  item_of [n_slates, max_len] i64 (-1 = none)
 
-and a batch is produced by torch device ops only (no host round trip, no per-slate Python):
+and a batch is produced on the device by two HIP kernels (``ltrx_fixlength_positions`` + ``ltrx_assemble_batch``,
+allrank_amd/csrc/ltrx_data.hip; no host round trip, no per-slate Python; ``_positions_torch`` is the same transform in torch
+device ops, kept as the independent implementation the tests compare the kernel with):
   * slates shorter than ``slate_length`` are padded: features 0, label -1, index -1 (FixLength._pad, :81-93);
   * longer slates are subsampled WITHOUT replacement in random order (FixLength._sample, :61-79) by drawing one
     uniform key per item and keeping the top ``slate_length`` keys;
@@ -24,15 +26,56 @@ PADDED_Y_VALUE = -1
 PADDED_INDEX_VALUE = -1
 
 
+def parse_svm_file_on_device(path, device="cuda", n_features=None):
+    """(X f32[n, F], y f32[n], qid i64[n]) as device tensors, parsed on the GPU.  Feature indices follow scikit-learn's
+    zero_based="auto": one-based unless the smallest index in the file is 0."""
+    from . import _lib as LB
+    lib = LB.lib()
+    dev = torch.device(device)
+    raw = np.fromfile(path, dtype=np.uint8)
+    if raw.size == 0:
+        raise ValueError("empty file: %s" % path)
+    text = torch.from_numpy(raw).to(dev)
+    nl = torch.nonzero(text == 10).flatten()
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), nl + 1])
+    starts = starts[starts < text.numel()]
+    # drop blank / comment-only lines like sklearn does
+    first = text[starts]
+    starts = starts[(first != 10) & (first != 13) & (first != 35)].contiguous()
+    n = int(starts.numel())
+    y = torch.empty(n, dtype=torch.float32, device=dev)
+    qid = torch.empty(n, dtype=torch.int64, device=dev)
+    mm = torch.tensor([2 ** 31 - 1, -1], dtype=torch.int32, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    st = LB.stream_of(text)
+    LB.check(lib.ltrx_libsvm_parse(LB.ptr(text), LB.ptr(starts), n, int(text.numel()), LB.ptr(y), LB.ptr(qid), None, 0, 0, LB.ptr(mm),
+                                   LB.ptr(bad), st), "libsvm_parse(scan)")
+    lo, hi = (int(v) for v in mm.cpu())
+    if int(bad.item()):
+        raise ValueError("%d malformed line(s) in %s" % (int(bad.item()), path))
+    base = 0 if lo == 0 else 1
+    F = int(n_features) if n_features is not None else hi - base + 1
+    X = torch.zeros((n, F), dtype=torch.float32, device=dev)
+    LB.check(lib.ltrx_libsvm_parse(LB.ptr(text), LB.ptr(starts), n, int(text.numel()), None, None, LB.ptr(X), F, base, None, LB.ptr(bad),
+                                   st), "libsvm_parse(fill)")
+    return X, y, qid
+
+
 class DeviceSlates(object):
     def __init__(self, X, y, query_ids, device="cuda"):
         """X: [n_items, F] array (dense or scipy sparse), y: [n_items], query_ids: [n_items]; items of one query must be
         contiguous (as in libsvm LTR files); queries keep their order of first appearance (dataset_loading.py:109-113)."""
         if hasattr(X, "toarray"):
             X = X.toarray()
-        X = np.ascontiguousarray(X, dtype=np.float32)
-        y = np.asarray(y, dtype=np.float32)
-        q = np.asarray(query_ids)
+        self.device = torch.device(device)
+        if torch.is_tensor(X):                       # already on the device (parse_svm_file_on_device): only the query ids go to the host
+            q = query_ids.cpu().numpy() if torch.is_tensor(query_ids) else np.asarray(query_ids)
+            Xt, yt = X.to(self.device, torch.float32).contiguous(), y.to(self.device, torch.float32).contiguous()
+        else:
+            X = np.ascontiguousarray(X, dtype=np.float32)
+            y = np.asarray(y, dtype=np.float32)
+            q = np.asarray(query_ids)
+            Xt, yt = torch.from_numpy(X).to(self.device), torch.from_numpy(y).to(self.device)
         change = np.flatnonzero(q[1:] != q[:-1]) + 1
         starts = np.concatenate([[0], change]).astype(np.int64)
         offsets = np.concatenate([starts, [len(q)]]).astype(np.int64)
@@ -40,9 +83,8 @@ class DeviceSlates(object):
         self.n_slates = int(len(lens))
         self.n_features = int(X.shape[1])
         self.longest_query_length = int(lens.max())
-        self.device = torch.device(device)
-        self.x_items = torch.from_numpy(X).to(self.device)
-        self.y_items = torch.from_numpy(y).to(self.device)
+        self.x_items = Xt
+        self.y_items = yt
         self.offsets = torch.from_numpy(offsets).to(self.device)
         self.lengths = torch.from_numpy(lens).to(self.device)
         pos = torch.arange(self.longest_query_length, device=self.device)[None, :]
@@ -54,7 +96,12 @@ class DeviceSlates(object):
         self.argmax_pos = ypad.argmax(1)
 
     @classmethod
-    def from_svm_file(cls, path, device="cuda"):
+    def from_svm_file(cls, path, device="cuda", parser="device"):
+        """libsvm / SVMlight text -> DeviceSlates.  parser="device" (default on a GPU): the file's bytes are uploaded and parsed
+        by ``ltrx_libsvm_parse`` (one thread per line); parser="sklearn": the reference's host parser (dataset_loading.py:130)."""
+        if parser == "device" and torch.device(device).type == "cuda":
+            X, y, qid = parse_svm_file_on_device(path, device)
+            return cls(X, y, qid, device)
         from sklearn.datasets import load_svmlight_file
         X, y, qid = load_svmlight_file(path, query_id=True)
         return cls(X, y, qid, device)
@@ -67,8 +114,9 @@ class DeviceSlates(object):
         return [self.n_slates, self.longest_query_length, self.n_features]
 
     # ------------------------------------------------------------------------------------------------------------
-    def _positions(self, slates, L, generator):
-        """[B, L] positions inside each slate (-1 = padding) following FixLength."""
+    def _positions_torch(self, slates, L, generator):
+        """[B, L] positions inside each slate (-1 = padding) following FixLength -- torch device ops (reference implementation
+        of the kernel for the tests)."""
         lens = self.lengths[slates]
         B = slates.numel()
         maxlen = self.longest_query_length
@@ -97,10 +145,42 @@ class DeviceSlates(object):
                 out[todo] = samp[retry]
         return out
 
-    def batch(self, slates, slate_length, generator=None):
-        """slates: i64[B] slate ids -> (xb [B,L,F], yb [B,L], indices [B,L]) on the device."""
+    def positions(self, slates, L, seed):
+        """[B, L] positions inside each slate (-1 = padding): FixLength on the device (ltrx_fixlength_positions)."""
+        from . import _lib as LB
+        LB.require_device(self.y_items, slates)
+        slates = slates.to(torch.int64).contiguous()
+        B = int(slates.numel())
+        pos = torch.empty((B, int(L)), dtype=torch.int64, device=self.device)
+        LB.check(LB.lib().ltrx_fixlength_positions(LB.ptr(self.offsets), LB.ptr(self.y_items), LB.ptr(slates), B, int(L),
+                                                   self.longest_query_length, int(seed) & 0xFFFFFFFFFFFFFFFF, LB.ptr(pos),
+                                                   LB.stream_of(self.y_items)), "fixlength_positions")
+        return pos
+
+    def batch(self, slates, slate_length, generator=None, seed=None):
+        """slates: i64[B] slate ids -> (xb [B,L,F], yb [B,L], indices [B,L]) on the device.  ``seed`` keys the sampling of the
+        slates longer than ``slate_length`` (default: drawn from ``generator`` -- one host sync; ``batches`` draws one seed per
+        epoch and counts batches instead)."""
+        from . import _lib as LB
+        LB.require_device(self.x_items)
         L = int(slate_length)
-        pos = self._positions(slates, L, generator)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), device=self.device, generator=generator).item())
+        slates = slates.to(torch.int64).contiguous()
+        B = int(slates.numel())
+        pos = self.positions(slates, L, seed)
+        xb = torch.empty((B, L, self.n_features), dtype=torch.float32, device=self.device)
+        yb = torch.empty((B, L), dtype=torch.float32, device=self.device)
+        idx = torch.empty((B, L), dtype=torch.int64, device=self.device)
+        LB.check(LB.lib().ltrx_assemble_batch(LB.ptr(self.x_items), LB.ptr(self.y_items), LB.ptr(self.offsets), LB.ptr(slates), LB.ptr(pos),
+                                              B, L, self.n_features, LB.ptr(xb), LB.ptr(yb), LB.ptr(idx), LB.stream_of(xb)),
+                 "assemble_batch")
+        return xb, yb, idx
+
+    def batch_torch(self, slates, slate_length, generator=None):
+        """the same batch through torch device ops (tests)"""
+        L = int(slate_length)
+        pos = self._positions_torch(slates, L, generator)
         valid = pos >= 0
         item = self.item_of[slates].gather(1, pos.clamp(min=0))
         item = torch.where(valid, item, torch.zeros_like(item))
@@ -115,11 +195,13 @@ class DeviceSlates(object):
         L = self.longest_query_length if slate_length is None else int(slate_length)
         order = (torch.randperm(self.n_slates, device=self.device, generator=generator) if shuffle
                  else torch.arange(self.n_slates, device=self.device))
-        for s in range(0, self.n_slates, batch_size):
+        # one seed per epoch (one host sync), a counter per batch: sampling of long slates never syncs inside the epoch
+        base = int(torch.randint(0, 2 ** 40, (1,), device=self.device, generator=generator).item()) if L < self.longest_query_length else 0
+        for k, s in enumerate(range(0, self.n_slates, batch_size)):
             ids = order[s:s + batch_size]
             if drop_last and ids.numel() < batch_size:
                 break
-            yield self.batch(ids, L, generator)
+            yield self.batch(ids, L, seed=(base << 22) + k)
 
 
 def evaluate(model, dataset, metrics, batch_size=512, slate_length=None):

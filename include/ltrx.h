@@ -306,6 +306,26 @@ int ltrx_scale_inplace(float* x, size_t n, float s, ltrx_stream_t stream);
 int ltrx_out_act_fwd(const float* z, size_t n, int kind, float* y, ltrx_stream_t stream);
 int ltrx_out_act_bwd(const float* dy, const float* y, size_t n, int kind, float* dz, ltrx_stream_t stream);
 
+/* On-device batch assembly for a CSR training set resident in HBM (allrank_amd/csrc/ltrx_data.hip):
+ *   ltrx_fixlength_positions: FixLength (dataset_loading.py:32-93) for the B slates `slates` of a batch: positions[b][l] = the
+ *       position inside slate b that fills slot l, -1 = padding.  Short slates are padded (:81-93); slates of >= L items are
+ *       sampled without replacement in random order (:70) with the reference's relevance rule (:72-76).  Counter-based
+ *       randomness from `seed` (same seed, same batch -> same sample); max_slate_len <= 12288.
+ *   ltrx_assemble_batch: xb[B,L,F], yb[B,L] (-1 on padding), indices[B,L] (= positions) from the CSR arrays (ToTensor +
+ *       collate, :19-29). */
+int ltrx_fixlength_positions(const int64_t* offsets, const float* y_items, const int64_t* slates, int B, int L, int max_slate_len,
+                             uint64_t seed, int64_t* positions, ltrx_stream_t stream);
+int ltrx_assemble_batch(const float* x_items, const float* y_items, const int64_t* offsets, const int64_t* slates,
+                        const int64_t* positions, int B, int L, int F, float* xb, float* yb, int64_t* indices, ltrx_stream_t stream);
+
+/* libsvm / SVMlight text parsed on the device (the reference: sklearn's load_svmlight_file on the host, dataset_loading.py:130).
+ * text = the file's bytes in device memory, line_start[n_lines] = byte offset of every line.  One thread per line.
+ * Pass 1 (X NULL): y[line], qid[line], minmax_index = {smallest, largest} feature index (initialise to {INT_MAX, -1}).
+ * Pass 2: X[line][index - index_base] = value (X zero-initialised by the caller, dense [n_lines, n_features]).
+ * bad_lines (device int, zero-initialised) counts malformed lines. */
+int ltrx_libsvm_parse(const uint8_t* text, const int64_t* line_start, int64_t n_lines, int64_t n_bytes, float* y, int64_t* qid, float* X,
+                      int n_features, int index_base, int* minmax_index, int* bad_lines, ltrx_stream_t stream);
+
 /* Test hook: D[32x32] = A[32x2] * B[2x32] with ONE v_mfma_f32_32x32x2_f32, written through the operand / result
  * lane layout the attention kernels assume.  Lets the parity suite tell a layout bug from a logic bug. */
 int ltrx_selftest_mfma32x32x2(const float* A, const float* B, float* D, ltrx_stream_t stream);

@@ -1,11 +1,20 @@
-"""DeviceSlates (allrank_amd/data.py) semantics == FixLength / ToTensor of allrank/data/dataset_loading.py:19-93,
-checked on CPU tensors (the class is device-agnostic torch code)."""
+"""The torch restatement of FixLength / ToTensor inside allrank_amd/data.py (``DeviceSlates.batch_torch``; device-agnostic torch
+ops) == allrank/data/dataset_loading.py:19-93, checked on CPU tensors.  The product path (``DeviceSlates.batch`` -> the HIP kernels of
+ltrx_data.hip) is compared with this restatement on the GPU (tests/test_gpu_data.py) and refuses CPU tensors."""
 import numpy as np
 import pytest
 import torch
 
 from allrank_amd.data import DeviceSlates
 from oracle.ref_loader import reference_available
+
+
+def _batches(ds, batch_size, slate_length=None, shuffle=False, generator=None):
+    """DeviceSlates.batches with the torch implementation of the transform"""
+    L = ds.longest_query_length if slate_length is None else int(slate_length)
+    order = torch.randperm(ds.n_slates, generator=generator) if shuffle else torch.arange(ds.n_slates)
+    for s in range(0, ds.n_slates, batch_size):
+        yield ds.batch_torch(order[s:s + batch_size], L, generator)
 
 
 def _toy(seed=0, n_q=40, F=6):
@@ -31,7 +40,7 @@ def test_padding_branch_matches_fixlength_pad():
     ds = DeviceSlates(X, y, qid, device="cpu")
     assert len(ds) == 40 and ds.longest_query_length == 50 and ds.shape == [40, 50, 6]
     L = 60
-    xb, yb, idx = next(ds.batches(40, L))
+    xb, yb, idx = next(_batches(ds, 40, L))
     off = np.concatenate([[0], np.cumsum(lens)])
     for s in range(40):
         n = lens[s]
@@ -49,7 +58,7 @@ def test_sampling_branch_without_replacement_and_relevance_rules():
     off = np.concatenate([[0], np.cumsum(lens)])
     seen_orders = set()
     for rep in range(30):
-        xb, yb, idx = ds.batch(torch.arange(40), L, g)
+        xb, yb, idx = ds.batch_torch(torch.arange(40), L, g)
         for s in range(40):
             n = lens[s]
             if n < L:
@@ -72,11 +81,11 @@ def test_epoch_iterator_covers_every_slate_once():
     g = torch.Generator().manual_seed(0)
     nb = 0
     firsts = []
-    for xb, yb, idx in ds.batches(16, 50, shuffle=True, generator=g):
+    for xb, yb, idx in _batches(ds, 16, 50, shuffle=True, generator=g):
         nb += xb.shape[0]
         firsts += [tuple(np.round(r, 5)) for r in xb[:, 0, :2].numpy().tolist()]
     assert nb == 40 and len(set(firsts)) == 40
-    xv, yv, iv = next(ds.batches(64))                      # validation: pad to the longest slate
+    xv, yv, iv = next(_batches(ds, 64))                      # validation: pad to the longest slate
     assert xv.shape == (40, 50, 6)
 
 
@@ -91,9 +100,16 @@ def test_against_reference_fixlength_pad_and_libsvm_roundtrip(tmp_path):
     dump_svmlight_file(X, y, path, query_id=qid)
     ds = DeviceSlates.from_svm_file(path, device="cpu")
     L = 64
-    xb, yb, idx = next(ds.batches(12, L))
+    xb, yb, idx = next(_batches(ds, 12, L))
     off = np.concatenate([[0], np.cumsum(lens)])
     fl, tt = FixLength(L), ToTensor()
     for s in range(12):
         rx, ry, ri = tt(fl((X[off[s]:off[s + 1]].astype(np.float64), y[off[s]:off[s + 1]], None)))
         assert torch.allclose(xb[s], rx, atol=1e-6) and torch.equal(yb[s], ry) and torch.equal(idx[s], ri)
+
+
+def test_product_batch_path_refuses_cpu_tensors():
+    X, y, qid, lens = _toy()
+    ds = DeviceSlates(X, y, qid, device="cpu")
+    with pytest.raises(RuntimeError):
+        ds.batch(torch.arange(4), 16, seed=1)
