@@ -1,0 +1,506 @@
+// Fused masked self-attention on the bf16 matrix cores with fp32-class accuracy, for slates that FIT IN LDS
+// (allrank/models/transformer.py:137-156 attention, :178-203 MultiHeadedAttention.forward; slate length <= 256, 32 < d_k <= 64).
+//
+// Why another attention path: the exact-fp32 kernels of ltrx_mha.hip run on v_mfma_f32_32x32x2_f32, 1/16 of the bf16 MFMA
+// rate -- 29 % of the training step at config (3).  Here every contraction is three v_mfma_f32_32x32x16_bf16 products
+// X Y ~= Xhi Yhi + Xhi Ylo + Xlo Yhi (x = hi + lo, both bf16; fp32 accumulate; error <= 3 * 2^-18 per product, the same
+// arithmetic as the dense projections of ltrx_gemm.hip): 5.3x fewer matrix-pipe cycles.  What made the earlier split-bf16
+// attempt (round 1, ltrx_mha_bf16.hip: no faster than fp32) slow was not the MFMAs but everything around them: every
+// 128-query workgroup re-staged and re-split every 32-key tile of K and V behind two barriers, with a strided transposition
+// pass for the operand that is contracted over keys.  This version removes all of that:
+//   * ONE workgroup (8 waves) per (slate, head).  The two streamed operands of a kernel (K and V; Q and dO in the dK/dV
+//     kernel) are split ONCE into bf16 hi/lo images of the whole slate -- 2 x 64 KB of the CU's 160 KB LDS -- then every wave
+//     runs its whole loop out of LDS: one barrier per kernel instead of two per tile, no re-staging, no re-splitting.
+//   * no transposed copies: an operand contracted over its ROWS (V in P V, K in dS K, dO and Q in the dK/dV kernel) is read
+//     from the same row-major image with ds_read_b64_tr_b16 (each 16-lane group fetches a [4 rows][16 cols] block transposed:
+//     lane = column, 4 consecutive rows), whose row groups {16u + 4 half + 0..3, 16u + 8 + 4 half + 0..3} are exactly the
+//     rows a lane's P / dS registers 8u..8u+7 hold in the MFMA D layout -- P never moves between lanes.
+//   * image layout: [row][64] bf16 per plane, 16-byte chunk c of row r at position c ^ s(r), s(r) = bit2(r) | bit3(r) << 1 |
+//     bit1(r) << 2: conflict-free for the 16-lane groups of the row-wise ds_read_b128 AND for the four rows x two column
+//     blocks of a transposed read (row bit 1 moves the 32-byte region, row bit 0 the 128-byte half of the bank row).
+// Softmax in the log2 domain, natural-log LSE saved, dropout on P regenerated from (seed, query row, key) -- identical
+// conventions to ltrx_mha.hip, so forward / backward kernels of the two paths are interchangeable.  Variable-length
+// (cu_seqlens) batches: slate b is rows cu[b] .. cu[b+1]-1; waves beyond the slate's length exit after the staging barrier.
+#include "ltrx_device.h"
+
+using namespace ltrx;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
+
+namespace {
+
+constexpr int RMAX = 256;                 // rows (items of a slate) held in LDS
+constexpr int DK = 64;                    // padded head dimension
+constexpr int PLANE = RMAX * DK * 2;      // bytes of one bf16 plane
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+typedef DropSpec DropCfg;
+__device__ __forceinline__ uint32_t drop_row_seed(const DropCfg& d, uint32_t bh, int L, int qrow) {   // == ltrx_mha.hip
+  uint32_t x = d.seed ^ ((bh * (uint32_t)L + (uint32_t)qrow) * 0x9E3779B9u);
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float drop_scale_rk(const DropCfg& d, uint32_t row_seed, int key) {
+  uint32_t x = (row_seed ^ (uint32_t)key) * 0x9E3779B1u;
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  return ((x >> 8) >= d.thresh) ? d.inv_keep : 0.f;
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ int rowmap(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// byte offset of 16-byte chunk `chunk` (8 columns) of row `row` inside a plane
+__device__ __forceinline__ int img_off(int row, int chunk) {
+  const int s = ((row >> 2) & 1) | (((row >> 3) & 1) << 1) | (((row >> 1) & 1) << 2);
+  return row * (DK * 2) + ((chunk ^ s) << 4);
+}
+
+// Staging is pipelined per 32-row tile: the 512 threads fetch tile t+1 of the kernel's TWO streamed tensors into registers
+// (threads 0-255: tensor A, 256-511: tensor B; one (row, 8-column chunk) = 2 float4 each) while the waves compute on tile t;
+// the split into bf16 hi / lo and the LDS store happen right before the barrier that opens tile t+1.  Tiles live at their
+// own rows of the whole-slate image, so ONE barrier per tile orders everything (no WAR: a tile is written once).
+struct TileRegs {
+  float4 a, b;
+};
+__device__ __forceinline__ void tile_gload(TileRegs& r, const float* __restrict__ base, int tile, int nrows, int dk, size_t rs) {
+  const int idx = threadIdx.x & 255;
+  const int row = tile * 32 + (idx >> 3), c = (idx & 7) * 8;
+  r.a = make_float4(0.f, 0.f, 0.f, 0.f);
+  r.b = r.a;
+  if (row < nrows && c < dk) r.a = *reinterpret_cast<const float4*>(base + (size_t)row * rs + c);
+  if (row < nrows && c + 4 < dk) r.b = *reinterpret_cast<const float4*>(base + (size_t)row * rs + c + 4);
+}
+__device__ __forceinline__ void tile_sstore(unsigned char* img, int tile, const TileRegs& r) {
+  const int idx = threadIdx.x & 255;
+  const int row = tile * 32 + (idx >> 3), chunk = idx & 7;
+  const float x[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
+  bf16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = (__bf16)x[e];
+    l[e] = (__bf16)(x[e] - (float)h[e]);
+  }
+  const int o = img_off(row, chunk);
+  *reinterpret_cast<bf16x8*>(img + o) = h;
+  *reinterpret_cast<bf16x8*>(img + PLANE + o) = l;
+}
+
+// the wave's fixed operand FIXED[row0 + l31][16 ks + 8 half + (0..7)], pre-split (registers)
+__device__ __forceinline__ void load_fixed(bf16x8 (&fh)[4], bf16x8 (&fl)[4], const float* __restrict__ base, int row0, int nrows,
+                                           int dk, size_t rs) {
+  const int row = row0 + (threadIdx.x & 31);
+  const int half = (threadIdx.x & 63) >> 5;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c = 16 * ks + 8 * half;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (row < nrows && c < dk) a = *reinterpret_cast<const float4*>(base + (size_t)row * rs + c);
+    if (row < nrows && c + 4 < dk) b = *reinterpret_cast<const float4*>(base + (size_t)row * rs + c + 4);
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      fh[ks][e] = (__bf16)x[e];
+      fl[ks][e] = (__bf16)(x[e] - (float)fh[ks][e]);
+    }
+  }
+}
+
+#define LTRX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+// acc[r] = sum_c IMG[tile_row0 + rowmap(r, half)][c] * FIXED[l31][c].  NACC accumulators (4: one per 16-deep k-step, term-major
+// order, consecutive MFMAs never write the same accumulator; 2: 32 fewer live registers for the kernels at the VGPR limit)
+template <int NACC>
+__device__ __forceinline__ f32x16 rows_x_fixed(const unsigned char* img, int tile_row0, const bf16x8 (&fh)[4], const bf16x8 (&fl)[4]) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  f32x16 a[NACC];
+  bf16x8 xh[4], xl[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int o = img_off(tile_row0 + l31, 2 * ks + half);
+    xh[ks] = *reinterpret_cast<const bf16x8*>(img + o);
+    xl[ks] = *reinterpret_cast<const bf16x8*>(img + PLANE + o);
+  }
+#pragma unroll
+  for (int n = 0; n < NACC; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[n][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) a[ks % NACC] = LTRX_MFMA(xl[ks], fh[ks], a[ks % NACC]);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) a[ks % NACC] = LTRX_MFMA(xh[ks], fl[ks], a[ks % NACC]);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) a[ks % NACC] = LTRX_MFMA(xh[ks], fh[ks], a[ks % NACC]);
+  if (NACC == 4) return (a[0] + a[1]) + (a[2] + a[3]);
+  return a[0] + a[1 % NACC];
+}
+
+// out[ct][r'] += sum_row IMG[tile_row0 + row][32 ct + l31] * p[row]    (p in D layout: register r <-> tile row rowmap(r, half))
+// The A fragment (column 32 ct + l31, rows {16u + 4 half + 0..3, 16u + 8 + 4 half + 0..3}) comes from two transposed reads.
+__device__ __forceinline__ void cols_x_p(const unsigned char* img, int tile_row0, const f32x16& p, f32x16 (&out)[2]) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, i16 = lane & 15, g16 = (lane >> 4) & 1;
+  bf16x8 ph[2], pl[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = p[8 * u + e];
+      const __bf16 h = (__bf16)x;
+      ph[u][e] = h;
+      pl[u][e] = (__bf16)(x - (float)h);
+    }
+  // lane i16 of a 16-lane group supplies the address of row (i16 >> 2), columns 4 (i16 & 3) .. +3 of the [4][16] block
+  const int rsub = i16 >> 2, c8 = (i16 & 3) >> 1, b8 = (i16 & 1) * 8;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r0 = tile_row0 + 16 * u + 4 * half + rsub;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int chunk = (2 * ct + g16) * 2 + c8;
+      const int o0 = img_off(r0, chunk) + b8, o1 = img_off(r0 + 8, chunk) + b8;
+      const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + o0));
+      const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + o1));
+      const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + PLANE + o0));
+      const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + PLANE + o1));
+      const bf16x8 xh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      const bf16x8 xl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+      out[ct] = LTRX_MFMA(xl, ph[u], out[ct]);
+      out[ct] = LTRX_MFMA(xh, pl[u], out[ct]);
+      out[ct] = LTRX_MFMA(xh, ph[u], out[ct]);
+    }
+  }
+}
+
+// lane owns output row row0 + l31; register 4g + e of out[ct] is column 32 ct + 8 g + 4 half + e
+__device__ __forceinline__ void store_rows(float* __restrict__ base, int row0, int nrows, int dk, size_t rs, const f32x16 (&out)[2],
+                                           float scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = row0 + (lane & 31);
+  if (row >= nrows) return;
+  float* rp = base + (size_t)row * rs;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 32 * ct + 8 * g + 4 * (lane >> 5);
+      if (c < dk)
+        *reinterpret_cast<float4*>(rp + c) = make_float4(out[ct][4 * g + 0] * scale, out[ct][4 * g + 1] * scale,
+                                                         out[ct][4 * g + 2] * scale, out[ct][4 * g + 3] * scale);
+    }
+}
+
+__device__ __forceinline__ void zero2(f32x16 (&o)[2]) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+}
+
+struct Slate {
+  int b, head, bh, Lmax, len;
+  size_t row0;
+};
+__device__ __forceinline__ Slate which_slate(int L, int h, const int* __restrict__ cu, const int* __restrict__ order) {
+  Slate s;
+  s.head = blockIdx.x % h;
+  s.b = order ? order[blockIdx.x / h] : (int)(blockIdx.x / h);
+  s.bh = s.b * h + s.head;
+  s.Lmax = L;
+  s.row0 = cu ? (size_t)cu[s.b] : (size_t)s.b * L;
+  s.len = cu ? cu[s.b + 1] - cu[s.b] : L;
+  return s;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward: wave w owns queries 32 w .. 32 w + 31 of the slate
+// ------------------------------------------------------------------------------------------------------------------
+template <bool DROP>
+__global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, const uint8_t* __restrict__ kpm, int L,
+                                                               int h, int dk, int rs, float* __restrict__ o, int ors,
+                                                               float* __restrict__ lse, float scale, DropCfg drop,
+                                                               const uint32_t* __restrict__ drop_step, const int* __restrict__ cu,
+                                                               const int* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* kimg = smem;
+  unsigned char* vimg = smem + 2 * PLANE;
+  float* kbias = reinterpret_cast<float*>(smem + 4 * PLANE);
+  if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
+  const Slate sl = which_slate(L, h, cu, order);
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int len = sl.len;
+  const float* qb = q + sl.row0 * rs + (size_t)sl.head * dk;
+  const float* src = (threadIdx.x < 256 ? k : v) + sl.row0 * rs + (size_t)sl.head * dk;     // this thread's streamed tensor
+  unsigned char* dst = threadIdx.x < 256 ? kimg : vimg;
+  TileRegs tr;
+  tile_gload(tr, src, 0, len, dk, rs);
+  if (threadIdx.x < RMAX) kbias[threadIdx.x] = (threadIdx.x >= len || (kpm && kpm[sl.row0 + threadIdx.x])) ? -INFINITY : 0.f;
+  const int q0 = wave * 32;
+  const bool active = q0 < len;                 // (inactive waves still help staging and take every barrier)
+  bf16x8 qh[4], ql[4];
+  load_fixed(qh, ql, qb, q0, len, dk, rs);
+  f32x16 oacc[2];
+  zero2(oacc);
+  float m = -INFINITY, l = 0.f;
+  const uint32_t drow = DROP ? drop_row_seed(drop, sl.bh, sl.Lmax, q0 + (lane & 31)) : 0u;
+  const float sl2 = scale * kLog2e;
+  const int nkt = (len + 31) / 32;
+  for (int kt = 0; kt < nkt; ++kt) {
+    tile_sstore(dst, kt, tr);
+    if (kt + 1 < nkt) tile_gload(tr, src, kt + 1, len, dk, rs);       // in flight during this tile's MFMAs
+    __syncthreads();
+    if (!active) continue;
+    f32x16 s = rows_x_fixed<4>(kimg, kt * 32, qh, ql);         // S^T[key = rowmap(r, half)][query = l31]
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = s[r] * sl2 + kbias[kt * 32 + rowmap(r, half)];
+      mt = fmaxf(mt, s[r]);
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float mref = (mn == -INFINITY) ? 0.f : mn;
+    const float alpha = fast_exp2(m - mref);
+    float ps = 0.f;
+    f32x16 p;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = fast_exp2(s[r] - mref);
+      ps += p[r];
+    }
+    l = l * alpha + ps;
+    if (DROP) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[r] *= drop_scale_rk(drop, drow, kt * 32 + rowmap(r, half));
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[ct][r] *= alpha;
+    cols_x_p(vimg, kt * 32, p, oacc);                            // O^T[d][query] += V^T[d][key] P^T[key][query]
+    m = mn;
+  }
+  if (!active) return;
+  const float lt = l + __shfl_xor(l, 32, 64);
+  const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
+  store_rows(o + sl.row0 * ors + (size_t)sl.head * dk, q0, len, dk, ors, oacc, inv);
+  const int qrow = q0 + (lane & 31);
+  if (half == 0 && qrow < len) lse[((size_t)sl.b * h + sl.head) * sl.Lmax + qrow] = (lt > 0.f) ? (m + log2f(lt)) * kLn2 : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward dQ (+ delta): K and V resident; wave owns 32 queries (Q and dO fragments in registers)
+// ------------------------------------------------------------------------------------------------------------------
+template <bool DROP>
+__global__ void __launch_bounds__(512) ltrx_mha_bwd_dq_res_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const uint8_t* __restrict__ kpm,
+    const float* __restrict__ o, const float* __restrict__ dout, const float* __restrict__ lse, float* __restrict__ delta, int L, int h,
+    int dk, int rs, int ors, float* __restrict__ dq, int drs, float scale, DropCfg drop, const uint32_t* __restrict__ drop_step,
+    const int* __restrict__ cu, const int* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* kimg = smem;
+  unsigned char* vimg = smem + 2 * PLANE;
+  float* kbias = reinterpret_cast<float*>(smem + 4 * PLANE);
+  if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
+  const Slate sl = which_slate(L, h, cu, order);
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int len = sl.len;
+  const float* src = (threadIdx.x < 256 ? k : v) + sl.row0 * rs + (size_t)sl.head * dk;
+  unsigned char* dst = threadIdx.x < 256 ? kimg : vimg;
+  TileRegs tr;
+  tile_gload(tr, src, 0, len, dk, rs);
+  if (threadIdx.x < RMAX) kbias[threadIdx.x] = (threadIdx.x >= len || (kpm && kpm[sl.row0 + threadIdx.x])) ? -INFINITY : 0.f;
+  const int q0 = wave * 32;
+  const bool active = q0 < len;
+  const int qrow = q0 + (lane & 31);
+  const size_t stat = ((size_t)sl.b * h + sl.head) * sl.Lmax + qrow;
+  // delta_q = <dO_q, O_q> in fp32 (each half-wave covers half of the head dimension); published for the dK/dV kernel
+  float del_q = 0.f;
+  if (qrow < len) {
+    const float* op = o + (sl.row0 + qrow) * ors + (size_t)sl.head * dk;
+    const float* dp = dout + (sl.row0 + qrow) * ors + (size_t)sl.head * dk;
+    const int cm = (dk / 2) & ~3;
+    const int c0 = half ? cm : 0, c1 = half ? dk : cm;
+    for (int c = c0; c < c1; c += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(op + c);
+      const float4 g = *reinterpret_cast<const float4*>(dp + c);
+      del_q += a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
+    }
+  }
+  del_q += __shfl_xor(del_q, 32, 64);
+  if (half == 0 && qrow < len) delta[stat] = del_q;
+  const float lse_q = (qrow < len) ? lse[stat] * kLog2e : 0.f;
+  bf16x8 qh[4], ql[4], doh[4], dol[4];
+  load_fixed(qh, ql, q + sl.row0 * rs + (size_t)sl.head * dk, q0, len, dk, rs);
+  load_fixed(doh, dol, dout + sl.row0 * ors + (size_t)sl.head * dk, q0, len, dk, ors);
+  const uint32_t drow = DROP ? drop_row_seed(drop, sl.bh, sl.Lmax, qrow) : 0u;
+  const float sl2 = scale * kLog2e;
+  f32x16 dqacc[2];
+  zero2(dqacc);
+  const int nkt = (len + 31) / 32;
+  for (int kt = 0; kt < nkt; ++kt) {
+    tile_sstore(dst, kt, tr);
+    if (kt + 1 < nkt) tile_gload(tr, src, kt + 1, len, dk, rs);
+    __syncthreads();
+    if (!active) continue;
+    const f32x16 s = rows_x_fixed<2>(kimg, kt * 32, qh, ql);    // S^T[key][query]
+    const f32x16 dp = rows_x_fixed<2>(vimg, kt * 32, doh, dol); // dP^T[key][query] = V dO^T
+    f32x16 ds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + rowmap(r, half);
+      const float p = fast_exp2(s[r] * sl2 + kbias[key] - lse_q);
+      const float dm = DROP ? drop_scale_rk(drop, drow, key) : 1.0f;
+      ds[r] = p * (dp[r] * dm - del_q) * scale;
+    }
+    cols_x_p(kimg, kt * 32, ds, dqacc);                          // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+  }
+  if (!active) return;
+  store_rows(dq + sl.row0 * drs + (size_t)sl.head * dk, q0, len, dk, drs, dqacc, 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward dK, dV: Q and dO resident; wave owns 32 keys (K and V fragments in registers)
+// ------------------------------------------------------------------------------------------------------------------
+template <bool DROP>
+__global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const uint8_t* __restrict__ kpm,
+    const float* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta, int L, int h, int dk, int rs,
+    int ors, float* __restrict__ dkout, float* __restrict__ dvout, int drs, float scale, DropCfg drop,
+    const uint32_t* __restrict__ drop_step, const int* __restrict__ cu, const int* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* qimg = smem;
+  unsigned char* doimg = smem + 2 * PLANE;
+  float* lse_t = reinterpret_cast<float*>(smem + 4 * PLANE);
+  float* del_t = lse_t + RMAX;
+  uint32_t* drow_t = reinterpret_cast<uint32_t*>(del_t + RMAX);
+  if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
+  const Slate sl = which_slate(L, h, cu, order);
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int len = sl.len;
+  const bool first = threadIdx.x < 256;
+  const float* src = first ? q + sl.row0 * rs + (size_t)sl.head * dk : dout + sl.row0 * ors + (size_t)sl.head * dk;
+  const size_t srs = first ? (size_t)rs : (size_t)ors;
+  unsigned char* dst = first ? qimg : doimg;
+  TileRegs tr;
+  tile_gload(tr, src, 0, len, dk, srs);
+  const size_t statb = ((size_t)sl.b * h + sl.head) * sl.Lmax;
+  if (threadIdx.x < RMAX) {
+    const int qr = threadIdx.x;
+    lse_t[qr] = (qr < len) ? lse[statb + qr] * kLog2e : INFINITY;       // +inf -> P = exp2(-inf) = 0 for rows >= len
+    del_t[qr] = (qr < len) ? delta[statb + qr] : 0.f;
+    if (DROP) drow_t[qr] = drop_row_seed(drop, sl.bh, sl.Lmax, qr);
+  }
+  const int k0 = wave * 32;
+  bf16x8 kh[4], kl[4], vh[4], vl[4];
+  load_fixed(kh, kl, k + sl.row0 * rs + (size_t)sl.head * dk, k0, len, dk, rs);
+  load_fixed(vh, vl, v + sl.row0 * rs + (size_t)sl.head * dk, k0, len, dk, rs);
+  const bool active = k0 < len;
+  const int key = k0 + (lane & 31);
+  const bool key_masked = (key >= len) || (kpm && kpm[sl.row0 + (key < len ? key : 0)] != 0);
+  const float kbias = key_masked ? -INFINITY : 0.f;
+  const float sl2 = scale * kLog2e;
+  f32x16 dkacc[2], dvacc[2];
+  zero2(dkacc);
+  zero2(dvacc);
+  const int nqt = (len + 31) / 32;
+  for (int qt = 0; qt < nqt; ++qt) {
+    tile_sstore(dst, qt, tr);
+    if (qt + 1 < nqt) tile_gload(tr, src, qt + 1, len, dk, srs);
+    __syncthreads();
+    if (!active) continue;
+    // (order chosen for register pressure: both 16-register products first, then the two accumulations; the fences keep the
+    //  scheduler from hoisting the second accumulation's transposed reads above the first)
+    f32x16 p = rows_x_fixed<2>(qimg, qt * 32, kh, kl);            // S[query = rowmap(r, half)][key = l31]
+    f32x16 ds = rows_x_fixed<2>(doimg, qt * 32, vh, vl);         // dP[query][key] = dO V^T
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = qt * 32 + rowmap(r, half);
+      const float pr = fast_exp2(p[r] * sl2 + kbias - lse_t[qr]);
+      const float dm = DROP ? drop_scale_rk(drop, drow_t[qr], key) : 1.0f;
+      ds[r] = pr * (ds[r] * dm - del_t[qr]) * scale;             // dS
+      p[r] = pr * dm;                                            // P M
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cols_x_p(doimg, qt * 32, p, dvacc);                          // dV^T[d][key] += dO^T[d][query] (P M)[query][key]
+    __builtin_amdgcn_sched_barrier(0);
+    cols_x_p(qimg, qt * 32, ds, dkacc);                          // dK^T[d][key] += Q^T[d][query] dS[query][key]
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (!active) return;
+  store_rows(dkout + sl.row0 * drs + (size_t)sl.head * dk, k0, len, dk, drs, dkacc, 1.0f);
+  store_rows(dvout + sl.row0 * drs + (size_t)sl.head * dk, k0, len, dk, drs, dvacc, 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host launchers (called from ltrx_mha.hip's C entry points when the shape fits: L <= 256, 32 < d_k <= 64)
+// ------------------------------------------------------------------------------------------------------------------
+static constexpr size_t RES_SMEM = 4 * (size_t)PLANE + 3 * RMAX * sizeof(float);
+
+bool ltrx_mha_res_fits(int L, int dk) { return L <= RMAX && dk > 32 && dk <= DK; }
+
+template <typename K>
+static int res_attr(K kernel) {
+  return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_SMEM) == hipSuccess ? LTRX_OK : LTRX_EHIP;
+}
+
+int ltrx_mha_fwd_res_launch(const float* q, const float* k, const float* v, const uint8_t* kpm, int B, int L, int h, int dk, int rs,
+                            float* o, int ors, float* lse, float p_drop, uint32_t seed, const uint32_t* seed_step, const int* cu,
+                            const int* order, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    if (res_attr(ltrx_mha_fwd_res_kernel<false>) != LTRX_OK || res_attr(ltrx_mha_fwd_res_kernel<true>) != LTRX_OK) return LTRX_EHIP;
+    attr = true;
+  }
+  const DropCfg drop = ltrx_make_drop(p_drop, seed);
+  const float scale = 1.0f / sqrtf((float)dk);
+  const dim3 grid(B * h);
+  if (drop.thresh != 0u)
+    hipLaunchKernelGGL(ltrx_mha_fwd_res_kernel<true>, grid, dim3(512), RES_SMEM, s, q, k, v, kpm, L, h, dk, rs, o, ors, lse, scale, drop,
+                       seed_step, cu, order);
+  else
+    hipLaunchKernelGGL(ltrx_mha_fwd_res_kernel<false>, grid, dim3(512), RES_SMEM, s, q, k, v, kpm, L, h, dk, rs, o, ors, lse, scale, drop,
+                       seed_step, cu, order);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+int ltrx_mha_bwd_res_launch(const float* q, const float* k, const float* v, const uint8_t* kpm, const float* o, const float* dout,
+                            const float* lse, int B, int L, int h, int dk, int rs, int ors, float* dq, float* dkk, float* dv, int drs,
+                            float* delta, float p_drop, uint32_t seed, const uint32_t* seed_step, const int* cu, const int* order,
+                            hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    if (res_attr(ltrx_mha_bwd_dq_res_kernel<false>) != LTRX_OK || res_attr(ltrx_mha_bwd_dq_res_kernel<true>) != LTRX_OK ||
+        res_attr(ltrx_mha_bwd_dkdv_res_kernel<false>) != LTRX_OK || res_attr(ltrx_mha_bwd_dkdv_res_kernel<true>) != LTRX_OK)
+      return LTRX_EHIP;
+    attr = true;
+  }
+  const DropCfg drop = ltrx_make_drop(p_drop, seed);
+  const float scale = 1.0f / sqrtf((float)dk);
+  const dim3 grid(B * h);
+  if (drop.thresh != 0u)
+    hipLaunchKernelGGL(ltrx_mha_bwd_dq_res_kernel<true>, grid, dim3(512), RES_SMEM, s, q, k, v, kpm, o, dout, lse, delta, L, h, dk, rs, ors,
+                       dq, drs, scale, drop, seed_step, cu, order);
+  else
+    hipLaunchKernelGGL(ltrx_mha_bwd_dq_res_kernel<false>, grid, dim3(512), RES_SMEM, s, q, k, v, kpm, o, dout, lse, delta, L, h, dk, rs, ors,
+                       dq, drs, scale, drop, seed_step, cu, order);
+  LTRX_LAUNCH_CHECK();
+  if (drop.thresh != 0u)
+    hipLaunchKernelGGL(ltrx_mha_bwd_dkdv_res_kernel<true>, grid, dim3(512), RES_SMEM, s, q, k, v, kpm, dout, lse, delta, L, h, dk, rs, ors,
+                       dkk, dv, drs, scale, drop, seed_step, cu, order);
+  else
+    hipLaunchKernelGGL(ltrx_mha_bwd_dkdv_res_kernel<false>, grid, dim3(512), RES_SMEM, s, q, k, v, kpm, dout, lse, delta, L, h, dk, rs, ors,
+                       dkk, dv, drs, scale, drop, seed_step, cu, order);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}

@@ -192,8 +192,10 @@ int ltrx_layernorm_bwd(const float* dy, const float* xsum, const float* a, const
  * lse / delta); key_pad_mask may be NULL in that layout (every packed row is a valid key).
  * slate_order (i32[B] in device memory, or NULL): a permutation of the slates giving the order in which their workgroups are
  * launched -- longest first balances the CUs on ragged batches; results do not depend on it. */
-/* precision of the attention contractions: 0 (default) = exact fp32 MFMA (bit-exact fp32 products, error ~5e-7),
- * 1 = split-bf16 on the bf16 MFMA (3 products per fp32 product; error ~1e-5 after the softmax exponential). */
+/* arithmetic of the attention contractions: 1 (default) = split-bf16 on the bf16 MFMA (3 products per fp32 product, fp32-class,
+ * like the dense projections) with the whole slate resident in LDS, used wherever the shape fits (slate length <= 256,
+ * 32 < d_k <= 64; dropout and variable-length batches included); 0 = exact fp32 MFMA (bit-exact fp32 products) for every
+ * shape -- the strict reference.  Shapes that do not fit always run the exact kernels. */
 void ltrx_mha_set_mode(int mode);
 int ltrx_mha_get_mode(void);
 int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L, int h,

@@ -223,11 +223,12 @@ def test_layernorm_forward_backward():
         assert np.abs(bt.grad.cpu().numpy() - grads["n.b_2"]).max() < 1e-4 * max(1.0, np.abs(grads["n.b_2"]).max())
 
 
-@pytest.mark.parametrize("mode", [0, 1])      # 0 = exact fp32 MFMA (default), 1 = split-bf16 MFMA
+@pytest.mark.parametrize("mode", [0, 1])      # 0 = exact fp32 MFMA everywhere, 1 = split-bf16 LDS-resident kernels where the shape fits (default)
 @pytest.mark.parametrize("B,L,h,dk", [(2, 240, 8, 64), (3, 70, 4, 8), (2, 33, 1, 96), (1, 300, 2, 32), (2, 129, 1, 128),
-                                      (2, 64, 2, 72)])
+                                      (2, 64, 2, 72), (3, 256, 2, 64), (4, 37, 3, 48), (2, 5, 1, 64)])
 def test_attention_forward_backward(B, L, h, dk, mode):
     from allrank_amd import ops, _lib as LB
+    prev_mode = LB.lib().ltrx_mha_get_mode()
     LB.lib().ltrx_mha_set_mode(mode)
     rng = np.random.default_rng(L * 7 + dk)
     d = h * dk
@@ -236,7 +237,7 @@ def test_attention_forward_backward(B, L, h, dk, mode):
     for b in range(B):
         mask[b, L - 1 - 5 * b:] = b > 0
     if B > 1:
-        mask[1, 3] = True                      # a padded key in the middle (the reference allows arbitrary masks)
+        mask[1, min(3, L - 1)] = L > 4         # a padded key in the middle (the reference allows arbitrary masks)
     go = rng.standard_normal((B, L, d)).astype(np.float32)
     t = _t(qkv, True)
     q, k, v = t[:, :, :d], t[:, :, d:2 * d], t[:, :, 2 * d:]
@@ -258,7 +259,7 @@ def test_attention_forward_backward(B, L, h, dk, mode):
     for name, ref, sl in (("dq", gq, slice(0, d)), ("dk", gk, slice(d, 2 * d)), ("dv", gv, slice(2 * d, 3 * d))):
         err[name] = float(np.abs(g[:, :, sl] - unheads(ref)).max() / max(np.abs(ref).max(), 1e-6))
     _log("attention_%d_%d_%d_%d_mode%d" % (B, L, h, dk, mode), err)
-    LB.lib().ltrx_mha_set_mode(0)
+    LB.lib().ltrx_mha_set_mode(prev_mode)
     assert err["o"] < 2e-5 and err["dq"] < 1e-4 and err["dk"] < 1e-4 and err["dv"] < 1e-4, err
     assert np.all(g[:, :, d:][np.broadcast_to(mask[:, :, None], (B, L, 2 * d))] == 0)   # padded keys get exactly 0
 
@@ -1294,8 +1295,12 @@ def test_full_size_step_properties():
     yi = torch.gather(y, 1, ip)
     l_i, g_i, s_i = first_step(xi, yi, B)
     assert abs(l_i - l_all) <= 1e-5 * (1 + abs(l_all)), (l_i, l_all)
-    assert (s_i - torch.gather(s_all, 1, ip)).abs().max().item() < 2e-5
-    assert (g_i - g_all).abs().max().item() <= GT * gscale
+    # (within-slate order changes which keys share a tile and the summation order of the attention contractions; with the
+    #  three-product bf16 arithmetic of the attention the two runs carry independent ~2e-5 errors on scores of magnitude ~6)
+    assert (s_i - torch.gather(s_all, 1, ip)).abs().max().item() < 1e-4
+    # (gradients: the two runs also take different ReLU masks on the handful of hidden units whose pre-activation is within the
+    #  forward round-off of 0 -- see tests/test_gpu_benchdims.py -- each worth one row's contribution to the FFN gradients)
+    assert (g_i - g_all).abs().max().item() <= 4 * GT * gscale
     # (4) ragged batch: variable-length execution == padded execution
     xr, yr, _ = bench.synth_batch(B, L, F, 124, dev, ragged=True)
     l_pad, g_pad, s_pad = first_step(xr, yr, B)
