@@ -218,105 +218,6 @@ __global__ void __launch_bounds__(BM_ * 2) __attribute__((amdgpu_waves_per_eu(2,
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// NT, software-pipelined: two LDS buffers and two register sets.  Per K-tile ONE barrier; the global loads of tile
-// t+2 are in flight for a whole iteration; the bf16 split + LDS store of tile t+1 sits in the same basic block as the
-// MFMAs of tile t, so the VALU / LDS-write work overlaps the matrix pipe.  128 x 128 x 32 tile, 4 waves, 80 KB LDS
-// (two workgroups per CU).
-// ------------------------------------------------------------------------------------------------------------------
-template <int NTERMS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) ltrx_gemm_nt_pipe_kernel(const float* __restrict__ A, int lda,
-                                                                   const float* __restrict__ B, int ldb,
-                                                                   float* __restrict__ C, int ldc, int M, int N, int K,
-                                                                   const float* __restrict__ bias, int act,
-                                                                   const float* __restrict__ aux, int ldaux, int tiles_n,
-                                                                  ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step) {
-  constexpr int BM_ = 128, BK_ = 32;
-  __shared__ __attribute__((aligned(16))) Smem<NTERMS, BM_, BK_> s[2];
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (id / tiles_n) * BM_, n0 = (id % tiles_n) * BN;
-  const int wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
-  const int srow = threadIdx.x >> 3, sc4 = (threadIdx.x & 7) * 4;
-  float4 ra0[4], rb0[4], ra1[4], rb1[4];
-
-  auto gload = [&](float4 (&ra)[4], float4 (&rb)[4], int k0) {
-    const int k = k0 + sc4;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int r = srow + 32 * p;
-      ra[p] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4*>(A + (size_t)(m0 + r) * lda + k)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[p] = (n0 + r < N && k < K) ? *reinterpret_cast<const float4*>(B + (size_t)(n0 + r) * ldb + k)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto sstore = [&](Smem<NTERMS, BM_, BK_>& d, const float4 (&ra)[4], const float4 (&rb)[4]) {
-    bf16x4 h, l, l2;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int o = swz_off<BK_>(srow + 32 * p, sc4);
-      split4<NTERMS>(ra[p], h, l, l2);
-      *reinterpret_cast<bf16x4*>(&d.a[0][o]) = h;
-      *reinterpret_cast<bf16x4*>(&d.a[1][o]) = l;
-      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&d.a[2][o]) = l2;
-      split4<NTERMS>(rb[p], h, l, l2);
-      *reinterpret_cast<bf16x4*>(&d.b[0][o]) = h;
-      *reinterpret_cast<bf16x4*>(&d.b[1][o]) = l;
-      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&d.b[2][o]) = l2;
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = (K + BK_ - 1) / BK_;
-  gload(ra0, rb0, 0);
-  sstore(s[0], ra0, rb0);
-  if (nk > 1) gload(ra0, rb0, BK_);          // set 0 now holds tile 1
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    // even step: compute tile kt from s[0]; stage tile kt+1 (set 0) into s[1]; prefetch tile kt+2 into set 1
-    if (kt + 2 < nk) gload(ra1, rb1, (kt + 2) * BK_);
-    mma_tile<NTERMS, BM_, BK_>(s[0], wr, wc, acc);
-    if (kt + 1 < nk) sstore(s[1], ra0, rb0);
-    __syncthreads();
-    if (kt + 1 >= nk) break;
-    // odd step: compute tile kt+1 from s[1]; stage tile kt+2 (set 1) into s[0]; prefetch tile kt+3 into set 0
-    if (kt + 3 < nk) gload(ra0, rb0, (kt + 3) * BK_);
-    mma_tile<NTERMS, BM_, BK_>(s[1], wr, wc, acc);
-    if (kt + 2 < nk) sstore(s[0], ra1, rb1);
-    __syncthreads();
-  }
-
-  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
-  ltrx::DropSpec dsp = drop;
-  if (drop_step) dsp.seed ^= drop_step[0] * 0x9E3779B9u;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wc * 64 + j * 32 + l31;
-    if (col >= N) continue;
-    const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wr * 64 + i * 32 + rowmap(r, half);
-        if (row < M) {
-          float v = acc[i][j][r] + bv;
-          if (act == 1) v = fmaxf(v, 0.f);
-          if (act == 2) v = (aux[(size_t)row * ldaux + col] > 0.f) ? v * drop.inv_keep : 0.f;
-          else if (drop.thresh != 0u) v *= ltrx::drop_keep_scale(dsp, (uint64_t)row * (uint64_t)N + (uint64_t)col);
-          C[(size_t)row * ldc + col] = v;
-        }
-      }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // NT, large-tile variant for the big projections: 256 x 256 x 32 tile, 8 waves (2 x 4), wave tile 128 x 64 (128
 // accumulator VGPRs), two LDS stages (128 KB: one workgroup per CU) and ONE LDS-only barrier per K-step.
 // Why (tools/lab/gemm_ablate.hip, gemm256.hip; MI355X, M 61440 x N 2048 x K 512): in the 128 x 128 kernel the memory side
@@ -792,8 +693,8 @@ static void launch_slab_reduce(const float* slabs, int splits, size_t n, float* 
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-// tile variant: 0 = auto; 1 = 128x128x32 (4 waves); 2 = 128x128x64; 3 = 256x128x32 (8 waves); 4 = 256x128x64; 5 = pipelined
-// 128x128x32; 6 = 256x256x32 large-tile kernel (auto picks it for exact multiples with >= 360 tiles); 7 = its 128x256x32 form
+// tile variant: 0 = auto; 1 = 128x128x32 (4 waves); 2 = 128x128x64; 3 = 256x128x32 (8 waves); 4 = 256x128x64;
+// 6 = 256x256x32 large-tile kernel (auto picks it for exact multiples with >= 360 tiles); 7 = its 128x256x32 form
 static int g_nt_variant = 0;
 extern "C" void ltrx_gemm_set_variant(int v) { g_nt_variant = v; }
 
@@ -884,12 +785,6 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
       case 2: launch_nt<2, 128, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, drop, drop_step, s); break;
       case 3: launch_nt<2, 256, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, drop, drop_step, s); break;
       case 4: launch_nt<2, 256, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, drop, drop_step, s); break;
-      case 5: {
-        const int tiles_m = (M + 127) / 128, tiles_n = (N + BN - 1) / BN;
-        hipLaunchKernelGGL(ltrx_gemm_nt_pipe_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), 0, s, A, lda, B, ldb, C, ldc, M, N,
-                           K, bias, act, aux, ldaux, tiles_n, drop, drop_step);
-        break;
-      }
       default: launch_nt<2, 128, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, drop, drop_step, s); break;
     }
   }

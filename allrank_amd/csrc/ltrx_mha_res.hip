@@ -80,7 +80,7 @@ __device__ __forceinline__ void tile_gload(TileRegs& r, const float* __restrict_
 }
 __device__ __forceinline__ void tile_sstore(unsigned char* img, int tile, const TileRegs& r) {
   const int idx = threadIdx.x & 255;
-  const int row = tile * 32 + (idx >> 3), chunk = idx & 7;
+  const int row = (tile & 7) * 32 + (idx >> 3), chunk = idx & 7;      // ring slot of the tile
   const float x[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
   bf16x8 h, l;
 #pragma unroll
@@ -243,8 +243,8 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
   unsigned char* dst = threadIdx.x < 256 ? kimg : vimg;
   TileRegs tr;
   tile_gload(tr, src, 0, len, dk, rs);
-  if (threadIdx.x < RMAX) kbias[threadIdx.x] = (threadIdx.x >= len || (kpm && kpm[sl.row0 + threadIdx.x])) ? -INFINITY : 0.f;
-  const int q0 = wave * 32;
+  if ((int)(blockIdx.y * RMAX) >= len) return;        // whole workgroup beyond this slate (uniform: before any barrier)
+  const int q0 = blockIdx.y * RMAX + wave * 32;
   const bool active = q0 < len;                 // (inactive waves still help staging and take every barrier)
   bf16x8 qh[4], ql[4];
   load_fixed(qh, ql, qb, q0, len, dk, rs);
@@ -256,14 +256,19 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
   const int nkt = (len + 31) / 32;
   for (int kt = 0; kt < nkt; ++kt) {
     tile_sstore(dst, kt, tr);
+    if (threadIdx.x < 32) {
+      const int key = kt * 32 + threadIdx.x;
+      kbias[(kt & 7) * 32 + threadIdx.x] = (key >= len || (kpm && kpm[sl.row0 + key])) ? -INFINITY : 0.f;
+    }
     if (kt + 1 < nkt) tile_gload(tr, src, kt + 1, len, dk, rs);       // in flight during this tile's MFMAs
     __syncthreads();
     if (!active) continue;
-    f32x16 s = rows_x_fixed<4>(kimg, kt * 32, qh, ql);         // S^T[key = rowmap(r, half)][query = l31]
+    const int slot = (kt & 7) * 32;                            // ring slot (rows of the LDS images) of this tile
+    f32x16 s = rows_x_fixed<4>(kimg, slot, qh, ql);            // S^T[key = rowmap(r, half)][query = l31]
     float mt = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s[r] = s[r] * sl2 + kbias[kt * 32 + rowmap(r, half)];
+      s[r] = s[r] * sl2 + kbias[slot + rowmap(r, half)];
       mt = fmaxf(mt, s[r]);
     }
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
@@ -286,7 +291,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[ct][r] *= alpha;
-    cols_x_p(vimg, kt * 32, p, oacc);                            // O^T[d][query] += V^T[d][key] P^T[key][query]
+    cols_x_p(vimg, slot, p, oacc);                               // O^T[d][query] += V^T[d][key] P^T[key][query]
     m = mn;
   }
   if (!active) return;
@@ -318,8 +323,8 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dq_res_kernel(
   unsigned char* dst = threadIdx.x < 256 ? kimg : vimg;
   TileRegs tr;
   tile_gload(tr, src, 0, len, dk, rs);
-  if (threadIdx.x < RMAX) kbias[threadIdx.x] = (threadIdx.x >= len || (kpm && kpm[sl.row0 + threadIdx.x])) ? -INFINITY : 0.f;
-  const int q0 = wave * 32;
+  if ((int)(blockIdx.y * RMAX) >= len) return;
+  const int q0 = blockIdx.y * RMAX + wave * 32;
   const bool active = q0 < len;
   const int qrow = q0 + (lane & 31);
   const size_t stat = ((size_t)sl.b * h + sl.head) * sl.Lmax + qrow;
@@ -349,20 +354,25 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dq_res_kernel(
   const int nkt = (len + 31) / 32;
   for (int kt = 0; kt < nkt; ++kt) {
     tile_sstore(dst, kt, tr);
+    if (threadIdx.x < 32) {
+      const int key = kt * 32 + threadIdx.x;
+      kbias[(kt & 7) * 32 + threadIdx.x] = (key >= len || (kpm && kpm[sl.row0 + key])) ? -INFINITY : 0.f;
+    }
     if (kt + 1 < nkt) tile_gload(tr, src, kt + 1, len, dk, rs);
     __syncthreads();
     if (!active) continue;
-    const f32x16 s = rows_x_fixed<2>(kimg, kt * 32, qh, ql);    // S^T[key][query]
-    const f32x16 dp = rows_x_fixed<2>(vimg, kt * 32, doh, dol); // dP^T[key][query] = V dO^T
+    const int slot = (kt & 7) * 32;
+    const f32x16 s = rows_x_fixed<2>(kimg, slot, qh, ql);       // S^T[key][query]
+    const f32x16 dp = rows_x_fixed<2>(vimg, slot, doh, dol);    // dP^T[key][query] = V dO^T
     f32x16 ds;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = kt * 32 + rowmap(r, half);
-      const float p = fast_exp2(s[r] * sl2 + kbias[key] - lse_q);
+      const float p = fast_exp2(s[r] * sl2 + kbias[slot + rowmap(r, half)] - lse_q);
       const float dm = DROP ? drop_scale_rk(drop, drow, key) : 1.0f;
       ds[r] = p * (dp[r] * dm - del_q) * scale;
     }
-    cols_x_p(kimg, kt * 32, ds, dqacc);                          // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+    cols_x_p(kimg, slot, ds, dqacc);                             // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
   }
   if (!active) return;
   store_rows(dq + sl.row0 * drs + (size_t)sl.head * dk, q0, len, dk, drs, dqacc, 1.0f);
@@ -394,13 +404,8 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
   TileRegs tr;
   tile_gload(tr, src, 0, len, dk, srs);
   const size_t statb = ((size_t)sl.b * h + sl.head) * sl.Lmax;
-  if (threadIdx.x < RMAX) {
-    const int qr = threadIdx.x;
-    lse_t[qr] = (qr < len) ? lse[statb + qr] * kLog2e : INFINITY;       // +inf -> P = exp2(-inf) = 0 for rows >= len
-    del_t[qr] = (qr < len) ? delta[statb + qr] : 0.f;
-    if (DROP) drow_t[qr] = drop_row_seed(drop, sl.bh, sl.Lmax, qr);
-  }
-  const int k0 = wave * 32;
+  if ((int)(blockIdx.y * RMAX) >= len) return;
+  const int k0 = blockIdx.y * RMAX + wave * 32;
   bf16x8 kh[4], kl[4], vh[4], vl[4];
   load_fixed(kh, kl, k + sl.row0 * rs + (size_t)sl.head * dk, k0, len, dk, rs);
   load_fixed(vh, vl, v + sl.row0 * rs + (size_t)sl.head * dk, k0, len, dk, rs);
@@ -415,25 +420,32 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
   const int nqt = (len + 31) / 32;
   for (int qt = 0; qt < nqt; ++qt) {
     tile_sstore(dst, qt, tr);
+    if (threadIdx.x < 32) {                                      // per-query statistics of this tile (ring slot)
+      const int qr = qt * 32 + threadIdx.x, sl_ = (qt & 7) * 32 + threadIdx.x;
+      lse_t[sl_] = (qr < len) ? lse[statb + qr] * kLog2e : INFINITY;       // +inf -> P = exp2(-inf) = 0 for rows >= len
+      del_t[sl_] = (qr < len) ? delta[statb + qr] : 0.f;
+      if (DROP) drow_t[sl_] = drop_row_seed(drop, sl.bh, sl.Lmax, qr);
+    }
     if (qt + 1 < nqt) tile_gload(tr, src, qt + 1, len, dk, srs);
     __syncthreads();
     if (!active) continue;
+    const int slot = (qt & 7) * 32;
     // (order chosen for register pressure: both 16-register products first, then the two accumulations; the fences keep the
     //  scheduler from hoisting the second accumulation's transposed reads above the first)
-    f32x16 p = rows_x_fixed<2>(qimg, qt * 32, kh, kl);            // S[query = rowmap(r, half)][key = l31]
-    f32x16 ds = rows_x_fixed<2>(doimg, qt * 32, vh, vl);         // dP[query][key] = dO V^T
+    f32x16 p = rows_x_fixed<2>(qimg, slot, kh, kl);               // S[query = rowmap(r, half)][key = l31]
+    f32x16 ds = rows_x_fixed<2>(doimg, slot, vh, vl);            // dP[query][key] = dO V^T
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int qr = qt * 32 + rowmap(r, half);
+      const int qr = slot + rowmap(r, half);
       const float pr = fast_exp2(p[r] * sl2 + kbias - lse_t[qr]);
       const float dm = DROP ? drop_scale_rk(drop, drow_t[qr], key) : 1.0f;
       ds[r] = pr * (ds[r] * dm - del_t[qr]) * scale;             // dS
       p[r] = pr * dm;                                            // P M
     }
     __builtin_amdgcn_sched_barrier(0);
-    cols_x_p(doimg, qt * 32, p, dvacc);                          // dV^T[d][key] += dO^T[d][query] (P M)[query][key]
+    cols_x_p(doimg, slot, p, dvacc);                             // dV^T[d][key] += dO^T[d][query] (P M)[query][key]
     __builtin_amdgcn_sched_barrier(0);
-    cols_x_p(qimg, qt * 32, ds, dkacc);                          // dK^T[d][key] += Q^T[d][query] dS[query][key]
+    cols_x_p(qimg, slot, ds, dkacc);                             // dK^T[d][key] += Q^T[d][query] dS[query][key]
     __builtin_amdgcn_sched_barrier(0);
   }
   if (!active) return;
@@ -446,7 +458,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
 // ------------------------------------------------------------------------------------------------------------------
 static constexpr size_t RES_SMEM = 4 * (size_t)PLANE + 3 * RMAX * sizeof(float);
 
-bool ltrx_mha_res_fits(int L, int dk) { return L <= RMAX && dk > 32 && dk <= DK; }
+bool ltrx_mha_res_fits(int L, int dk) { return L > 0 && (L + RMAX - 1) / RMAX <= 65535 && dk > 32 && dk <= DK; }
 
 template <typename K>
 static int res_attr(K kernel) {
@@ -463,7 +475,7 @@ int ltrx_mha_fwd_res_launch(const float* q, const float* k, const float* v, cons
   }
   const DropCfg drop = ltrx_make_drop(p_drop, seed);
   const float scale = 1.0f / sqrtf((float)dk);
-  const dim3 grid(B * h);
+  const dim3 grid(B * h, (L + RMAX - 1) / RMAX);
   if (drop.thresh != 0u)
     hipLaunchKernelGGL(ltrx_mha_fwd_res_kernel<true>, grid, dim3(512), RES_SMEM, s, q, k, v, kpm, L, h, dk, rs, o, ors, lse, scale, drop,
                        seed_step, cu, order);
@@ -487,7 +499,7 @@ int ltrx_mha_bwd_res_launch(const float* q, const float* k, const float* v, cons
   }
   const DropCfg drop = ltrx_make_drop(p_drop, seed);
   const float scale = 1.0f / sqrtf((float)dk);
-  const dim3 grid(B * h);
+  const dim3 grid(B * h, (L + RMAX - 1) / RMAX);
   if (drop.thresh != 0u)
     hipLaunchKernelGGL(ltrx_mha_bwd_dq_res_kernel<true>, grid, dim3(512), RES_SMEM, s, q, k, v, kpm, o, dout, lse, delta, L, h, dk, rs, ors,
                        dq, drs, scale, drop, seed_step, cu, order);

@@ -225,7 +225,7 @@ def test_layernorm_forward_backward():
 
 @pytest.mark.parametrize("mode", [0, 1])      # 0 = exact fp32 MFMA everywhere, 1 = split-bf16 LDS-resident kernels where the shape fits (default)
 @pytest.mark.parametrize("B,L,h,dk", [(2, 240, 8, 64), (3, 70, 4, 8), (2, 33, 1, 96), (1, 300, 2, 32), (2, 129, 1, 128),
-                                      (2, 64, 2, 72), (3, 256, 2, 64), (4, 37, 3, 48), (2, 5, 1, 64)])
+                                      (2, 64, 2, 72), (3, 256, 2, 64), (4, 37, 3, 48), (2, 5, 1, 64), (1, 300, 2, 64), (2, 1024, 1, 64), (2, 513, 2, 48)])
 def test_attention_forward_backward(B, L, h, dk, mode):
     from allrank_amd import ops, _lib as LB
     prev_mode = LB.lib().ltrx_mha_get_mode()
@@ -1121,7 +1121,7 @@ def test_gather_scatter_rows():
 
 @pytest.mark.parametrize("p_drop", [0.0, 0.3])
 @pytest.mark.parametrize("B,L,h,dk,lens", [(3, 70, 4, 8, [70, 1, 33]), (4, 240, 8, 64, [240, 100, 129, 17]),
-                                           (2, 300, 2, 32, [257, 300])])
+                                           (2, 300, 2, 32, [257, 300]), (3, 600, 2, 64, [600, 257, 31]), (2, 1024, 1, 64, [1024, 700])])
 def test_attention_varlen_matches_padded(B, L, h, dk, lens, p_drop):
     """cu_seqlens layout (packed valid rows, no mask) == padded layout + key mask on the valid rows: forward output and
     all three input gradients, bit for bit (same tiles, same order), dropout included (the mask hash is keyed by the
