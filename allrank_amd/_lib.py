@@ -7,7 +7,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libltrx.so")
+LIB_PATH = os.environ.get("LTRX_LIB_PATH") or os.path.join(_HERE, "libltrx.so")     # (override: A/B runs of two builds)
 
 _c_float_p = ctypes.c_void_p   # device pointers are passed as raw addresses
 _vp = ctypes.c_void_p

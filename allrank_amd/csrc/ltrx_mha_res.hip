@@ -114,6 +114,9 @@ __device__ __forceinline__ void load_fixed(bf16x8 (&fh)[4], bf16x8 (&fl)[4], con
 }
 
 #define LTRX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#ifndef LTRX_MHA_SETPRIO
+#define LTRX_MHA_SETPRIO 0
+#endif
 
 // acc[r] = sum_c IMG[tile_row0 + rowmap(r, half)][c] * FIXED[l31][c].  NACC accumulators (4: one per 16-deep k-step, term-major
 // order, consecutive MFMAs never write the same accumulator; 2: 32 fewer live registers for the kernels at the VGPR limit)
@@ -132,12 +135,14 @@ __device__ __forceinline__ f32x16 rows_x_fixed(const unsigned char* img, int til
   for (int n = 0; n < NACC; ++n)
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[n][r] = 0.f;
+  if (LTRX_MHA_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) a[ks % NACC] = LTRX_MFMA(xl[ks], fh[ks], a[ks % NACC]);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) a[ks % NACC] = LTRX_MFMA(xh[ks], fl[ks], a[ks % NACC]);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) a[ks % NACC] = LTRX_MFMA(xh[ks], fh[ks], a[ks % NACC]);
+  if (LTRX_MHA_SETPRIO) __builtin_amdgcn_s_setprio(0);
   if (NACC == 4) return (a[0] + a[1]) + (a[2] + a[3]);
   return a[0] + a[1 % NACC];
 }

@@ -73,8 +73,9 @@ class FusedTrainer(object):
       ReLU+dropout, the residual add of the LayerNorm kernel, the attention probabilities) and REGENERATED in the backward
       -- no mask tensors, and a replayed hipGraph draws fresh masks because the step word lives in device memory.
     Supported model family: FCModel (optional input_norm = nn.LayerNorm, activation None/ReLU) -> optional encoder with
-    optional fixed / learned positional encoding (positional.py:15-77) -> OutputLayer(d_output=1, activation None / Sigmoid /
-    Tanh).  Anything else (d_output > 1, other FC activations) raises NotImplementedError (use ``Trainer``).
+    optional fixed / learned positional encoding (positional.py:15-77) -> OutputLayer(any d_output, activation None / Sigmoid /
+    Tanh; d_output > 1 feeds the ``ordinal`` loss, ``scores`` is then the sum over the output units, model.py:119-128).
+    Other FC / output activations raise NotImplementedError (use ``Trainer``).
     """
 
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
@@ -120,8 +121,7 @@ class FusedTrainer(object):
         self.pos = enc.position if (enc is not None and enc.position is not None) else None
         self.pos_learned = isinstance(self.pos, LearnedPositionalEncoding)
         out = model.output_layer
-        if out.d_output != 1:
-            raise NotImplementedError("FusedTrainer: OutputLayer must have d_output == 1")
+        self.n_out = int(out.d_output)                # > 1: ordinal configs (model.py:111-128: forward [B, L, d_output], score = sum)
         if isinstance(out.activation, nn.Identity):
             self.out_act = 0
         elif isinstance(out.activation, nn.Sigmoid):
@@ -279,10 +279,17 @@ class FusedTrainer(object):
             self.d_br = torch.zeros((M, d), **f32)            # gradient of a dropped residual branch (ds * keep)
             self.ws_ln = torch.empty(max(self.lib.ltrx_layernorm_bwd_workspace_bytes(M, d), 64), dtype=torch.uint8, device=dev)
             self.ws_mha = torch.empty(max(self.lib.ltrx_mha_bwd_workspace_bytes(B, L, self.h), 64), dtype=torch.uint8, device=dev)
-        self.scores = torch.zeros((B, L), **f32)
+        no = self.n_out
+        self.scores_raw = torch.zeros((B, L) if no == 1 else (B, L, no), **f32)      # what the loss sees (model.forward)
+        self.scores = self.scores_raw if no == 1 else torch.zeros((B, L), **f32)      # model.score (sum over the output units)
         if compact:
-            self.scores_c = torch.zeros(M, **f32)
-            self.dsc_c = torch.zeros(M, **f32)
+            self.scores_c = torch.zeros(M if no == 1 else (M, no), **f32)
+            self.dsc_c = torch.zeros(M if no == 1 else (M, no), **f32)
+        if no > 1:
+            npad = (no + 3) // 4 * 4
+            self.dz_pad = torch.zeros((M, npad), **f32)        # d loss / d pre-activation, K padded to a multiple of 4 for the dgrad GEMM
+            self.woutT_pad = torch.zeros((d, npad), **f32)     # W_out^T zero-padded the same way (refreshed after every optimizer step)
+            self.zb = torch.zeros(no, **f32)
         self.d_a = torch.zeros((M, d), **f32)                 # gradient w.r.t. the residual stream (ping)
         self.d_b = torch.zeros((M, d), **f32)                 # (pong)
         maxn = max([3 * d, self.dff if self.N else 0] + self.fc_sizes[1:])
@@ -295,6 +302,8 @@ class FusedTrainer(object):
             shapes = [(s1, s0) for s0, s1 in zip(self.fc_sizes[:-1], self.fc_sizes[1:])]
             if self.N:
                 shapes += [(3 * d, d), (d, d), (self.dff, d), (d, self.dff)]
+            if self.n_out > 1:
+                shapes += [(self.n_out, d)]
             for (npp, kpp) in shapes:
                 nb = max(nb, self.lib.ltrx_gemm_tn_workspace_bytes(M, npp, kpp))
             self.ws_tn = torch.empty(max(nb, 64), dtype=torch.uint8, device=dev)
@@ -325,6 +334,8 @@ class FusedTrainer(object):
             self._tn, self._ttiles = len(srcs), tstart[-1]
             self._refresh_transposes()
         self.loss = FusedLoss(loss_name, B, L, dev, **(loss_args or {}))
+        if (self.n_out > 1) != (loss_name == "ordinal") or (loss_name == "ordinal" and int(loss_args["n"]) != self.n_out):
+            raise NotImplementedError("FusedTrainer: d_output > 1 goes with the ordinal loss of the same n (and only with it)")
         # ListMLE: the reference draws torch.randperm(L) on every call (listMLE.py:17).  shuffle_ties=True (default) does
         # the same with a device generator; tests that compare with the oracle set shuffle_ties=False and an explicit
         # permutation via ``trainer.loss.set_perm``.
@@ -389,6 +400,8 @@ class FusedTrainer(object):
         self.LB.check(self.lib.ltrx_relu_bwd(self.LB.ptr(dr), self.LB.ptr(r), self.rows * dr.shape[1], 1.0 / (1.0 - p), self._st()), "relu_bwd")
 
     def _refresh_transposes(self):
+        if self.n_out > 1:                                        # W_out^T [d, d_output] zero-padded to a multiple of 4 columns
+            self.woutT_pad[:, :self.n_out].copy_(self.W(self.model.output_layer.w_1.weight).t())
         if self.gemm == "hipblaslt":
             return
         if self._tn:
@@ -425,7 +438,7 @@ class FusedTrainer(object):
         post-dropout activation that produced the layer input) the ReLU(+dropout p) backward mask is applied in the GEMM
         epilogue; without it, p > 0 re-applies the dropout mask of site ``seed`` (identity activation)."""
         if self.gemm == "hipblaslt":
-            torch.mm(dy[:self.rows], w, out=out[:self.rows])
+            torch.mm(dy[:self.rows, :w.shape[0]], w, out=out[:self.rows])      # (dy may carry zero padding columns)
             if relu_of is not None:
                 self._relu_bwd(out, relu_of, p)
             elif p:
@@ -508,27 +521,38 @@ class FusedTrainer(object):
             feat = self.xf
         else:
             feat = x
-        sc_rows = self.scores_c if self.compact else self.scores
-        self.LB.check(lib.ltrx_score_head_fwd(P(feat), P(W(out.w_1.weight)), P(W(out.w_1.bias)), M, d, P(sc_rows), self._st()),
-                      "score_head_fwd")
+        no = self.n_out
+        sc_rows = self.scores_c if self.compact else self.scores_raw
+        if no == 1:
+            self.LB.check(lib.ltrx_score_head_fwd(P(feat), P(W(out.w_1.weight)), P(W(out.w_1.bias)), M, d, P(sc_rows), self._st()),
+                          "score_head_fwd")
+        else:                                                     # Linear(d, d_output) as a GEMM (model.py:117)
+            self._lin_fwd(feat, W(out.w_1.weight), W(out.w_1.bias), sc_rows.view(-1, no))
         if self.out_act:                                          # OutputLayer activation (model.py:117), in place
-            self.LB.check(lib.ltrx_out_act_fwd(P(sc_rows), M, self.out_act, P(sc_rows), self._st()), "out_act_fwd")
+            self.LB.check(lib.ltrx_out_act_fwd(P(sc_rows), M * no, self.out_act, P(sc_rows), self._st()), "out_act_fwd")
         if self.compact:                                          # packed scores -> the padded [B, L] grid of the loss kernels
-            self.scores.zero_()
-            self.LB.check(lib.ltrx_scatter_rows(P(self.scores_c), 1, P(self.idx), self.n_valid, 1, P(self.scores), 1, self._st()),
+            self.scores_raw.zero_()
+            self.LB.check(lib.ltrx_scatter_rows(P(self.scores_c), no, P(self.idx), self.n_valid, no, P(self.scores_raw), no, self._st()),
                           "scatter_rows")
+        if no > 1:
+            torch.sum(self.scores_raw, dim=-1, out=self.scores)   # model.score (model.py:127)
         # ---------------- loss (value + d/dscores) ----------------
-        loss, dsc = self.loss.run(self.scores, self.y_in, self._divisor)
+        loss, dsc = self.loss.run(self.scores_raw, self.y_in, self._divisor)
         # ---------------- backward ----------------
         ga, gb = self.d_a, self.d_b
         if self.compact:                                          # d loss / d scores of the packed rows (alignment rows: 0)
-            self.LB.check(lib.ltrx_gather_rows(P(dsc), 1, P(self.idx), self.n_valid, M, 1, P(self.dsc_c), 1, self._st()),
+            self.LB.check(lib.ltrx_gather_rows(P(dsc), no, P(self.idx), self.n_valid, M, no, P(self.dsc_c), no, self._st()),
                           "gather_rows")
             dsc = self.dsc_c
         if self.out_act:                                          # d loss / d pre-activation = d loss / d score * act'(score)
-            self.LB.check(lib.ltrx_out_act_bwd(P(dsc), P(sc_rows), M, self.out_act, P(dsc), self._st()), "out_act_bwd")
-        self.LB.check(lib.ltrx_score_head_bwd(P(dsc), P(feat), P(W(out.w_1.weight)), M, d, P(ga), P(G(out.w_1.weight)),
-                                              P(G(out.w_1.bias)), P(self.ws_head), self._st()), "score_head_bwd")
+            self.LB.check(lib.ltrx_out_act_bwd(P(dsc), P(sc_rows), M * no, self.out_act, P(dsc), self._st()), "out_act_bwd")
+        if no == 1:
+            self.LB.check(lib.ltrx_score_head_bwd(P(dsc), P(feat), P(W(out.w_1.weight)), M, d, P(ga), P(G(out.w_1.weight)),
+                                                  P(G(out.w_1.bias)), P(self.ws_head), self._st()), "score_head_bwd")
+        else:                                                     # the d_output-wide head: weight / bias / input gradients as GEMMs
+            self.dz_pad[:M, :no].copy_(dsc.reshape(-1, no)[:M])
+            self._lin_wgrad(self.dz_pad[:, :no], feat, G(out.w_1.weight), G(out.w_1.bias))
+            self._lin_dgrad(self.dz_pad, W(out.w_1.weight), self.woutT_pad, ga)
         if self.N:
             nf = self.enc.norm
             self._ln_bwd(ga, self.xsum_f, W(nf.a_2), self.mean_f, self.rstd_f, None, gb, G(nf.a_2), G(nf.b_2))

@@ -387,6 +387,13 @@ class FusedLoss(object):
             self.cnt = torch.zeros(1, dtype=torch.float32, device=device)
             self.mode = (1 if (name == "rankNet_weightByGTDiff" or args.get("weight_by_diff")) else
                          2 if (name == "rankNet_weightByGTDiff_pow" or args.get("weight_by_diff_powed")) else 0)
+        elif name in ("bce", "ordinal"):
+            # bce: scores [B, SL] probabilities; ordinal: scores [B, SL, n] (n = the OutputLayer's d_output, ordinal.py:25-50)
+            self.n_ord = int(args["n"]) if name == "ordinal" else 0
+            nb = lib.ltrx_bce_workspace_bytes(B, SL, self.n_ord)
+            self.cnt = torch.zeros(1, dtype=torch.float32, device=device)
+            if self.n_ord:
+                self.grad = torch.zeros((B, SL, self.n_ord), dtype=torch.float32, device=device)
         elif name == "binary_listNet":
             nb = lib.ltrx_binary_listnet_workspace_bytes(B, SL)
         elif name == "pointwise_rmse":
@@ -436,6 +443,14 @@ class FusedLoss(object):
                 ext = sharding.allreduce_sum_(self.cnt)
             rc = lib.ltrx_ranknet_fwd_bwd(L.ptr(yp), L.ptr(yt), B, SL, self.pad, self.mode, L.ptr(ext), L.ptr(self.loss), None,
                                           L.ptr(self.grad), L.ptr(self.ws), st)
+        elif n in ("bce", "ordinal"):
+            ext = None
+            if sharding.active():
+                L.check(lib.ltrx_bce_fwd_bwd(L.ptr(yp), L.ptr(yt), B, SL, self.n_ord, self.pad, None, L.ptr(self.loss), L.ptr(self.cnt), None,
+                                             L.ptr(self.ws), st), n + "(count)")
+                ext = sharding.allreduce_sum_(self.cnt)
+            rc = lib.ltrx_bce_fwd_bwd(L.ptr(yp), L.ptr(yt), B, SL, self.n_ord, self.pad, L.ptr(ext), L.ptr(self.loss), None, L.ptr(self.grad),
+                                      L.ptr(self.ws), st)
         elif n == "binary_listNet":
             rc = lib.ltrx_binary_listnet_fwd_bwd(L.ptr(yp), L.ptr(yt), B, SL, self.eps, self.pad, div, L.ptr(self.loss),
                                                  L.ptr(self.grad), L.ptr(self.ws), st)

@@ -29,6 +29,10 @@ def main():
              pe="learned", max_indices=60),
         dict(n_features=20, fc_sizes=[32], fc_activation=None, fc_input_norm=True, N=1, d_ff=64, h=4, output_activation="Tanh",
              pe=None, max_indices=0),
+        # ordinal configuration (reproducibility: d_output = number of relevance levels, Sigmoid, loss "ordinal"); no padded slate:
+        # torch >= 2 rejects BCELoss targets of -1, so the reference itself only runs this loss on un-padded batches here
+        dict(n_features=20, fc_sizes=[32], fc_activation=None, fc_input_norm=False, N=1, d_ff=64, h=4, output_activation="Sigmoid",
+             pe=None, max_indices=0, d_output=4, loss="ordinal"),
     ]
     out = {"n_models": np.int64(len(cfgs))}
     for mi, cfg in enumerate(cfgs):
@@ -36,7 +40,7 @@ def main():
         pe = PositionalEncoding(strategy=cfg["pe"], max_indices=cfg["max_indices"]) if cfg["pe"] else None
         tr = TransformerConfig(N=cfg["N"], d_ff=cfg["d_ff"], h=cfg["h"], positional_encoding=pe, dropout=0.0)
         fc = dict(sizes=list(cfg["fc_sizes"]), input_norm=cfg["fc_input_norm"], activation=cfg["fc_activation"], dropout=0.0)
-        model = make_model(fc, tr, dict(d_output=1, output_activation=cfg["output_activation"]), cfg["n_features"])
+        model = make_model(fc, tr, dict(d_output=cfg.get("d_output", 1), output_activation=cfg["output_activation"]), cfg["n_features"])
         with torch.no_grad():
             for _, p_ in model.named_parameters():
                 if p_.dim() == 1:
@@ -47,14 +51,17 @@ def main():
         y = rng.integers(0, 5, (B, L)).astype(np.float32)
         # original ranks: a random subset of 0..69 in random order (ranks >= max_indices exercise the clamp to the padding row)
         idx = np.stack([rng.permutation(70)[:L] for _ in range(B)]).astype(np.int64)
-        for b in range(1, B):
+        for b in range(1, B if cfg.get("loss") != "ordinal" else 0):
             n = L - 7 * b
             y[b, n:] = -1
             x[b, n:] = 0
             idx[b, n:] = -1
         mask = y == -1
         sc = model(torch.tensor(x), torch.tensor(mask), torch.tensor(idx))
-        loss = RL.approxNDCGLoss(sc, torch.tensor(y))
+        if cfg.get("loss") == "ordinal":
+            loss = RL.ordinal(sc, torch.tensor(y), n=cfg["d_output"])
+        else:
+            loss = RL.approxNDCGLoss(sc, torch.tensor(y))
         loss.backward()
         pre = "m%d." % mi
         for k_, v_ in cfg.items():
