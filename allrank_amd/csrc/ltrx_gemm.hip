@@ -98,8 +98,10 @@ __device__ __forceinline__ void mma_tile(const Smem<NTERMS, BM_, BK_>& s, int wr
       LTRX_MMA_TERM(0, NTERMS - 1)
       LTRX_MMA_TERM(NTERMS - 1, 0)
     }
-    LTRX_MMA_TERM(0, 1)
-    LTRX_MMA_TERM(1, 0)
+    if (NTERMS >= 2) {
+      LTRX_MMA_TERM(0, NTERMS >= 2 ? 1 : 0)
+      LTRX_MMA_TERM(NTERMS >= 2 ? 1 : 0, 0)
+    }
     LTRX_MMA_TERM(0, 0)
 #undef LTRX_MMA_TERM
   }
@@ -160,16 +162,16 @@ __global__ void __launch_bounds__(BM_ * 2) __attribute__((amdgpu_waves_per_eu(2,
       const int o = swz_off<BK_>(srow + RSTEP * p, sc4);
       split4<NTERMS>(ra[p], h, l, l2);
       *reinterpret_cast<bf16x4*>(&s.a[0][o]) = h;
-      *reinterpret_cast<bf16x4*>(&s.a[1][o]) = l;
-      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.a[2][o]) = l2;
+      if (NTERMS >= 2) *reinterpret_cast<bf16x4*>(&s.a[NTERMS >= 2 ? 1 : 0][o]) = l;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.a[NTERMS - 1][o]) = l2;
     }
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
       const int o = swz_off<BK_>(srow + RSTEP * p, sc4);
       split4<NTERMS>(rb[p], h, l, l2);
       *reinterpret_cast<bf16x4*>(&s.b[0][o]) = h;
-      *reinterpret_cast<bf16x4*>(&s.b[1][o]) = l;
-      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.b[2][o]) = l2;
+      if (NTERMS >= 2) *reinterpret_cast<bf16x4*>(&s.b[NTERMS >= 2 ? 1 : 0][o]) = l;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.b[NTERMS - 1][o]) = l2;
     }
   };
 
@@ -242,13 +244,15 @@ __device__ __forceinline__ void lds_only_barrier() {
 
 // BM = 256 (wave tile 128 x 64) or 128 (wave tile 64 x 64, 96 KB of LDS): the 128-row variant is for shapes whose 256-row
 // tiling would leave half of the CUs without a tile (M 15360 x N 512: 120 tiles of 256 x 256, 240 of 128 x 256)
-template <int BM>
+// NT = number of bf16 terms per operand: 2 = hi + lo (three products), 1 = hi only (ONE product: the plain-bf16
+// throughput mode, precision code 2 of the host wrappers -- NOT the parity arithmetic)
+template <int BM, int NT = 2>
 struct SmemNT {
-  __bf16 a[2][BM * 32];
-  __bf16 b[2][256 * 32];
+  __bf16 a[NT][BM * 32];
+  __bf16 b[NT][256 * 32];
 };
 
-template <bool TAIL, int BM>
+template <bool TAIL, int BM, int NT>
 __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                               int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
                                                               const float* __restrict__ bias, int act,
@@ -256,7 +260,8 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
                                                               ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step) {
   constexpr int BK_ = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  typedef SmemNT<BM> SmemT;
+  typedef SmemNT<BM, NT> SmemT;
+  constexpr int L1 = NT - 1;           // index of the lo image (aliases hi when there is none; never touched then)
   constexpr int RI = BM / 64;          // 32-row accumulator blocks per wave (two wave rows)
   SmemT* s = reinterpret_cast<SmemT*>(smem_raw);
   const int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -291,11 +296,11 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
       if (p < RI) {
         split4<2>(ra[p < RI ? p : 0], h, l, l2);
         *reinterpret_cast<bf16x4*>(&d.a[0][o]) = h;
-        *reinterpret_cast<bf16x4*>(&d.a[1][o]) = l;
+        if (NT == 2) *reinterpret_cast<bf16x4*>(&d.a[L1][o]) = l;
       }
       split4<2>(rb[p], h, l, l2);
       *reinterpret_cast<bf16x4*>(&d.b[0][o]) = h;
-      *reinterpret_cast<bf16x4*>(&d.b[1][o]) = l;
+      if (NT == 2) *reinterpret_cast<bf16x4*>(&d.b[L1][o]) = l;
     }
   };
   f32x16 acc[RI][2];
@@ -308,9 +313,9 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
   auto mma = [&](const SmemT& t) {
 #pragma unroll
     for (int ks = 0; ks < BK_ / 16; ++ks) {
-      bf16x8 af[2][RI], bfr[2][2];
+      bf16x8 af[NT][RI], bfr[NT][2];
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
+      for (int tt = 0; tt < NT; ++tt) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           bfr[tt][j] = *reinterpret_cast<const bf16x8*>(&t.b[tt][swz_off<BK_>(wc * 64 + j * 32 + l31, ks * 16 + 8 * half)]);
@@ -321,8 +326,10 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
 #define LTRX_MMA256(TA, TB)                                                                                       \
   _Pragma("unroll") for (int i = 0; i < RI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                    \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA][i], bfr[TB][j], acc[i][j], 0, 0, 0);
-      LTRX_MMA256(0, 1)
-      LTRX_MMA256(1, 0)
+      if (NT == 2) {
+        LTRX_MMA256(0, L1)
+        LTRX_MMA256(L1, 0)
+      }
       LTRX_MMA256(0, 0)
 #undef LTRX_MMA256
     }
@@ -462,12 +469,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))
       bf16x4 h, l, l2;
       split4<NTERMS>(make_float4(ra[p][0], ra[p][1], ra[p][2], ra[p][3]), h, l, l2);
       *reinterpret_cast<bf16x4*>(&s.a[0][o]) = h;
-      *reinterpret_cast<bf16x4*>(&s.a[1][o]) = l;
-      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.a[2][o]) = l2;
+      if (NTERMS >= 2) *reinterpret_cast<bf16x4*>(&s.a[NTERMS >= 2 ? 1 : 0][o]) = l;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.a[NTERMS - 1][o]) = l2;
       split4<NTERMS>(make_float4(rb[p][0], rb[p][1], rb[p][2], rb[p][3]), h, l, l2);
       *reinterpret_cast<bf16x4*>(&s.b[0][o]) = h;
-      *reinterpret_cast<bf16x4*>(&s.b[1][o]) = l;
-      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.b[2][o]) = l2;
+      if (NTERMS >= 2) *reinterpret_cast<bf16x4*>(&s.b[NTERMS >= 2 ? 1 : 0][o]) = l;
+      if (NTERMS == 3) *reinterpret_cast<bf16x4*>(&s.b[NTERMS - 1][o]) = l2;
     }
   };
 
@@ -524,12 +531,15 @@ __device__ __forceinline__ int swz_t(int row, int k) {
   return (row ^ ((row >> 4) & 1)) * 32 + c * 8 + (k & 7);
 }
 
+template <int NT>
 __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                               int ldb, float* __restrict__ slabs, float* __restrict__ bias_slabs,
                                                               int M, int NP, int KP, int tiles_k, int m_per_split) {
   constexpr int BK_ = 32;
+  constexpr int L1 = NT - 1;
+  typedef SmemNT<256, NT> SmemT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  SmemNT<256>* s = reinterpret_cast<SmemNT<256>*>(smem_raw);
+  SmemT* s = reinterpret_cast<SmemT*>(smem_raw);
   // Workgroup -> (split, tile) in split-major order through the XCD remap: all tiles of one m-slab run on ONE XCD, so the dY
   // slab (shared by the tiles of a tile row) and the X slab (shared by the tiles of a tile column) are fetched from HBM once
   // and served to the other tiles by that XCD's L2.  PMC at the FFN shape (profiles/r01_pmc_tn256_xcd.md): L2 hit rate
@@ -558,10 +568,10 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __res
   };
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool want_bias = bias_slabs != nullptr && (tile % tiles_k) == 0;      // column sums of A = the bias gradient
-  auto sstore1 = [&](SmemNT<256>& d, int g) {
+  auto sstore1 = [&](SmemT& d, int g) {
     {
       __bf16* img0 = g ? d.b[0] : d.a[0];
-      __bf16* img1 = g ? d.b[1] : d.a[1];
+      __bf16* img1 = g ? d.b[L1] : d.a[L1];
       const float cx[4][4] = {{r[g][0].x, r[g][1].x, r[g][2].x, r[g][3].x}, {r[g][0].y, r[g][1].y, r[g][2].y, r[g][3].y},
                               {r[g][0].z, r[g][1].z, r[g][2].z, r[g][3].z}, {r[g][0].w, r[g][1].w, r[g][2].w, r[g][3].w}};
 #pragma unroll
@@ -570,12 +580,12 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __res
         split4<2>(make_float4(cx[c][0], cx[c][1], cx[c][2], cx[c][3]), h, l, l2);
         const int o = swz_t(4 * cg + c, 4 * mg);
         *reinterpret_cast<bf16x4*>(&img0[o]) = h;
-        *reinterpret_cast<bf16x4*>(&img1[o]) = l;
+        if (NT == 2) *reinterpret_cast<bf16x4*>(&img1[o]) = l;
         if (g == 0 && want_bias) bsum[c] += (cx[c][0] + cx[c][1]) + (cx[c][2] + cx[c][3]);
       }
     }
   };
-  auto sstore = [&](SmemNT<256>& d) {
+  auto sstore = [&](SmemT& d) {
     sstore1(d, 0);
     sstore1(d, 1);
   };
@@ -586,11 +596,11 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __res
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-  auto mma1 = [&](const SmemNT<256>& t, int ks) {
+  auto mma1 = [&](const SmemT& t, int ks) {
     {
-      bf16x8 af[2][4], bfr[2][2];
+      bf16x8 af[NT][4], bfr[NT][2];
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
+      for (int tt = 0; tt < NT; ++tt) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           bfr[tt][j] = *reinterpret_cast<const bf16x8*>(&t.b[tt][swz_t(wc * 64 + j * 32 + l31, ks * 16 + 8 * half)]);
@@ -601,13 +611,15 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __res
 #define LTRX_MMA256(TA, TB)                                                                                       \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                     \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA][i], bfr[TB][j], acc[i][j], 0, 0, 0);
-      LTRX_MMA256(0, 1)
-      LTRX_MMA256(1, 0)
+      if (NT == 2) {
+        LTRX_MMA256(0, L1)
+        LTRX_MMA256(L1, 0)
+      }
       LTRX_MMA256(0, 0)
 #undef LTRX_MMA256
     }
   };
-  auto mma = [&](const SmemNT<256>& t) {
+  auto mma = [&](const SmemT& t) {
     mma1(t, 0);
     mma1(t, 1);
   };
@@ -725,6 +737,8 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
   // large-tile kernel: exact multiples only, and enough tiles to cover the 256 CUs at least ~1.4 times
   const bool vec_epi = (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
                        (!aux || ((ldaux & 3) == 0 && ((uintptr_t)aux & 15) == 0));      // 16-byte epilogue accesses
+  const bool plain = strict == 2;                     // precision code: 0 = three products, 1 = six (strict), 2 = one (plain bf16)
+  if (strict == 2) strict = 0;
   if (v == 0 && !strict && (N % 256) == 0 && (K % 32) == 0 && vec_epi) {
     // one workgroup per CU: a grid that fills 3/4 .. 1 round, or at least ~1.4 rounds (measured, tools/gemm_variants.py:
     // 240 tiles 53 vs 77 us, 360 tiles parity, 120 tiles parity, 480 tiles 102 vs 132 us)
@@ -735,10 +749,11 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
       // their own (smaller) problem: 5-25 % faster over that range (tools/gemm_split_probe.py).  Only without dropout
       // generated in the epilogue -- its hash is indexed by the row of THIS launch.
       const int m1 = (256 / (N / 256)) * 256;
-      int rc = ltrx_gemm_nt(A, lda, B, ldb, C, ldc, m1, N, K, bias, act, aux, ldaux, drop_p, drop_seed, drop_step, strict, stream);
+      const int prec = plain ? 2 : strict;
+      int rc = ltrx_gemm_nt(A, lda, B, ldb, C, ldc, m1, N, K, bias, act, aux, ldaux, drop_p, drop_seed, drop_step, prec, stream);
       if (rc != LTRX_OK) return rc;
       return ltrx_gemm_nt(A + (size_t)m1 * lda, lda, B, ldb, C + (size_t)m1 * ldc, ldc, M - m1, N, K, bias, act,
-                          aux ? aux + (size_t)m1 * ldaux : nullptr, ldaux, drop_p, drop_seed, drop_step, strict, stream);
+                          aux ? aux + (size_t)m1 * ldaux : nullptr, ldaux, drop_p, drop_seed, drop_step, prec, stream);
     }
     if (t >= 360 || (t >= 168 && t <= 256)) v = 6;
     else if (t >= 136 && t < 168 && (size_t)((M + 127) / 128) * (N / 256) > 256) v = 6;   // one partial round still beats two rounds of smaller tiles
@@ -752,34 +767,40 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
     if ((N % 256) || (K % 32) || strict || !vec_epi) return LTRX_EUNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(2 * sizeof(SmemNT<256>))) != hipSuccess ||
-          hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(2 * sizeof(SmemNT<256>))) != hipSuccess ||
-          hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<false, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(2 * sizeof(SmemNT<128>))) != hipSuccess ||
-          hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(2 * sizeof(SmemNT<128>))) != hipSuccess)
+#define LTRX_NT256_ATTR(TAIL_, BM_, NT_)                                                                                     \
+  (hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<TAIL_, BM_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                       (int)(2 * sizeof(SmemNT<BM_, NT_>))) != hipSuccess)
+      if (LTRX_NT256_ATTR(false, 256, 2) || LTRX_NT256_ATTR(true, 256, 2) || LTRX_NT256_ATTR(false, 128, 2) ||
+          LTRX_NT256_ATTR(true, 128, 2) || LTRX_NT256_ATTR(false, 256, 1) || LTRX_NT256_ATTR(true, 256, 1) ||
+          LTRX_NT256_ATTR(false, 128, 1) || LTRX_NT256_ATTR(true, 128, 1))
         return LTRX_EHIP;
+#undef LTRX_NT256_ATTR
       attr_set = true;
     }
     const int tiles_n = N / 256;
     const int bm = (v == 6) ? 256 : 128;
     const dim3 grid(((M + bm - 1) / bm) * tiles_n);
-#define LTRX_NT256(TAIL_, BM_)                                                                                              \
-  hipLaunchKernelGGL((ltrx_gemm_nt256_kernel<TAIL_, BM_>), grid, dim3(512), 2 * sizeof(SmemNT<BM_>), s, A, lda, B, ldb, C, ldc, M, \
-                     N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step)
+#define LTRX_NT256_(TAIL_, BM_, NT_)                                                                                         \
+  hipLaunchKernelGGL((ltrx_gemm_nt256_kernel<TAIL_, BM_, NT_>), grid, dim3(512), 2 * sizeof(SmemNT<BM_, NT_>), s, A, lda, B, ldb, C, \
+                     ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step)
+#define LTRX_NT256(TAIL_, BM_)                                                                                               \
+  do {                                                                                                                       \
+    if (plain) LTRX_NT256_(TAIL_, BM_, 1); else LTRX_NT256_(TAIL_, BM_, 2);                                                  \
+  } while (0)
     if (v == 6) {
       if (M % 256) LTRX_NT256(true, 256); else LTRX_NT256(false, 256);
     } else {
       if (M % 128) LTRX_NT256(true, 128); else LTRX_NT256(false, 128);
     }
+#undef LTRX_NT256_
 #undef LTRX_NT256
     LTRX_LAUNCH_CHECK();
     return LTRX_OK;
   }
   if (strict) {
     launch_nt<3, 128, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, drop, drop_step, s);
+  } else if (plain) {
+    launch_nt<1, 128, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, drop, drop_step, s);
   } else {
     switch (v) {
       case 2: launch_nt<2, 128, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, drop, drop_step, s); break;
@@ -844,20 +865,28 @@ extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, fl
                             int KP, int strict, void* ws, ltrx_stream_t stream) {
   if (!A || !B || !C || !ws || M <= 0 || NP <= 0 || KP <= 0) return LTRX_EINVAL;
   if (lda < NP || ldb < KP) return LTRX_EUNSUPPORTED;
+  const bool plain = strict == 2;                     // precision code as in ltrx_gemm_nt
+  if (strict == 2) strict = 0;
   if (!strict && g_nt_variant != 1 && tn256_ok(M, NP, KP) && (lda & 3) == 0 && (ldb & 3) == 0) {
     hipStream_t s = (hipStream_t)stream;
     int splits, mps;
     tn256_plan(M, NP, KP, &splits, &mps);
     static bool attr_set = false;
     if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)ltrx_gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(2 * sizeof(SmemNT<256>))) != hipSuccess)
+      if (hipFuncSetAttribute((const void*)ltrx_gemm_tn256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(2 * sizeof(SmemNT<256, 2>))) != hipSuccess ||
+          hipFuncSetAttribute((const void*)ltrx_gemm_tn256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(2 * sizeof(SmemNT<256, 1>))) != hipSuccess)
         return LTRX_EHIP;
       attr_set = true;
     }
     float* bslabs = bias_out ? (float*)ws + (size_t)splits * NP * KP : nullptr;
-    hipLaunchKernelGGL(ltrx_gemm_tn256_kernel, dim3((NP / 256) * (KP / 256), splits), dim3(512), 2 * sizeof(SmemNT<256>), s, A, lda, B,
-                       ldb, (float*)ws, bslabs, M, NP, KP, KP / 256, mps);
+    if (plain)
+      hipLaunchKernelGGL(ltrx_gemm_tn256_kernel<1>, dim3((NP / 256) * (KP / 256), splits), dim3(512), 2 * sizeof(SmemNT<256, 1>), s, A,
+                         lda, B, ldb, (float*)ws, bslabs, M, NP, KP, KP / 256, mps);
+    else
+      hipLaunchKernelGGL(ltrx_gemm_tn256_kernel<2>, dim3((NP / 256) * (KP / 256), splits), dim3(512), 2 * sizeof(SmemNT<256, 2>), s, A,
+                         lda, B, ldb, (float*)ws, bslabs, M, NP, KP, KP / 256, mps);
     LTRX_LAUNCH_CHECK();
     launch_slab_reduce((const float*)ws, splits, (size_t)NP * KP, C, bslabs, splits, (size_t)NP, bias_out, s);
     LTRX_LAUNCH_CHECK();
@@ -873,6 +902,8 @@ extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, fl
   float* bslabs = bias_out ? (float*)ws + (size_t)splits * NP * KP : nullptr;
   if (strict)
     hipLaunchKernelGGL(ltrx_gemm_tn_kernel<3>, grid, dim3(256), 0, s, A, lda, B, ldb, (float*)ws, bslabs, M, NP, KP, tiles_k, mps);
+  else if (plain)
+    hipLaunchKernelGGL(ltrx_gemm_tn_kernel<1>, grid, dim3(256), 0, s, A, lda, B, ldb, (float*)ws, bslabs, M, NP, KP, tiles_k, mps);
   else
     hipLaunchKernelGGL(ltrx_gemm_tn_kernel<2>, grid, dim3(256), 0, s, A, lda, B, ldb, (float*)ws, bslabs, M, NP, KP, tiles_k, mps);
   LTRX_LAUNCH_CHECK();

@@ -514,17 +514,19 @@ extern "C" int ltrx_selftest_mfma32x32x2(const float* A, const float* Bm, float*
 //           shape fits (slate length <= 256, 32 < d_k <= 64); fp32-class (three bf16 products per fp32 product, like the dense
 //           projections).  Other shapes run the exact kernels of this file.
 //   mode 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-exact fp32 products) for every shape -- the strict reference.
+//   mode 2: the kernels of mode 1 with ONE bf16 product per contraction (plain bf16 operands, fp32 accumulate and softmax):
+//           the throughput mode, about 2^-9 relative error per product -- NOT the parity arithmetic.
 static int g_mha_mode = 1;
-extern "C" void ltrx_mha_set_mode(int mode) { g_mha_mode = mode ? 1 : 0; }
+extern "C" void ltrx_mha_set_mode(int mode) { g_mha_mode = (mode == 2) ? 2 : (mode ? 1 : 0); }
 extern "C" int ltrx_mha_get_mode(void) { return g_mha_mode; }
 bool ltrx_mha_res_fits(int L, int dk);
 int ltrx_mha_fwd_res_launch(const float* q, const float* k, const float* v, const uint8_t* kpm, int B, int L, int h, int dk, int rs,
                             float* o, int ors, float* lse, float p_drop, uint32_t seed, const uint32_t* seed_step, const int* cu,
-                            const int* order, hipStream_t s);
+                            const int* order, bool plain, hipStream_t s);
 int ltrx_mha_bwd_res_launch(const float* q, const float* k, const float* v, const uint8_t* kpm, const float* o, const float* dout,
                             const float* lse, int B, int L, int h, int dk, int rs, int ors, float* dq, float* dkk, float* dv, int drs,
                             float* delta, float p_drop, uint32_t seed, const uint32_t* seed_step, const int* cu, const int* order,
-                            hipStream_t s);
+                            bool plain, hipStream_t s);
 
 static int mha_check(int B, int L, int h, int dk, int rs, int ors) {
   if (B <= 0 || L <= 0 || h <= 0 || dk <= 0) return LTRX_EINVAL;
@@ -551,9 +553,9 @@ extern "C" int ltrx_mha_fwd(const float* q, const float* k, const float* v, cons
   int rc = mha_check(B, L, h, d_k, row_stride, o_row_stride);
   if (rc != LTRX_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (g_mha_mode == 1 && ltrx_mha_res_fits(L, d_k))
+  if (g_mha_mode != 0 && ltrx_mha_res_fits(L, d_k))
     return ltrx_mha_fwd_res_launch(q, k, v, key_pad_mask, B, L, h, d_k, row_stride, o, o_row_stride, lse_out, p_drop, seed, seed_step,
-                                   cu_seqlens, slate_order, s);
+                                   cu_seqlens, slate_order, g_mha_mode == 2, s);
   const DropCfg drop = make_drop(p_drop, seed);
   const dim3 grid(B * h, (L + 127) / 128);
   const float scale = 1.0f / sqrtf((float)d_k);
@@ -587,9 +589,9 @@ extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, cons
   if (d_row_stride % 4 != 0 || d_row_stride < h * d_k) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* delta = (float*)ws;
-  if (g_mha_mode == 1 && ltrx_mha_res_fits(L, d_k))
+  if (g_mha_mode != 0 && ltrx_mha_res_fits(L, d_k))
     return ltrx_mha_bwd_res_launch(q, k, v, key_pad_mask, o, dout, lse, B, L, h, d_k, row_stride, o_row_stride, dq, dk, dv, d_row_stride,
-                                   delta, p_drop, seed, seed_step, cu_seqlens, slate_order, s);
+                                   delta, p_drop, seed, seed_step, cu_seqlens, slate_order, g_mha_mode == 2, s);
   const DropCfg drop = make_drop(p_drop, seed);
   const dim3 grid(B * h, (L + 127) / 128);
   const float scale = 1.0f / sqrtf((float)d_k);

@@ -78,6 +78,8 @@ __device__ __forceinline__ void tile_gload(TileRegs& r, const float* __restrict_
   if (row < nrows && c < dk) r.a = *reinterpret_cast<const float4*>(base + (size_t)row * rs + c);
   if (row < nrows && c + 4 < dk) r.b = *reinterpret_cast<const float4*>(base + (size_t)row * rs + c + 4);
 }
+// PL ("plain"): the one-product bf16 throughput mode (ltrx_mha_set_mode(2)): no lo planes, no lo products -- NOT parity arithmetic
+template <bool PL>
 __device__ __forceinline__ void tile_sstore(unsigned char* img, int tile, const TileRegs& r) {
   const int idx = threadIdx.x & 255;
   const int row = (tile & 7) * 32 + (idx >> 3), chunk = idx & 7;      // ring slot of the tile
@@ -90,7 +92,7 @@ __device__ __forceinline__ void tile_sstore(unsigned char* img, int tile, const 
   }
   const int o = img_off(row, chunk);
   *reinterpret_cast<bf16x8*>(img + o) = h;
-  *reinterpret_cast<bf16x8*>(img + PLANE + o) = l;
+  if (!PL) *reinterpret_cast<bf16x8*>(img + PLANE + o) = l;
 }
 
 // the wave's fixed operand FIXED[row0 + l31][16 ks + 8 half + (0..7)], pre-split (registers)
@@ -120,7 +122,7 @@ __device__ __forceinline__ void load_fixed(bf16x8 (&fh)[4], bf16x8 (&fl)[4], con
 
 // acc[r] = sum_c IMG[tile_row0 + rowmap(r, half)][c] * FIXED[l31][c].  NACC accumulators (4: one per 16-deep k-step, term-major
 // order, consecutive MFMAs never write the same accumulator; 2: 32 fewer live registers for the kernels at the VGPR limit)
-template <int NACC>
+template <int NACC, bool PL>
 __device__ __forceinline__ f32x16 rows_x_fixed(const unsigned char* img, int tile_row0, const bf16x8 (&fh)[4], const bf16x8 (&fl)[4]) {
   const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   f32x16 a[NACC];
@@ -129,17 +131,19 @@ __device__ __forceinline__ f32x16 rows_x_fixed(const unsigned char* img, int til
   for (int ks = 0; ks < 4; ++ks) {
     const int o = img_off(tile_row0 + l31, 2 * ks + half);
     xh[ks] = *reinterpret_cast<const bf16x8*>(img + o);
-    xl[ks] = *reinterpret_cast<const bf16x8*>(img + PLANE + o);
+    if (!PL) xl[ks] = *reinterpret_cast<const bf16x8*>(img + PLANE + o);
   }
 #pragma unroll
   for (int n = 0; n < NACC; ++n)
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[n][r] = 0.f;
   if (LTRX_MHA_SETPRIO) __builtin_amdgcn_s_setprio(1);
+  if (!PL) {
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) a[ks % NACC] = LTRX_MFMA(xl[ks], fh[ks], a[ks % NACC]);
+    for (int ks = 0; ks < 4; ++ks) a[ks % NACC] = LTRX_MFMA(xl[ks], fh[ks], a[ks % NACC]);
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) a[ks % NACC] = LTRX_MFMA(xh[ks], fl[ks], a[ks % NACC]);
+    for (int ks = 0; ks < 4; ++ks) a[ks % NACC] = LTRX_MFMA(xh[ks], fl[ks], a[ks % NACC]);
+  }
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) a[ks % NACC] = LTRX_MFMA(xh[ks], fh[ks], a[ks % NACC]);
   if (LTRX_MHA_SETPRIO) __builtin_amdgcn_s_setprio(0);
@@ -149,18 +153,15 @@ __device__ __forceinline__ f32x16 rows_x_fixed(const unsigned char* img, int til
 
 // out[ct][r'] += sum_row IMG[tile_row0 + row][32 ct + l31] * p[row]    (p in D layout: register r <-> tile row rowmap(r, half))
 // The A fragment (column 32 ct + l31, rows {16u + 4 half + 0..3, 16u + 8 + 4 half + 0..3}) comes from two transposed reads.
-__device__ __forceinline__ void cols_x_p(const unsigned char* img, int tile_row0, const f32x16& p, f32x16 (&out)[2]) {
+// (read_cols / mma_cols are separate so that a kernel can place the 16 reads ahead of the arithmetic that produces p; measured on
+// MI355X, round 2: issuing them before the softmax / dS arithmetic, or fencing reads from MFMAs, changes nothing -- +-1 %,
+// gpurun_out/mha_ab.txt -- the second wave of each SIMD already covers that latency.)
+struct ColFrags {
+  bf16x8 h[2][2], l[2][2];          // [u][ct]
+};
+template <bool PL>
+__device__ __forceinline__ void read_cols(const unsigned char* img, int tile_row0, ColFrags& f) {
   const int lane = threadIdx.x & 63, half = lane >> 5, i16 = lane & 15, g16 = (lane >> 4) & 1;
-  bf16x8 ph[2], pl[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float x = p[8 * u + e];
-      const __bf16 h = (__bf16)x;
-      ph[u][e] = h;
-      pl[u][e] = (__bf16)(x - (float)h);
-    }
   // lane i16 of a 16-lane group supplies the address of row (i16 >> 2), columns 4 (i16 & 3) .. +3 of the [4][16] block
   const int rsub = i16 >> 2, c8 = (i16 & 3) >> 1, b8 = (i16 & 1) * 8;
 #pragma unroll
@@ -172,15 +173,46 @@ __device__ __forceinline__ void cols_x_p(const unsigned char* img, int tile_row0
       const int o0 = img_off(r0, chunk) + b8, o1 = img_off(r0 + 8, chunk) + b8;
       const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + o0));
       const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + o1));
-      const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + PLANE + o0));
-      const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + PLANE + o1));
-      const bf16x8 xh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-      const bf16x8 xl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-      out[ct] = LTRX_MFMA(xl, ph[u], out[ct]);
-      out[ct] = LTRX_MFMA(xh, pl[u], out[ct]);
-      out[ct] = LTRX_MFMA(xh, ph[u], out[ct]);
+      f.h[u][ct] = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      if (!PL) {
+        const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + PLANE + o0));
+        const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + PLANE + o1));
+        f.l[u][ct] = bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+      }
     }
   }
+}
+template <bool PL>
+__device__ __forceinline__ void mma_cols(const ColFrags& f, const f32x16& p, f32x16 (&out)[2]) {
+  bf16x8 ph[2], pl[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = p[8 * u + e];
+      const __bf16 h = (__bf16)x;
+      ph[u][e] = h;
+      pl[u][e] = (__bf16)(x - (float)h);
+    }
+  if (LTRX_MHA_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (!PL) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) out[ct] = LTRX_MFMA(f.l[u][ct], ph[u], out[ct]);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) out[ct] = LTRX_MFMA(f.h[u][ct], pl[u], out[ct]);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) out[ct] = LTRX_MFMA(f.h[u][ct], ph[u], out[ct]);
+  }
+  if (LTRX_MHA_SETPRIO) __builtin_amdgcn_s_setprio(0);
+}
+template <bool PL>
+__device__ __forceinline__ void cols_x_p(const unsigned char* img, int tile_row0, const f32x16& p, f32x16 (&out)[2]) {
+  ColFrags f;
+  read_cols<PL>(img, tile_row0, f);
+  mma_cols<PL>(f, p, out);
 }
 
 // lane owns output row row0 + l31; register 4g + e of out[ct] is column 32 ct + 8 g + 4 half + e
@@ -228,7 +260,7 @@ __device__ __forceinline__ Slate which_slate(int L, int h, const int* __restrict
 // ------------------------------------------------------------------------------------------------------------------
 // forward: wave w owns queries 32 w .. 32 w + 31 of the slate
 // ------------------------------------------------------------------------------------------------------------------
-template <bool DROP>
+template <bool DROP, bool PL>
 __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ v, const uint8_t* __restrict__ kpm, int L,
                                                                int h, int dk, int rs, float* __restrict__ o, int ors,
@@ -260,7 +292,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
   const float sl2 = scale * kLog2e;
   const int nkt = (len + 31) / 32;
   for (int kt = 0; kt < nkt; ++kt) {
-    tile_sstore(dst, kt, tr);
+    tile_sstore<PL>(dst, kt, tr);
     if (threadIdx.x < 32) {
       const int key = kt * 32 + threadIdx.x;
       kbias[(kt & 7) * 32 + threadIdx.x] = (key >= len || (kpm && kpm[sl.row0 + key])) ? -INFINITY : 0.f;
@@ -269,7 +301,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
     __syncthreads();
     if (!active) continue;
     const int slot = (kt & 7) * 32;                            // ring slot (rows of the LDS images) of this tile
-    f32x16 s = rows_x_fixed<4>(kimg, slot, qh, ql);            // S^T[key = rowmap(r, half)][query = l31]
+    f32x16 s = rows_x_fixed<4, PL>(kimg, slot, qh, ql);            // S^T[key = rowmap(r, half)][query = l31]
     float mt = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -296,7 +328,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[ct][r] *= alpha;
-    cols_x_p(vimg, slot, p, oacc);                               // O^T[d][query] += V^T[d][key] P^T[key][query]
+    cols_x_p<PL>(vimg, slot, p, oacc);                                     // O^T[d][query] += V^T[d][key] P^T[key][query]
     m = mn;
   }
   if (!active) return;
@@ -310,7 +342,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
 // ------------------------------------------------------------------------------------------------------------------
 // backward dQ (+ delta): K and V resident; wave owns 32 queries (Q and dO fragments in registers)
 // ------------------------------------------------------------------------------------------------------------------
-template <bool DROP>
+template <bool DROP, bool PL>
 __global__ void __launch_bounds__(512) ltrx_mha_bwd_dq_res_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const uint8_t* __restrict__ kpm,
     const float* __restrict__ o, const float* __restrict__ dout, const float* __restrict__ lse, float* __restrict__ delta, int L, int h,
@@ -358,7 +390,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dq_res_kernel(
   zero2(dqacc);
   const int nkt = (len + 31) / 32;
   for (int kt = 0; kt < nkt; ++kt) {
-    tile_sstore(dst, kt, tr);
+    tile_sstore<PL>(dst, kt, tr);
     if (threadIdx.x < 32) {
       const int key = kt * 32 + threadIdx.x;
       kbias[(kt & 7) * 32 + threadIdx.x] = (key >= len || (kpm && kpm[sl.row0 + key])) ? -INFINITY : 0.f;
@@ -367,8 +399,8 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dq_res_kernel(
     __syncthreads();
     if (!active) continue;
     const int slot = (kt & 7) * 32;
-    const f32x16 s = rows_x_fixed<2>(kimg, slot, qh, ql);       // S^T[key][query]
-    const f32x16 dp = rows_x_fixed<2>(vimg, slot, doh, dol);    // dP^T[key][query] = V dO^T
+    const f32x16 s = rows_x_fixed<2, PL>(kimg, slot, qh, ql);       // S^T[key][query]
+    const f32x16 dp = rows_x_fixed<2, PL>(vimg, slot, doh, dol);    // dP^T[key][query] = V dO^T
     f32x16 ds;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -377,7 +409,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dq_res_kernel(
       const float dm = DROP ? drop_scale_rk(drop, drow, key) : 1.0f;
       ds[r] = p * (dp[r] * dm - del_q) * scale;
     }
-    cols_x_p(kimg, slot, ds, dqacc);                             // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+    cols_x_p<PL>(kimg, slot, ds, dqacc);                                   // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
   }
   if (!active) return;
   store_rows(dq + sl.row0 * drs + (size_t)sl.head * dk, q0, len, dk, drs, dqacc, 1.0f);
@@ -386,7 +418,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dq_res_kernel(
 // ------------------------------------------------------------------------------------------------------------------
 // backward dK, dV: Q and dO resident; wave owns 32 keys (K and V fragments in registers)
 // ------------------------------------------------------------------------------------------------------------------
-template <bool DROP>
+template <bool DROP, bool PL>
 __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const uint8_t* __restrict__ kpm,
     const float* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta, int L, int h, int dk, int rs,
@@ -424,7 +456,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
   zero2(dvacc);
   const int nqt = (len + 31) / 32;
   for (int qt = 0; qt < nqt; ++qt) {
-    tile_sstore(dst, qt, tr);
+    tile_sstore<PL>(dst, qt, tr);
     if (threadIdx.x < 32) {                                      // per-query statistics of this tile (ring slot)
       const int qr = qt * 32 + threadIdx.x, sl_ = (qt & 7) * 32 + threadIdx.x;
       lse_t[sl_] = (qr < len) ? lse[statb + qr] * kLog2e : INFINITY;       // +inf -> P = exp2(-inf) = 0 for rows >= len
@@ -437,8 +469,8 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
     const int slot = (qt & 7) * 32;
     // (order chosen for register pressure: both 16-register products first, then the two accumulations; the fences keep the
     //  scheduler from hoisting the second accumulation's transposed reads above the first)
-    f32x16 p = rows_x_fixed<2>(qimg, slot, kh, kl);               // S[query = rowmap(r, half)][key = l31]
-    f32x16 ds = rows_x_fixed<2>(doimg, slot, vh, vl);            // dP[query][key] = dO V^T
+    f32x16 p = rows_x_fixed<2, PL>(qimg, slot, kh, kl);               // S[query = rowmap(r, half)][key = l31]
+    f32x16 ds = rows_x_fixed<2, PL>(doimg, slot, vh, vl);            // dP[query][key] = dO V^T
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qr = slot + rowmap(r, half);
@@ -448,9 +480,9 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
       p[r] = pr * dm;                                            // P M
     }
     __builtin_amdgcn_sched_barrier(0);
-    cols_x_p(doimg, slot, p, dvacc);                             // dV^T[d][key] += dO^T[d][query] (P M)[query][key]
+    cols_x_p<PL>(doimg, slot, p, dvacc);                             // dV^T[d][key] += dO^T[d][query] (P M)[query][key]
     __builtin_amdgcn_sched_barrier(0);
-    cols_x_p(qimg, slot, ds, dkacc);                             // dK^T[d][key] += Q^T[d][query] dS[query][key]
+    cols_x_p<PL>(qimg, slot, ds, dkacc);                             // dK^T[d][key] += Q^T[d][query] dS[query][key]
     __builtin_amdgcn_sched_barrier(0);
   }
   if (!active) return;
@@ -472,21 +504,26 @@ static int res_attr(K kernel) {
 
 int ltrx_mha_fwd_res_launch(const float* q, const float* k, const float* v, const uint8_t* kpm, int B, int L, int h, int dk, int rs,
                             float* o, int ors, float* lse, float p_drop, uint32_t seed, const uint32_t* seed_step, const int* cu,
-                            const int* order, hipStream_t s) {
+                            const int* order, bool plain, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    if (res_attr(ltrx_mha_fwd_res_kernel<false>) != LTRX_OK || res_attr(ltrx_mha_fwd_res_kernel<true>) != LTRX_OK) return LTRX_EHIP;
+    if (res_attr(ltrx_mha_fwd_res_kernel<false, false>) != LTRX_OK || res_attr(ltrx_mha_fwd_res_kernel<true, false>) != LTRX_OK ||
+        res_attr(ltrx_mha_fwd_res_kernel<false, true>) != LTRX_OK || res_attr(ltrx_mha_fwd_res_kernel<true, true>) != LTRX_OK)
+      return LTRX_EHIP;
     attr = true;
   }
   const DropCfg drop = ltrx_make_drop(p_drop, seed);
   const float scale = 1.0f / sqrtf((float)dk);
   const dim3 grid(B * h, (L + RMAX - 1) / RMAX);
-  if (drop.thresh != 0u)
-    hipLaunchKernelGGL(ltrx_mha_fwd_res_kernel<true>, grid, dim3(512), RES_SMEM, s, q, k, v, kpm, L, h, dk, rs, o, ors, lse, scale, drop,
-                       seed_step, cu, order);
-  else
-    hipLaunchKernelGGL(ltrx_mha_fwd_res_kernel<false>, grid, dim3(512), RES_SMEM, s, q, k, v, kpm, L, h, dk, rs, o, ors, lse, scale, drop,
-                       seed_step, cu, order);
+#define LTRX_FWD(D_, P_)                                                                                                          \
+  hipLaunchKernelGGL((ltrx_mha_fwd_res_kernel<D_, P_>), grid, dim3(512), RES_SMEM, s, q, k, v, kpm, L, h, dk, rs, o, ors, lse, scale, \
+                     drop, seed_step, cu, order)
+  if (drop.thresh != 0u) {
+    if (plain) LTRX_FWD(true, true); else LTRX_FWD(true, false);
+  } else {
+    if (plain) LTRX_FWD(false, true); else LTRX_FWD(false, false);
+  }
+#undef LTRX_FWD
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }
@@ -494,30 +531,38 @@ int ltrx_mha_fwd_res_launch(const float* q, const float* k, const float* v, cons
 int ltrx_mha_bwd_res_launch(const float* q, const float* k, const float* v, const uint8_t* kpm, const float* o, const float* dout,
                             const float* lse, int B, int L, int h, int dk, int rs, int ors, float* dq, float* dkk, float* dv, int drs,
                             float* delta, float p_drop, uint32_t seed, const uint32_t* seed_step, const int* cu, const int* order,
-                            hipStream_t s) {
+                            bool plain, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    if (res_attr(ltrx_mha_bwd_dq_res_kernel<false>) != LTRX_OK || res_attr(ltrx_mha_bwd_dq_res_kernel<true>) != LTRX_OK ||
-        res_attr(ltrx_mha_bwd_dkdv_res_kernel<false>) != LTRX_OK || res_attr(ltrx_mha_bwd_dkdv_res_kernel<true>) != LTRX_OK)
+    if (res_attr(ltrx_mha_bwd_dq_res_kernel<false, false>) != LTRX_OK || res_attr(ltrx_mha_bwd_dq_res_kernel<true, false>) != LTRX_OK ||
+        res_attr(ltrx_mha_bwd_dkdv_res_kernel<false, false>) != LTRX_OK || res_attr(ltrx_mha_bwd_dkdv_res_kernel<true, false>) != LTRX_OK ||
+        res_attr(ltrx_mha_bwd_dq_res_kernel<false, true>) != LTRX_OK || res_attr(ltrx_mha_bwd_dq_res_kernel<true, true>) != LTRX_OK ||
+        res_attr(ltrx_mha_bwd_dkdv_res_kernel<false, true>) != LTRX_OK || res_attr(ltrx_mha_bwd_dkdv_res_kernel<true, true>) != LTRX_OK)
       return LTRX_EHIP;
     attr = true;
   }
   const DropCfg drop = ltrx_make_drop(p_drop, seed);
   const float scale = 1.0f / sqrtf((float)dk);
   const dim3 grid(B * h, (L + RMAX - 1) / RMAX);
-  if (drop.thresh != 0u)
-    hipLaunchKernelGGL(ltrx_mha_bwd_dq_res_kernel<true>, grid, dim3(512), RES_SMEM, s, q, k, v, kpm, o, dout, lse, delta, L, h, dk, rs, ors,
-                       dq, drs, scale, drop, seed_step, cu, order);
-  else
-    hipLaunchKernelGGL(ltrx_mha_bwd_dq_res_kernel<false>, grid, dim3(512), RES_SMEM, s, q, k, v, kpm, o, dout, lse, delta, L, h, dk, rs, ors,
-                       dq, drs, scale, drop, seed_step, cu, order);
+#define LTRX_DQ(D_, P_)                                                                                                            \
+  hipLaunchKernelGGL((ltrx_mha_bwd_dq_res_kernel<D_, P_>), grid, dim3(512), RES_SMEM, s, q, k, v, kpm, o, dout, lse, delta, L, h, dk, rs, \
+                     ors, dq, drs, scale, drop, seed_step, cu, order)
+#define LTRX_DKDV(D_, P_)                                                                                                          \
+  hipLaunchKernelGGL((ltrx_mha_bwd_dkdv_res_kernel<D_, P_>), grid, dim3(512), RES_SMEM, s, q, k, v, kpm, dout, lse, delta, L, h, dk, rs,  \
+                     ors, dkk, dv, drs, scale, drop, seed_step, cu, order)
+  if (drop.thresh != 0u) {
+    if (plain) LTRX_DQ(true, true); else LTRX_DQ(true, false);
+  } else {
+    if (plain) LTRX_DQ(false, true); else LTRX_DQ(false, false);
+  }
   LTRX_LAUNCH_CHECK();
-  if (drop.thresh != 0u)
-    hipLaunchKernelGGL(ltrx_mha_bwd_dkdv_res_kernel<true>, grid, dim3(512), RES_SMEM, s, q, k, v, kpm, dout, lse, delta, L, h, dk, rs, ors,
-                       dkk, dv, drs, scale, drop, seed_step, cu, order);
-  else
-    hipLaunchKernelGGL(ltrx_mha_bwd_dkdv_res_kernel<false>, grid, dim3(512), RES_SMEM, s, q, k, v, kpm, dout, lse, delta, L, h, dk, rs, ors,
-                       dkk, dv, drs, scale, drop, seed_step, cu, order);
+  if (drop.thresh != 0u) {
+    if (plain) LTRX_DKDV(true, true); else LTRX_DKDV(true, false);
+  } else {
+    if (plain) LTRX_DKDV(false, true); else LTRX_DKDV(false, false);
+  }
+#undef LTRX_DQ
+#undef LTRX_DKDV
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }

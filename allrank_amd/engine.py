@@ -81,7 +81,10 @@ class FusedTrainer(object):
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
                  use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None, compact=False):
         """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
-        products), or "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs).  dropout=False trains with every
+        products), "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs), or "bf16" -- the THROUGHPUT mode: one bf16
+        product per contraction in the dense projections AND in attention (fp32 storage, accumulation, LayerNorm, softmax,
+        loss and Adam; about 2^-9 relative error per product, outside the 1e-5 parity contract -- bench.py reports it
+        on its own line with its measured loss error).  dropout=False trains with every
         nn.Dropout of the model disabled; seed keys the dropout masks (default: drawn from torch's global generator);
         gradient_clipping_norm: clip_grad_norm_ of train_utils.py:24-25 (the coefficient stays on the device).
         compact=True: variable-length execution -- the valid items of each padded batch (dataset.py:28-38) are packed into
@@ -95,9 +98,10 @@ class FusedTrainer(object):
         from .model import FCModel, Encoder, LTRModel, LearnedPositionalEncoding
         self.LB = LB
         self.lib = LB.lib()
-        if gemm not in ("split_bf16", "split_bf16_strict", "hipblaslt"):
-            raise ValueError("gemm must be split_bf16, split_bf16_strict or hipblaslt")
+        if gemm not in ("split_bf16", "split_bf16_strict", "hipblaslt", "bf16"):
+            raise ValueError("gemm must be split_bf16, split_bf16_strict, hipblaslt or bf16")
         self.gemm = gemm
+        self._prec = {"split_bf16_strict": 1, "bf16": 2}.get(gemm, 0)        # precision code of ltrx_gemm_nt / ltrx_gemm_tn
         self._wT = {}
         self.model = model
         self.B, self.L, self.M = B, L, B * L
@@ -431,7 +435,7 @@ class FusedTrainer(object):
         P = self.LB.ptr
         self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), P(out), out.stride(0), self.rows, w.shape[0],
                                             x.shape[1], P(b), act, None, 0, float(p), seed, P(self.drop_step),
-                                            1 if self.gemm == "split_bf16_strict" else 0, self._st()), "gemm_nt(fwd)")
+                                            self._prec, self._st()), "gemm_nt(fwd)")
 
     def _lin_dgrad(self, dy, w, wT, out, relu_of=None, p=0.0, seed=0):
         """out = dy w   (input gradient of nn.Linear); wT = w^T contiguous.  With ``relu_of`` (the saved post-ReLU,
@@ -448,7 +452,7 @@ class FusedTrainer(object):
         self.LB.check(self.lib.ltrx_gemm_nt(P(dy), dy.stride(0), P(wT), wT.stride(0), P(out), out.stride(0), self.rows,
                                             wT.shape[0], dy.shape[1], None, 2 if relu_of is not None else 0, P(relu_of),
                                             relu_of.stride(0) if relu_of is not None else 0, float(p), seed, P(self.drop_step),
-                                            1 if self.gemm == "split_bf16_strict" else 0, self._st()), "gemm_nt(dgrad)")
+                                            self._prec, self._st()), "gemm_nt(dgrad)")
 
     def _lin_wgrad(self, dy, x, gw, gb):
         """gw = dy^T x, gb = column sums of dy   (weight and bias gradients of nn.Linear)"""
@@ -458,7 +462,7 @@ class FusedTrainer(object):
             return
         P = self.LB.ptr
         self.LB.check(self.lib.ltrx_gemm_tn(P(dy), dy.stride(0), P(x), x.stride(0), P(gw), P(gb), self.rows, dy.shape[1],
-                                            x.shape[1], 1 if self.gemm == "split_bf16_strict" else 0, P(self.ws_tn), self._st()),
+                                            x.shape[1], self._prec, P(self.ws_tn), self._st()),
                       "gemm_tn(wgrad)")
 
     # ---- the step body (capturable) ----------------------------------------------------------------------------
@@ -637,7 +641,15 @@ class FusedTrainer(object):
 
     def _full(self):
         self.LB.check(self.lib.ltrx_bump_u32(self.LB.ptr(self.drop_step), self._st()), "bump_u32")   # fresh masks every step
-        loss = self._body()
+        if self.gemm == "bf16":          # the attention arithmetic is a library-wide switch: one-product kernels for this step only
+            prev = self.lib.ltrx_mha_get_mode()
+            self.lib.ltrx_mha_set_mode(2)
+            try:
+                loss = self._body()
+            finally:
+                self.lib.ltrx_mha_set_mode(prev)
+        else:
+            loss = self._body()
         for w_ in self._works:                                   # bucketed gradient all-reduces launched during the backward
             w_.wait()
         self._works = []

@@ -255,7 +255,7 @@ def gemm_error_vs_fp64(w, B, L, device, gemm):
         torch.addmm(b_, A_, W_.t(), out=C_)
     else:
         LB.check(lib.ltrx_gemm_nt(LB.ptr(A_), Kk, LB.ptr(W_), Kk, LB.ptr(C_), Nn, Mrows, Nn, Kk, LB.ptr(b_), 0, None, 0, 0.0, 0, None,
-                                  1 if gemm == "split_bf16_strict" else 0, LB.stream_of(A_)), "gemm_nt")
+                                  {"split_bf16_strict": 1, "bf16": 2}.get(gemm, 0), LB.stream_of(A_)), "gemm_nt")
     rows = torch.linspace(0, Mrows - 1, min(4096, Mrows), device=device).long()
     ref = A_[rows].double() @ W_.double().t() + b_.double()
     scale = (A_[rows].abs().double() @ W_.abs().double().t()).max()
@@ -278,8 +278,9 @@ def main():
     ap.add_argument("--no-side-pass", action="store_true", help="profiling runs: skip the 64-slate side measurement")
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="transformer dropout (the shipped reference configs train with 0.1-0.4); masks are generated in-kernel")
-    ap.add_argument("--gemm", default="split_bf16", choices=["split_bf16", "split_bf16_strict", "hipblaslt"],
-                    help="dense projections: libltrx fp32-accurate split-bf16 MFMA GEMMs (default) or hipBLASLt fp32")
+    ap.add_argument("--gemm", default="split_bf16", choices=["split_bf16", "split_bf16_strict", "hipblaslt", "bf16"],
+                    help="dense projections: libltrx fp32-accurate split-bf16 MFMA GEMMs (default), hipBLASLt fp32, or bf16 = the "
+                         "one-product throughput mode (GEMMs and attention; outside the 1e-5 parity contract)")
     ap.add_argument("--engine", default="fused", choices=["fused", "autograd"],
                     help="fused: explicit hipGraph-captured step (engine.FusedTrainer); autograd: nn.Module + torch autograd/Adam")
     args = ap.parse_args()
@@ -426,11 +427,12 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("f32 (split-bf16x3 GEMMs)" if (args.engine == "fused" and args.gemm == "split_bf16") else
-                      "f32 (split-bf16x6 GEMMs)" if (args.engine == "fused" and args.gemm == "split_bf16_strict") else "f32"),
+                      "f32 (split-bf16x6 GEMMs)" if (args.engine == "fused" and args.gemm == "split_bf16_strict") else
+                      "bf16 products, f32 storage/accumulate (throughput mode, NOT parity-grade)" if (args.engine == "fused" and args.gemm == "bf16") else "f32"),
             "data": "synthetic",
             "config": {"workload": w["desc"], "slates_per_gpu": B, "slate_len": L, "global_batch": B * world,
                        "optimizer": "Adam lr=1e-3", "dropout": args.dropout, "slates": ("ragged (lognormal lengths)" + (", compact execution" if args.compact else "") if args.ragged else "dense"),
-                       "arithmetic": ("fp32 storage and accumulation; dense projections as fp32-accurate split-bf16 (3 bf16 MFMA products per fp32 product); attention on the exact fp32 MFMA" if (args.engine == "fused" and args.gemm != "hipblaslt") else "fp32 (hipBLASLt GEMMs, fp32 MFMA attention)"), "engine": args.engine, "gemm": args.gemm if args.engine == "fused" else "hipblaslt", "parallelism": "slate-sharded dp%d" % world,
+                       "arithmetic": ("fp32 storage and accumulation; ONE bf16 MFMA product per contraction in the dense projections and in attention (throughput mode)" if (args.engine == "fused" and args.gemm == "bf16") else "fp32 storage and accumulation; dense projections and attention contractions as fp32-accurate split-bf16 (3 bf16 MFMA products per fp32 product)" if (args.engine == "fused" and args.gemm != "hipblaslt") else "fp32 (hipBLASLt GEMMs, fp32 MFMA attention)"), "engine": args.engine, "gemm": args.gemm if args.engine == "fused" else "hipblaslt", "parallelism": "slate-sharded dp%d" % world,
                        "train_flops_per_item": fl_item},
             "model_tflops": round(value * fl_item / 1e12, 2),
             "model_mfma_frac_fp32": round(value * fl_item / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
@@ -458,7 +460,7 @@ def main():
         if w["N"] and args.engine == "fused":
             try:                               # measured arithmetic error of the benchmarked GEMM (and of the alternatives)
                 out["gemm_max_rel_err_vs_fp64"] = {g_: gemm_error_vs_fp64(w, B, L, device, g_) for g_ in
-                                                   sorted({args.gemm, "split_bf16_strict", "hipblaslt"})}
+                                                   sorted({args.gemm, "split_bf16_strict", "hipblaslt", "bf16"})}
             except Exception as e:
                 out["gemm_max_rel_err_vs_fp64"] = "failed: %r" % (e,)
         if world == 1 and args.engine == "fused" and w["N"] and not args.no_side_pass and not args.compact:
@@ -479,6 +481,33 @@ def main():
                     del t2, m2
                 except Exception as e:
                     out[key] = "failed: %r" % (e,)
+        if world == 1 and args.engine == "fused" and w["N"] and not args.no_side_pass and not args.compact and args.gemm == "split_bf16":
+            # SURVEY.md §8(d) "strict fp32 mode for parity, bf16 mode for throughput ... report both": the same step with ONE bf16
+            # product per contraction (GEMMs + attention).  Its loss error is measured here against the parity arithmetic at
+            # identical weights (same seed -> same initial model, first step of the same batch); it is NOT `value`.
+            try:
+                ma, mb = build_model(w, device, args.dropout), build_model(w, device, args.dropout)
+                ta = FusedTrainer(ma, w["loss"], w.get("loss_args", {}), B, L, lr=1e-3, world_size=1, use_graph=True, gemm="split_bf16")
+                tb = FusedTrainer(mb, w["loss"], w.get("loss_args", {}), B, L, lr=1e-3, world_size=1, use_graph=True, gemm="bf16")
+                la, lb = float(ta.step(x[:B], y[:B], idx[:B])), float(tb.step(x[:B], y[:B], idx[:B]))
+                sa, sb = ta.scores.clone(), tb.scores.clone()
+                for i in range(4):
+                    tb.step(x[:B], y[:B], idx[:B])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(10):
+                    tb.step(x[:B], y[:B], idx[:B])
+                torch.cuda.synchronize()
+                out["throughput_mode_bf16"] = {
+                    "value": round(10 * B * L / (time.perf_counter() - t0), 1), "unit": "slate-items/s",
+                    "arithmetic": "one bf16 MFMA product per contraction (dense projections + attention), fp32 storage / accumulation / LayerNorm / softmax / loss / Adam",
+                    "loss_abs_err_vs_parity_mode_step0": abs(la - lb), "loss_parity_mode_step0": la,
+                    "score_max_abs_err_vs_parity_mode_step0": float((sa - sb).abs().max().item()),
+                    "score_max_abs": float(sa.abs().max().item()),
+                    "within_1e-5_parity": bool(abs(la - lb) <= 1e-5)}
+                del ta, tb, ma, mb
+            except Exception as e:
+                out["throughput_mode_bf16"] = "failed: %r" % (e,)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, L)
         else:

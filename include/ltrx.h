@@ -195,7 +195,9 @@ int ltrx_layernorm_bwd(const float* dy, const float* xsum, const float* a, const
 /* arithmetic of the attention contractions: 1 (default) = split-bf16 on the bf16 MFMA (3 products per fp32 product, fp32-class,
  * like the dense projections) with the whole slate resident in LDS, used wherever the shape fits (slate length <= 256,
  * 32 < d_k <= 64; dropout and variable-length batches included); 0 = exact fp32 MFMA (bit-exact fp32 products) for every
- * shape -- the strict reference.  Shapes that do not fit always run the exact kernels. */
+ * shape -- the strict reference; 2 = the kernels of mode 1 with ONE bf16 product per contraction (plain-bf16 throughput mode,
+ * about 2^-9 relative error per product: outside the parity contract, reported separately by bench.py).  Shapes that do not
+ * fit always run the exact kernels. */
 void ltrx_mha_set_mode(int mode);
 int ltrx_mha_get_mode(void);
 int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L, int h,
@@ -267,8 +269,10 @@ int ltrx_score_head_bwd(const float* dscores, const float* x, const float* w, in
                         float* db, void* ws, ltrx_stream_t stream);
 
 /* fp32-accurate dense projections on the bf16 matrix cores ("split-bf16": each fp32 operand is split into bf16 hi + lo
- * while staged into LDS; A B^T ~= Ahi Bhi^T + Ahi Blo^T + Alo Bhi^T with fp32 accumulation; strict != 0 uses a 3-term
- * split and 6 products).  Replaces the nn.Linear GEMMs of model.py:35-44 and transformer.py:193-203,221-227.
+ * while staged into LDS; A B^T ~= Ahi Bhi^T + Ahi Blo^T + Alo Bhi^T with fp32 accumulation).  `strict` is the precision
+ * code of a call: 0 = the three products above (parity arithmetic, default); 1 = a 3-term split and 6 products (true-fp32
+ * error); 2 = ONE product Ahi Bhi^T (plain bf16 operands, fp32 accumulate: the throughput mode, about 2^-9 relative error
+ * per product -- outside the parity contract, reported separately by bench.py).  Replaces the nn.Linear GEMMs of model.py:35-44 and transformer.py:193-203,221-227.
  *   ltrx_gemm_nt: C[M,N] (ld ldc) = epi( A[M,K] (ld lda) * B[N,K]^T (ld ldb) + bias[N] )
  *                 -- forward (B = weight) and input gradient (B = weight^T);  K, lda, ldb multiples of 4.
  *                 epilogue `act`: 0 none, 1 ReLU (transformer.py:227 fused), 2 multiply by (aux[m,n] > 0): the ReLU
