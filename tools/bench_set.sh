@@ -14,3 +14,6 @@ run --workload attn1024_listmle
 run --workload fc_listnet
 run --gemm hipblaslt
 run --gemm split_bf16_strict
+run --gemm bf16
+run --gemm bf16 --slates-per-gpu 512
+run --gemm bf16 --ragged --compact
