@@ -142,11 +142,11 @@ def time_kernels(w, B, L, device):
         st2 = LB.stream_of(qkv)
         t_f = ev(lambda: LB.check(lib.ltrx_mha_fwd(LB.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, LB.ptr(m8), B, L, h, dk,
                                                    3 * d, LB.ptr(o_), d, LB.ptr(lse_), 0.0, 0, None, None, None, st2), "mha_fwd"))
-        res["ltrx_mha_fwd_kernel"] = dict(sec=t_f, flops=fl, launches_per_step=w["N"])
+        res["ltrx_mha_fwd (res split-bf16)"] = dict(sec=t_f, flops=fl, launches_per_step=w["N"])
         t_b = ev(lambda: LB.check(lib.ltrx_mha_bwd(LB.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, LB.ptr(m8), LB.ptr(o_),
                                                    LB.ptr(go), LB.ptr(lse_), B, L, h, dk, 3 * d, d, LB.ptr(dqkv), dqkv.data_ptr() + 4 * d,
                                                    dqkv.data_ptr() + 8 * d, 3 * d, 0.0, 0, None, None, None, LB.ptr(ws_), st2), "mha_bwd"))
-        res["ltrx_mha_bwd(dq+dkdv+delta)"] = dict(sec=t_b, flops=2.5 * fl, launches_per_step=w["N"])
+        res["ltrx_mha_bwd (dq+dkdv, res split-bf16)"] = dict(sec=t_b, flops=2.5 * fl, launches_per_step=w["N"])
         x = torch.randn(B * L, d, device=device)
         r = torch.randn(B * L, d, device=device)
         a = torch.ones(d, device=device)
@@ -403,7 +403,7 @@ def main():
             traffic = None       # PMC counters need their own rocprofv3 passes (never inside a timed run): see traffic_source
             roof = dict(kernel=name, bound="mfma", achieved=round(alg, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(alg / PEAK_BF16_MFMA_TFLOPS, 4), traffic=traffic,
-                        traffic_source="profiles/ (rocprofv3 --pmc passes of tools/lab/pmc_gemm2.sh; not collected inside bench.py)",
+                        traffic_source="profiles/r02_pmc_gemm256.md (rocprofv3 --pmc passes of tools/lab/pmc_gemm2.sh on the same kernel and shape: 0.88e9 HBM-side bytes per launch vs 0.633e9 algorithmic; PMC counters cannot be collected inside bench.py)",
                         avg_launch_us=round(k["sec"] * 1e6, 1),
                         timing="HIP events around the %d FFN-1 launches of 5 eager training steps after the timed region" % (5 * w["N"]),
                         back_to_back_launch_us=round(k.get("sec_back_to_back", k["sec"]) * 1e6, 1),
