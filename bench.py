@@ -224,6 +224,45 @@ def cpu_baseline(w, L, seconds_budget=20.0):
     return out
 
 
+def measure_hbm_traffic(M, N, K, timeout_s=150):
+    """HBM-side bytes per launch of the dominant GEMM kernel at the benchmarked shape, from rocprofv3 PMC counters collected
+    the way MI355X_MICROARCH.md (HBM section) prescribes: separate --pmc passes (FETCH_SIZE, then WRITE_SIZE; --kernel-trace only
+    beside them), counters in KB, FETCH_SIZE doubled on gfx950 (it tallies 128-B requests at 64 B for wide coalesced reads).
+    Runs AFTER the timed region, as two child processes executing tools/gemm_one.py (the same kernel, shape and library; 5
+    launches, the mean of launches 2..5 is used).  Returns (bytes, detail) or (None, reason)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    root = os.path.dirname(os.path.abspath(__file__))
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ltrx_pmc_")
+        try:
+            env = dict(os.environ, GM=str(M), GN=str(N), GK=str(K), GONLY="nt", TMPDIR=d)
+            subprocess.run([exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--",
+                            sys.executable, os.path.join(root, "tools", "gemm_one.py")], cwd=d, env=env, timeout=timeout_s,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "no counter_collection.csv from the %s pass" % counter
+            per = []
+            for r in csv.DictReader(open(files[0])):
+                if "nt256" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    per.append(float(r["Counter_Value"]))
+            if len(per) < 2:
+                return None, "kernel not found in the %s pass" % counter
+            vals[counter] = sum(per[1:]) / (len(per) - 1)
+        except Exception as e:
+            return None, "%s pass failed: %r" % (counter, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    rd, wr = 2.0 * vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
+    return rd + wr, dict(read_bytes=rd, write_bytes=wr, fetch_size_kb_raw=vals["FETCH_SIZE"], write_size_kb_raw=vals["WRITE_SIZE"],
+                         correction="FETCH_SIZE x 2 (gfx950, wide coalesced reads; MI355X_MICROARCH.md HBM section), counters in KB",
+                         collection="two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of tools/gemm_one.py after the timed region, mean of launches 2..5")
+
+
 def _self_spawn(n):
     import socket
     import subprocess
@@ -400,10 +439,14 @@ def main():
         name, k = max(kern.items(), key=lambda kv: kv[1]["sec"] * kv[1]["launches_per_step"])
         if name.startswith("ltrx_gemm"):
             alg = k["flops"] / k["sec"] / 1e12            # algorithmic: the 2*M*N*K flop of the fp32 GEMM it replaces
-            traffic = None       # PMC counters need their own rocprofv3 passes (never inside a timed run): see traffic_source
+            traffic, traffic_detail = (None, "skipped (--no-side-pass)")
+            if not args.no_side_pass and world == 1 and name.endswith("@FFN1"):
+                traffic, traffic_detail = measure_hbm_traffic(B * L, w["d_ff"], w["fc_sizes"][-1])
             roof = dict(kernel=name, bound="mfma", achieved=round(alg, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
                         frac=round(alg / PEAK_BF16_MFMA_TFLOPS, 4), traffic=traffic,
-                        traffic_source="profiles/r02_pmc_gemm256.md (rocprofv3 --pmc passes of tools/lab/pmc_gemm2.sh on the same kernel and shape: 0.88e9 HBM-side bytes per launch vs 0.633e9 algorithmic; PMC counters cannot be collected inside bench.py)",
+                        traffic_detail=traffic_detail,
+                        algorithmic_bytes_per_launch=4.0 * (B * L * w["fc_sizes"][-1] + w["d_ff"] * w["fc_sizes"][-1] + B * L * w["d_ff"]),
+                        traffic_source="live: measure_hbm_traffic() (rocprofv3 --pmc child passes); committed copy of the same passes: profiles/r02_pmc_gemm256.md",
                         avg_launch_us=round(k["sec"] * 1e6, 1),
                         timing="HIP events around the %d FFN-1 launches of 5 eager training steps after the timed region" % (5 * w["N"]),
                         back_to_back_launch_us=round(k.get("sec_back_to_back", k["sec"]) * 1e6, 1),

@@ -2,7 +2,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from allrank_amd import _lib as LB
 lib = LB.lib()
-m, n, k = int(os.environ.get('GM', '15360')), 2048, 512
+m, n, k = int(os.environ.get('GM', '15360')), int(os.environ.get('GN', '2048')), int(os.environ.get('GK', '512'))
 A = torch.randn(m, k, device="cuda"); B = torch.randn(n, k, device="cuda") / k ** 0.5; bias = torch.randn(n, device="cuda")
 C = torch.empty(m, n, device="cuda")
 if os.environ.get("GZERO"):           # DVFS probe: all-zero operands draw less power -> the same kernel at a higher clock
@@ -11,6 +11,9 @@ lib.ltrx_gemm_set_variant(int(os.environ.get("GV", "0")))
 PREC = int(os.environ.get("GPREC", "0"))       # 0 three products, 1 strict, 2 plain bf16
 for _ in range(5):
     LB.check(lib.ltrx_gemm_nt(LB.ptr(A), k, LB.ptr(B), k, LB.ptr(C), n, m, n, k, LB.ptr(bias), 0, None, 0, 0.0, 0, None, PREC, None), "nt")
+if os.environ.get("GONLY") == "nt":
+    torch.cuda.synchronize()
+    sys.exit(0)
 dY = torch.randn(m, n, device="cuda"); X = torch.randn(m, k, device="cuda")
 if os.environ.get("GZERO"):
     dY.zero_(); X.zero_()
