@@ -35,6 +35,7 @@ namespace {
 constexpr int RMAX = 256;                 // rows (items of a slate) held in LDS
 constexpr int DK = 64;                    // padded head dimension
 constexpr int PLANE = RMAX * DK * 2;      // bytes of one bf16 plane
+constexpr size_t RES_STATS = 4 * (size_t)PLANE + 3 * RMAX * sizeof(float);   // LDS bytes of the four planes + per-row statistics
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
@@ -116,6 +117,27 @@ __device__ __forceinline__ void load_fixed(bf16x8 (&fh)[4], bf16x8 (&fl)[4], con
 }
 
 #define LTRX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+// barrier that orders LDS only: __syncthreads() also drains vmcnt(0), i.e. it would wait at every tile for the global loads of
+// the NEXT tile that were issued just before it (and for the touch_line requests)
+__device__ __forceinline__ void lds_only_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#ifdef LTRX_MHA_STAMP        // lab builds only (tools/lab/lib_variant.sh): cycle stamps of one workgroup of the forward kernel
+__device__ unsigned long long g_mha_stamps[8][40][6];
+#define STAMP(kt, ph)                                                                  \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    if (blockIdx.x == LTRX_MHA_STAMP && (threadIdx.x & 63) == 0) g_mha_stamps[threadIdx.x >> 6][kt][ph] = __builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#else
+#define STAMP(kt, ph)
+#endif
+#ifndef LTRX_MHA_TOUCH
+#define LTRX_MHA_TOUCH 1
+#endif
 #ifndef LTRX_MHA_SETPRIO
 #define LTRX_MHA_SETPRIO 0
 #endif
@@ -255,6 +277,45 @@ __device__ __forceinline__ Slate which_slate(int L, int h, const int* __restrict
   return s;
 }
 
+// The workgroup that will take this CU's place is (about) blockIdx.x + 256 -- one workgroup per CU, 256 CUs, workgroup ids dealt
+// to the 8 XCDs round-robin, so it runs on THIS XCD.  Every workgroup's prologue is a burst of 77-300 KB of compulsory loads
+// (its fixed operands, the first streamed tile) with all CUs in the same phase: ~10 k of a forward workgroup's 57 k cycles
+// (cycle stamps, tools/lab/mha_stamps.py).  The forward kernel therefore requests one dword per 128-byte line of the successor's
+// Q rows and first K / V tile during its LAST tile -- any earlier and the next streamed tile's vmcnt wait, which is in-order, waits
+// for these requests too (measured +14 %); as LDS-DMA into a scratch area the release fence of the LDS barrier waits for them
+// (same +14 %) -- into registers that stay reserved until the end of the kernel, and the successor's prologue finds the lines in
+// (or on their way into) this XCD's L2: forward 198 -> 190 us at config 3 (prologue 10.1 k -> 4.9 k cycles).  The two backward
+// kernels measured no gain from the same trick and do not use it.
+struct Touch {
+  float t[2];
+};
+// one dword of line `i` of the rows [0, nrows) x head slice of `base`; the destination register stays reserved (and unread) until
+// touch_join() at the very end of the kernel -- the compiler does not know this is a load, so it never waits for it
+__device__ __forceinline__ float touch_line(const float* __restrict__ base, int i, int nrows, int dk, size_t rs) {
+  const int lpr = (dk * 4 + 127) >> 7;                       // 128-byte lines per row of a head slice
+  float t = 0.f;
+  if (i < nrows * lpr) {
+    const float* src = base + (size_t)(i / lpr) * rs + (i % lpr) * 32;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(t) : "v"(src) : "memory");
+  }
+  return t;
+}
+__device__ __forceinline__ void touch_join(const Touch& x) {
+  asm volatile("s_waitcnt vmcnt(0)" ::"v"(x.t[0]), "v"(x.t[1]) : "memory");
+}
+// the (slate, head) of workgroup blockIdx.x + 256 of the same row block, if there is one
+__device__ __forceinline__ bool next_slate(int L, int h, const int* __restrict__ cu, const int* __restrict__ order, Slate& s) {
+  const unsigned id = blockIdx.x + 256u;
+  if (id >= gridDim.x) return false;
+  s.head = id % h;
+  s.b = order ? order[id / h] : (int)(id / h);
+  s.bh = s.b * h + s.head;
+  s.Lmax = L;
+  s.row0 = cu ? (size_t)cu[s.b] : (size_t)s.b * L;
+  s.len = cu ? cu[s.b + 1] - cu[s.b] : L;
+  return true;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -271,6 +332,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
   unsigned char* kimg = smem;
   unsigned char* vimg = smem + 2 * PLANE;
   float* kbias = reinterpret_cast<float*>(smem + 4 * PLANE);
+  Touch tch = {{0.f, 0.f}};
   if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   const Slate sl = which_slate(L, h, cu, order);
   const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
@@ -279,6 +341,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
   const float* src = (threadIdx.x < 256 ? k : v) + sl.row0 * rs + (size_t)sl.head * dk;     // this thread's streamed tensor
   unsigned char* dst = threadIdx.x < 256 ? kimg : vimg;
   TileRegs tr;
+  STAMP(32, 0);
   tile_gload(tr, src, 0, len, dk, rs);
   if ((int)(blockIdx.y * RMAX) >= len) return;        // whole workgroup beyond this slate (uniform: before any barrier)
   const int q0 = blockIdx.y * RMAX + wave * 32;
@@ -292,16 +355,28 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
   const float sl2 = scale * kLog2e;
   const int nkt = (len + 31) / 32;
   for (int kt = 0; kt < nkt; ++kt) {
+    STAMP(kt, 0);
     tile_sstore<PL>(dst, kt, tr);
     if (threadIdx.x < 32) {
       const int key = kt * 32 + threadIdx.x;
       kbias[(kt & 7) * 32 + threadIdx.x] = (key >= len || (kpm && kpm[sl.row0 + key])) ? -INFINITY : 0.f;
     }
     if (kt + 1 < nkt) tile_gload(tr, src, kt + 1, len, dk, rs);       // in flight during this tile's MFMAs
-    __syncthreads();
+    if (LTRX_MHA_TOUCH && kt == nkt - 1 && blockIdx.y == 0) {     // (after the last wait on a streamed tile: nothing waits for these)
+      Slate nx;
+      if (next_slate(L, h, cu, order, nx)) {
+        const size_t o = nx.row0 * rs + (size_t)nx.head * dk;
+        tch.t[0] = touch_line(q + o, threadIdx.x, nx.len, dk, rs);
+        tch.t[1] = touch_line(threadIdx.x < 256 ? k + o : v + o, threadIdx.x & 255, min(nx.len, 32), dk, rs);
+      }
+    }
+    STAMP(kt, 1);
+    lds_only_barrier();
+    STAMP(kt, 2);
     if (!active) continue;
     const int slot = (kt & 7) * 32;                            // ring slot (rows of the LDS images) of this tile
     f32x16 s = rows_x_fixed<4, PL>(kimg, slot, qh, ql);            // S^T[key = rowmap(r, half)][query = l31]
+    STAMP(kt, 3);
     float mt = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -328,15 +403,23 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[ct][r] *= alpha;
+    STAMP(kt, 4);
     cols_x_p<PL>(vimg, slot, p, oacc);                                     // O^T[d][query] += V^T[d][key] P^T[key][query]
+    STAMP(kt, 5);
     m = mn;
   }
-  if (!active) return;
+  STAMP(33, 0);
+  if (!active) {
+    if (LTRX_MHA_TOUCH) touch_join(tch);
+    return;
+  }
   const float lt = l + __shfl_xor(l, 32, 64);
   const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
   store_rows(o + sl.row0 * ors + (size_t)sl.head * dk, q0, len, dk, ors, oacc, inv);
   const int qrow = q0 + (lane & 31);
   if (half == 0 && qrow < len) lse[((size_t)sl.b * h + sl.head) * sl.Lmax + qrow] = (lt > 0.f) ? (m + log2f(lt)) * kLn2 : 0.f;
+  STAMP(34, 0);
+  if (LTRX_MHA_TOUCH) touch_join(tch);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -396,7 +479,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dq_res_kernel(
       kbias[(kt & 7) * 32 + threadIdx.x] = (key >= len || (kpm && kpm[sl.row0 + key])) ? -INFINITY : 0.f;
     }
     if (kt + 1 < nkt) tile_gload(tr, src, kt + 1, len, dk, rs);
-    __syncthreads();
+    lds_only_barrier();
     if (!active) continue;
     const int slot = (kt & 7) * 32;
     const f32x16 s = rows_x_fixed<2, PL>(kimg, slot, qh, ql);       // S^T[key][query]
@@ -464,7 +547,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
       if (DROP) drow_t[sl_] = drop_row_seed(drop, sl.bh, sl.Lmax, qr);
     }
     if (qt + 1 < nqt) tile_gload(tr, src, qt + 1, len, dk, srs);
-    __syncthreads();
+    lds_only_barrier();
     if (!active) continue;
     const int slot = (qt & 7) * 32;
     // (order chosen for register pressure: both 16-register products first, then the two accumulations; the fences keep the
@@ -493,7 +576,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
 // ------------------------------------------------------------------------------------------------------------------
 // host launchers (called from ltrx_mha.hip's C entry points when the shape fits: L <= 256, 32 < d_k <= 64)
 // ------------------------------------------------------------------------------------------------------------------
-static constexpr size_t RES_SMEM = 4 * (size_t)PLANE + 3 * RMAX * sizeof(float);
+static constexpr size_t RES_SMEM = RES_STATS;
 
 bool ltrx_mha_res_fits(int L, int dk) { return L > 0 && (L + RMAX - 1) / RMAX <= 65535 && dk > 32 && dk <= DK; }
 
@@ -566,3 +649,9 @@ int ltrx_mha_bwd_res_launch(const float* q, const float* k, const float* v, cons
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }
+
+#ifdef LTRX_MHA_STAMP
+extern "C" int ltrx_debug_mha_stamps(unsigned long long* host_dst) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_mha_stamps), sizeof(unsigned long long) * 8 * 40 * 6) == hipSuccess ? 0 : 1;
+}
+#endif
