@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256, 2) ltrx_mha_fwd_kernel(const float* __res
 // backward: dQ   (wave owns 32 queries, streams key tiles)
 // ------------------------------------------------------------------------------------------------------------------
 template <int DKP, bool DROP>
-__global__ void __launch_bounds__(256, (DKP <= 64) ? 3 : 2) ltrx_mha_bwd_dq_kernel(
+__global__ void __launch_bounds__(256, (DKP <= 64) ? 3 : (DKP <= 96 ? 2 : 1)) ltrx_mha_bwd_dq_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ kpm, const float* __restrict__ o, const float* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ delta, int L, int h, int dk, int rs, int ors,
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(256, (DKP <= 64) ? 3 : 2) ltrx_mha_bwd_dq_kern
 // backward: dK, dV   (wave owns 32 keys, streams query tiles)
 // ------------------------------------------------------------------------------------------------------------------
 template <int DKP, bool DROP>
-__global__ void __launch_bounds__(256, 2) ltrx_mha_bwd_dkdv_kernel(
+__global__ void __launch_bounds__(256, (DKP <= 64) ? 2 : 1) ltrx_mha_bwd_dkdv_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const uint8_t* __restrict__ kpm, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, int L, int h, int dk, int rs, int ors, float* __restrict__ dkout,

@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from allrank_amd import _lib as LB
 lib = LB.lib()
-B, L, h, dk = 256, 240, 8, 64
+B, L, h, dk = (int(os.environ.get(k, d)) for k, d in (('MB', 256), ('ML', 240), ('MH', 8), ('MDK', 64)))
 d = h * dk
 dev = "cuda"
 qkv = torch.randn(B * L, 3 * d, device=dev)
