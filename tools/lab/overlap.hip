@@ -11,6 +11,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -o overlap overlap.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -383,12 +384,91 @@ static void runl4(const float4* src, float* out, const char* name) {
   printf("%-44s %8.3f us per iteration (K-step equivalent)\n", name, ms * 1e3 / 3 / iters);
 }
 
+// modes 30-34: do MFMAs and VALU work overlap on a SIMD?  NW waves per SIMD (workgroup of 256 * NW threads), per iteration
+// 12 v_mfma_f32_32x32x16_bf16 (384 pipe cycles) and NV independent v_fma_f32.
+//   30: MFMAs only   31: VALU only   32: 12 MFMAs then NV VALU (phases)   33: one MFMA, NV/12 VALU, ... (interleaved in program order)
+template <int MODE, int NV>
+__global__ void __launch_bounds__(512) kv(float* __restrict__ out, int iters) {
+  f32x16 acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  bf16x8 fa, fb;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    fa[e] = (__bf16)(float)(threadIdx.x + e);
+    fb[e] = (__bf16)(float)(threadIdx.x * 3 + e);
+  }
+  float x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = 1.0f + i + threadIdx.x;
+  const float c1 = 1.0001f, c2 = 0.5f;
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 30 || MODE == 32) {
+#pragma unroll
+      for (int m = 0; m < 12; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[m & 3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODE == 31 || MODE == 32) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) x[v & 15] = __builtin_fmaf(x[v & 15], c1, c2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODE == 33) {
+#pragma unroll
+      for (int m = 0; m < 12; ++m) {
+        acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[m & 3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < NV / 12; ++v) x[(m * (NV / 12) + v) & 15] = __builtin_fmaf(x[(m * (NV / 12) + v) & 15], c1, c2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t += x[i];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += acc[a][r];
+  if (t == 12345.678f) out[0] = t;
+}
+template <int MODE, int NV>
+static void runv(float* out, int threads, const char* name) {
+  const int iters = 20000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL((kv<MODE, NV>), dim3(256), dim3(threads), 0, 0, out, iters);
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((kv<MODE, NV>), dim3(256), dim3(threads), 0, 0, out, iters);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  printf("%-58s waves/SIMD %d  NV %3d: %7.1f ns per iteration\n", name, threads / 256, NV, ms * 1e6 / 3 / iters);
+}
+
 int main() {
   float4* src;
   float* out;
   hipMalloc(&src, (size_t)64 << 20);
   hipMalloc(&out, 64);
   hipMemset(src, 0, (size_t)64 << 20);
+  if (getenv("VALU_ONLY")) {
+    for (int th = 256; th <= 512; th += 256) {
+      runv<30, 144>(out, th, "30: 12 MFMAs");
+      runv<31, 144>(out, th, "31: 144 v_fma");
+      runv<32, 144>(out, th, "32: 12 MFMAs, then 144 v_fma");
+      runv<33, 144>(out, th, "33: (1 MFMA, 12 v_fma) x 12");
+      runv<31, 48>(out, th, "31: 48 v_fma");
+      runv<32, 48>(out, th, "32: 12 MFMAs, then 48 v_fma");
+      runv<33, 48>(out, th, "33: (1 MFMA, 4 v_fma) x 12");
+    }
+    return 0;
+  }
   for (int rep = 0; rep < 2; ++rep) {
     run<1>(src, out, "loads only (8 x dwordx4 per thread)");
     run<2>(src, out, "MFMAs only (48 per wave)");
