@@ -17,7 +17,9 @@ device ops, kept as the independent implementation the tests compare the kernel 
     exactly one relevant document in the slate: it replaces the last sampled slot (:72-74); otherwise the slate is
     re-sampled until a relevant item is in (:75-76).
 Output per batch: ``(xb f32[B, L, F], yb f32[B, L], indices i64[B, L])`` exactly like ToTensor (:19-29), on the device.
-Parsing libsvm text stays on the host (scikit-learn's load_svmlight_file, like the reference, :130).
+The libsvm text itself is parsed on the device too (``parse_svm_file_on_device`` -> ``ltrx_libsvm_parse``: the file's bytes are
+uploaded once, one thread per line; scikit-learn's load_svmlight_file, the reference's parser (:130), stays available as
+``from_svm_file(..., parser="sklearn")`` and is what the parity test compares with).
 """
 import numpy as np
 import torch
