@@ -500,6 +500,25 @@ def main():
             except Exception as e:      # never let the side measurement break the contract line
                 out["value_at_64_slates_per_gpu"] = "failed: %r" % (e,)
         out["comm"] = comm
+        if world == 1 and not args.no_side_pass:
+            try:          # what a caller that hands over HOST batches (the reference's DataLoader, train_utils.py:95) would add per step
+                hx, hy, hi = (t[:B].cpu().pin_memory() for t in (x, y, idx))
+                dx, dy, di = torch.empty_like(x[:B]), torch.empty_like(y[:B]), torch.empty_like(idx[:B])
+                for _ in range(2):
+                    dx.copy_(hx, non_blocking=True); dy.copy_(hy, non_blocking=True); di.copy_(hi, non_blocking=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    dx.copy_(hx, non_blocking=True); dy.copy_(hy, non_blocking=True); di.copy_(hi, non_blocking=True)
+                torch.cuda.synchronize()
+                h2d_ms = (time.perf_counter() - t0) / 10 * 1e3
+                step_ms = dt / args.steps * 1e3
+                out["host_batches"] = {"h2d_ms_per_batch": round(h2d_ms, 4), "bytes_per_batch": int(hx.numel() * 4 + hy.numel() * 4 + hi.numel() * 8),
+                                       "value_if_copy_not_overlapped": round(B * L / ((step_ms + h2d_ms) * 1e-3), 1),
+                                       "value_if_copy_overlapped": round(B * L / (max(step_ms, h2d_ms) * 1e-3), 1),
+                                       "note": "pinned host memory -> HBM of one batch (features, labels, indices); `value` itself is measured with the batch resident in HBM"}
+            except Exception as e:
+                out["host_batches"] = "failed: %r" % (e,)
         if w["N"] and args.engine == "fused":
             try:                               # measured arithmetic error of the benchmarked GEMM (and of the alternatives)
                 out["gemm_max_rel_err_vs_fp64"] = {g_: gemm_error_vs_fp64(w, B, L, device, g_) for g_ in
