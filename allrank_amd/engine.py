@@ -347,6 +347,7 @@ class FusedTrainer(object):
         self._perm_gen = torch.Generator(device=dev)
         self._perm_gen.manual_seed(int(seed) & 0x7FFFFFFF)
         self.use_graph = use_graph and not compact
+        self.graph_fwd, self._warm_fwd = None, 0
         self.probe = None                                     # list collecting (start, end) events of the FFN1 GEMM (eager steps only)
         self.graph = None
         self._warm = 0
@@ -466,13 +467,15 @@ class FusedTrainer(object):
                       "gemm_tn(wgrad)")
 
     # ---- the step body (capturable) ----------------------------------------------------------------------------
-    def _body(self):
+    def _forward(self, train=True):
+        """input buffers -> scores (self.scores_raw [B, L, n_out], self.scores [B, L]); ``train=False`` is model.eval(): every
+        dropout rate is 0 (the saved activations are written all the same, nothing reads them).  Returns (feat, sc_rows)."""
         P = self.LB.ptr
         lib, M, d, B, L = self.lib, self.rows, self.d, self.B, self.L
         kpm = None if self.compact else self.mask                 # packed rows are all valid keys
-        W, G = self.W, self.G
+        W = self.W
         fc = self.model.input_layer
-        # ---------------- forward ----------------
+        dp = (lambda p: p) if train else (lambda p: 0.0)          # dropout rate of a site in this pass
         h = self.x_in
         if self.in_norm is not None:                              # FCModel.input_norm (model.py:39)
             self.LB.check(lib.ltrx_layernorm_torch_fwd(P(h), P(W(self.in_norm.weight)), P(W(self.in_norm.bias)), M, self.fc_sizes[0],
@@ -480,7 +483,7 @@ class FusedTrainer(object):
                                                        self._st()), "layernorm_torch_fwd")
             h = self.x_norm
         for i, lyr in enumerate(fc.layers):
-            self._lin_fwd(h, W(lyr.weight), W(lyr.bias), self.fc_out[i], self.fc_act, self.p_fc, self._site(1000 + i))
+            self._lin_fwd(h, W(lyr.weight), W(lyr.bias), self.fc_out[i], self.fc_act, dp(self.p_fc), self._site(1000 + i))
             h = self.fc_out[i]
         if self.pos is not None:                                  # transformer.py:51-52: x = sqrt(d) x + pe[rank]
             self.LB.check(lib.ltrx_posenc_fwd(P(h), P(self._pos_table()), P(self.idx_rows), P(kpm), M, d, self.pos_pad, float(d) ** 0.5,
@@ -495,24 +498,24 @@ class FusedTrainer(object):
                 self._ln_fwd(x, None, W(n0.a_2), W(n0.b_2), None, st["xn0"], st["mean0"], st["rstd0"])
             else:                                                 # x = x1_prev + ffn_prev, fused with this layer's first norm
                 self._ln_fwd(x, self.branch, W(n0.a_2), W(n0.b_2), st["xsum0"], st["xn0"], st["mean0"], st["rstd0"],
-                             p_prev, s_prev)
+                             dp(p_prev), s_prev)
                 x = st["xsum0"]
             st["xin"] = x
             self._lin_fwd(st["xn0"], st["wqkv"], st["bqkv"], st["qkv"])
             qkv = st["qkv"]
             self.LB.check(lib.ltrx_mha_fwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(kpm), B, L, self.h,
-                                           d // self.h, 3 * d, P(st["o"]), d, P(st["lse"]), st["p_att"], st["s_att"],
+                                           d // self.h, 3 * d, P(st["o"]), d, P(st["lse"]), dp(st["p_att"]), st["s_att"],
                                            P(self.drop_step), P(self.cu), P(self.order), self._st()), "mha_fwd")
             lo = lay.self_attn.linears[3]
             self._lin_fwd(st["o"], W(lo.weight), W(lo.bias), self.branch)
             self._ln_fwd(x, self.branch, W(n1.a_2), W(n1.b_2), st["x1"], st["xn1"], st["mean1"], st["rstd1"],
-                         st["p_s0"], st["s_s0"])
+                         dp(st["p_s0"]), st["s_s0"])
             ff = lay.feed_forward
-            if self.probe is not None:                            # bench.py: HIP events around the roofline kernel, in the step
+            if self.probe is not None and train:                  # bench.py: HIP events around the roofline kernel, in the step
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            self._lin_fwd(st["xn1"], W(ff.w_1.weight), W(ff.w_1.bias), st["r"], 1, st["p_ff"], st["s_ff"])
-            if self.probe is not None:
+            self._lin_fwd(st["xn1"], W(ff.w_1.weight), W(ff.w_1.bias), st["r"], 1, dp(st["p_ff"]), st["s_ff"])
+            if self.probe is not None and train:
                 ev1.record()
                 self.probe.append((ev0, ev1))
             self._lin_fwd(st["r"], W(ff.w_2.weight), W(ff.w_2.bias), self.branch)
@@ -521,7 +524,7 @@ class FusedTrainer(object):
         out = self.model.output_layer
         if self.N:
             nf = self.enc.norm
-            self._ln_fwd(x, self.branch, W(nf.a_2), W(nf.b_2), self.xsum_f, self.xf, self.mean_f, self.rstd_f, p_prev, s_prev)
+            self._ln_fwd(x, self.branch, W(nf.a_2), W(nf.b_2), self.xsum_f, self.xf, self.mean_f, self.rstd_f, dp(p_prev), s_prev)
             feat = self.xf
         else:
             feat = x
@@ -540,6 +543,17 @@ class FusedTrainer(object):
                           "scatter_rows")
         if no > 1:
             torch.sum(self.scores_raw, dim=-1, out=self.scores)   # model.score (model.py:127)
+        return feat, sc_rows
+
+    def _body(self):
+        P = self.LB.ptr
+        lib, M, d, B, L = self.lib, self.rows, self.d, self.B, self.L
+        W, G = self.W, self.G
+        kpm = None if self.compact else self.mask
+        fc = self.model.input_layer
+        out = self.model.output_layer
+        no = self.n_out
+        feat, sc_rows = self._forward(True)
         # ---------------- loss (value + d/dscores) ----------------
         loss, dsc = self.loss.run(self.scores_raw, self.y_in, self._divisor)
         # ---------------- backward ----------------
@@ -748,6 +762,53 @@ class FusedTrainer(object):
                 self._graph_loss = self._full()       # capture only records; the replay below executes this step
         self.graph.replay()
         return self._graph_loss
+
+
+    def _fwd_only(self):
+        if self.gemm == "bf16":
+            prev = self.lib.ltrx_mha_get_mode()
+            self.lib.ltrx_mha_set_mode(2)
+            try:
+                self._forward(False)
+            finally:
+                self.lib.ltrx_mha_set_mode(prev)
+        else:
+            self._forward(False)
+
+    def score(self, xb, yb, indices=None, lengths=None):
+        """``model.score(xb, yb == PADDED_Y_VALUE, indices)`` in eval mode (model.py:82-92) through the kernels of the training
+        step -- the forward half only, every dropout off, replayed from its own hipGraph -- for the validation / metric passes of
+        an epoch (train_utils.py:32-56, 101-107).  The nn.Module forward computes the same scores with fp32 library GEMMs at
+        less than half the rate.  ``yb`` only provides the padding mask; the batch must have the trainer's [B, L] shape (top up
+        a short last batch with all-padded slates).  Returns the trainer's score buffer [B, L] (valid until the next call)."""
+        self._reattach()
+        self.y_in.copy_(yb)
+        self.mask.copy_(yb == PADDED_Y_VALUE)
+        if self.compact:
+            self._pack(xb.reshape(self.M, -1).contiguous(), lengths)
+        else:
+            self.x_in.copy_(xb.reshape(self.M, -1))
+        if self.pos is not None:
+            if indices is None:
+                raise ValueError("FusedTrainer: the model has a positional encoding, score() needs `indices`")
+            if self.compact:
+                self.idx_rows.fill_(-1)
+                self.idx_rows[:self.n_valid] = indices.reshape(-1)[self.idx[:self.n_valid].long()]
+            else:
+                self.idx_rows.copy_(indices.reshape(-1))
+        if not self.use_graph:
+            self._fwd_only()
+            return self.scores
+        if self.graph_fwd is None:
+            if self._warm_fwd < 2:
+                self._warm_fwd += 1
+                self._fwd_only()
+                return self.scores
+            self.graph_fwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_fwd):
+                self._fwd_only()
+        self.graph_fwd.replay()
+        return self.scores
 
 
 class _null(object):

@@ -14,6 +14,8 @@ What changes (all outside the arithmetic of a step):
     main.py:83 builds once install() has rebound the names), torch.optim.Adam with default betas / eps / no weight decay -- and the
     autograd ``Trainer`` (same kernels for attention / LayerNorm / loss, torch autograd + the given optimizer) otherwise;
   * no ``loss.item()`` per step: the running loss is accumulated on the device, one host sync per epoch (train_utils.py:29);
+  * the validation pass runs through ``FusedTrainer.score`` (the forward half of the explicit step, dropout off, its own hipGraph)
+    instead of the nn.Module forward;
   * train metrics come from the scores of the training forward itself instead of a second full pass over ``train_dl`` in train()
     mode (train_utils.py:99; same mode, same data, SURVEY.md §8f row 2);
   * the last, short batch of an epoch (DataLoader drop_last=False) is topped up with fully padded slates for the static-shape step
@@ -87,17 +89,26 @@ def _pad_batch(xb, yb, idx, B):
             torch.cat([idx, idx.new_full((n, idx.shape[1]), -1)]))
 
 
-def _evaluate(model, loss_func, dl, device, metrics):
-    """validation pass of train_utils.py:101-107: mean loss (weighted by batch size) and metric means, no autograd"""
+def _evaluate(model, loss_func, dl, device, metrics, trainer=None):
+    """validation pass of train_utils.py:101-107: mean loss (weighted by batch size) and metric means, no autograd.  With a
+    FusedTrainer the scores come from its forward-only pass (``FusedTrainer.score``: the kernels of the training step, dropout
+    off, hipGraph replay) instead of the nn.Module forward (fp32 library GEMMs)."""
     tot, num = torch.zeros((), device=device), 0
     acc = {name: [] for name in metrics}
     with torch.no_grad():
         for xb, yb, idx in dl:
             xb, yb, idx = xb.to(device), yb.to(device), idx.to(device)
-            mask = yb == PADDED_Y_VALUE
-            tot += loss_func(model(xb, mask, idx), yb).detach().float() * xb.shape[0]
-            num += xb.shape[0]
-            sc = model.score(xb, mask, idx)
+            n = int(xb.shape[0])
+            if trainer is not None and n <= trainer.B and tuple(xb.shape[1:2]) == (trainer.L,):
+                xs, ys, ids = _pad_batch(xb, yb, idx, trainer.B)
+                sc = trainer.score(xs, ys, ids)[:n]
+                out = trainer.scores_raw[:n]
+            else:
+                mask = yb == PADDED_Y_VALUE
+                out = model(xb, mask, idx)
+                sc = out if out.dim() == 2 else model.score(xb, mask, idx)
+            tot += loss_func(out, yb).detach().float() * n
+            num += n
             for name, ats in metrics.items():
                 acc[name].append(getattr(EM, name)(sc, yb, ats=ats))
     out = {}
@@ -182,7 +193,7 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
                 off += 1
 
         model.eval()
-        val_loss, val_metrics = _evaluate(model, loss_func, valid_dl, device, metrics)
+        val_loss, val_metrics = _evaluate(model, loss_func, valid_dl, device, metrics, trainer if fused else None)
 
         lr_now = optimizer.param_groups[0]["lr"]
         if writer is not None:

@@ -51,7 +51,7 @@ class FCModel(nn.Module):
     def forward(self, x):
         x = self.input_norm(x)
         for layer in self.layers:
-            x = self.dropout(self.activation(layer(x)))
+            x = self.dropout(self.activation(ops.linear(x, layer.weight, layer.bias)))
         return x
 
 
@@ -102,10 +102,10 @@ class MultiHeadedAttention(nn.Module):
         mask = mask.reshape(B, -1)[:, -SL:] if mask.dim() > 2 else mask
         w = torch.cat([self.linears[i].weight for i in range(3)], dim=0)
         b = torch.cat([self.linears[i].bias for i in range(3)], dim=0)
-        qkv = F.linear(query, w, b)                                        # [B, L, 3d]
+        qkv = ops.linear(query, w, b)                                      # [B, L, 3d]
         p_drop = self.dropout.p if self.training else 0.0          # transformer.py:154-155, inside the fused kernel
         o = ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], mask, self.h, p_drop)
-        return self.linears[3](o)
+        return ops.linear(o, self.linears[3].weight, self.linears[3].bias)
 
 
 class PositionwiseFeedForward(nn.Module):
@@ -118,7 +118,8 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):
-        return self.w_2(self.dropout(F.relu(self.w_1(x))))
+        # (ReLU in the epilogue of the first GEMM)
+        return ops.linear(self.dropout(ops.linear(x, self.w_1.weight, self.w_1.bias, act=1)), self.w_2.weight, self.w_2.bias)
 
 
 class EncoderLayer(nn.Module):

@@ -1,4 +1,4 @@
-"""torch.autograd bindings of the scoring-model kernels of libltrx.so (custom LayerNorm, fused masked attention).
+"""torch.autograd bindings of the scoring-model kernels of libltrx.so (custom LayerNorm, fused masked attention, nn.Linear).
 
 PyTorch owns the tensors and the autograd graph edges; all arithmetic happens in the HIP kernels behind the C ABI
 (include/ltrx.h).  Device tensors only, fp32, no CPU fallback.
@@ -113,6 +113,76 @@ def attention(q, k, v, key_pad_mask, h, p_drop=0.0, seed=None):
     if p_drop and seed is None:
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
     return _AttentionFn.apply(q, k, v, key_pad_mask, h, float(p_drop or 0.0), int(seed or 0))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# nn.Linear on the split-bf16 GEMMs (the drop-in nn.Module path: allrank's own fit() / loss_batch, model.score(), validation)
+# ------------------------------------------------------------------------------------------------------------------
+_LINEAR_BACKEND = "split_bf16"
+
+
+def set_linear_backend(name):
+    """"split_bf16" (default): ``linear()`` runs ltrx_gemm_nt / ltrx_gemm_tn (fp32-accurate three-product bf16 MFMA GEMMs, the
+    arithmetic of the explicit step); "hipblaslt": torch's F.linear (exact-fp32 library GEMMs, 2-2.5x slower on MI355X)."""
+    global _LINEAR_BACKEND
+    if name not in ("split_bf16", "hipblaslt"):
+        raise ValueError("linear backend must be split_bf16 or hipblaslt")
+    _LINEAR_BACKEND = name
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = act(x w^T + b)   (nn.Linear, model.py:35-44, transformer.py:193-203, 221-227; act 1 = the ReLU of :227 in the epilogue)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        L.require_device(x, w, b)
+        N, K = w.shape
+        x2 = L.f32c(x).reshape(-1, K)
+        w = L.f32c(w)
+        b = L.f32c(b) if b is not None else None
+        M = x2.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        L.check(L.lib().ltrx_gemm_nt(L.ptr(x2), K, L.ptr(w), K, L.ptr(y), N, M, N, K, L.ptr(b), int(act), None, 0, 0.0, 0, None, 0,
+                                     L.stream_of(x2)), "gemm_nt(linear fwd)")
+        ctx.save_for_backward(x2, w, y if act else None)
+        ctx.has_bias, ctx.act, ctx.xshape = b is not None, int(act), x.shape
+        return y.view(x.shape[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        N, K = w.shape
+        M = x2.shape[0]
+        dy2 = L.f32c(dy).reshape(M, N)
+        if ctx.act:                                              # ReLU backward
+            dy2 = dy2 * (y > 0)
+        lib = L.lib()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if N % 4 == 0:
+                wT = w.t().contiguous()                          # [K, N]: the NT kernel wants both operands contraction-contiguous
+                dx = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
+                L.check(lib.ltrx_gemm_nt(L.ptr(dy2), N, L.ptr(wT), N, L.ptr(dx), K, M, K, N, None, 0, None, 0, 0.0, 0, None, 0,
+                                         L.stream_of(dy2)), "gemm_nt(linear dgrad)")
+            else:
+                dx = dy2 @ w
+            dx = dx.view(ctx.xshape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
+            db = torch.empty(N, dtype=torch.float32, device=dy2.device) if ctx.has_bias else None
+            ws = torch.empty(max(int(lib.ltrx_gemm_tn_workspace_bytes(M, N, K)), 64), dtype=torch.uint8, device=dy2.device)
+            L.check(lib.ltrx_gemm_tn(L.ptr(dy2), N, L.ptr(x2), K, L.ptr(dw), L.ptr(db), M, N, K, 0, L.ptr(ws), L.stream_of(dy2)),
+                    "gemm_tn(linear wgrad)")
+        return dx, dw, db, None
+
+
+def linear(x, w, b=None, act=0):
+    """F.linear(x, w, b) (followed by ReLU when act == 1) for device tensors on the split-bf16 GEMMs; shapes the kernels do not
+    take (in_features not a multiple of 4) and the "hipblaslt" backend go through torch."""
+    if _LINEAR_BACKEND != "split_bf16" or not x.is_cuda or w.shape[1] % 4 != 0 or x.dtype != torch.float32:
+        y = torch.nn.functional.linear(x, w, b)
+        return torch.relu(y) if act else y
+    return _LinearFn.apply(x, w, b, act)
 
 
 def mfma_selftest(A, Bm):

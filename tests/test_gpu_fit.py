@@ -133,3 +133,53 @@ def test_evaluate_equals_compute_metrics_of_the_oracle():
     for at, r in zip(ats, ref):
         assert abs(got["ndcg_%d" % at] - float(r)) <= 1e-5, (at, got["ndcg_%d" % at], r)
     assert 0.0 <= got["mrr_10"] <= 1.0
+
+
+@pytest.mark.parametrize("shape,K,N,act", [((7, 33), 136, 512, 0), ((96, 240), 512, 2048, 1), ((5, 9), 20, 1, 0), ((3, 11), 45, 64, 0)])
+def test_ops_linear_matches_fp64(shape, K, N, act):
+    """ops.linear (nn.Linear of the drop-in nn.Module path on the split-bf16 GEMMs): forward and all three gradients against
+    fp64 torch; shapes the kernels do not take (K % 4 != 0) fall back to F.linear and must agree just the same."""
+    from allrank_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(*shape, K, device=DEV, generator=g, requires_grad=True)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(N, device=DEV, generator=g, requires_grad=True)
+    go = torch.randn(*shape, N, device=DEV, generator=g)
+    y = ops.linear(x, w, b, act)
+    y.backward(go)
+    x64, w64, b64 = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    y64 = torch.nn.functional.linear(x64, w64, b64)
+    if act:                                             # the engine's own ReLU mask: a pre-activation within round-off of 0 may
+        y64 = y64 * (y.detach() > 0)                    # land on either side in ANY finite-precision forward
+    y64.backward(go.double())
+    M = int(np.prod(shape))
+    for name, a, r, scale in (("y", y, y64, None), ("dx", x.grad, x64.grad, None), ("dw", w.grad, w64.grad, None), ("db", b.grad, b64.grad, None)):
+        ref = r.detach()
+        err = float((a.detach().double() - ref).abs().max())
+        assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (name, err, float(ref.abs().max()))
+
+
+def test_fused_trainer_score_matches_module_eval_forward():
+    """FusedTrainer.score = model.eval(); model.score(...) (dropout off) through the forward half of the explicit step, also
+    right after training steps with dropout and from its hipGraph replay"""
+    from allrank_amd.engine import FusedTrainer
+    from allrank_amd.model import make_model
+    torch.manual_seed(5)
+    B, L, F = 6, 40, 24
+    model = make_model(dict(sizes=[32], input_norm=False, activation=None, dropout=0.0),
+                       dict(N=2, d_ff=64, h=4, positional_encoding=None, dropout=0.3), dict(d_output=1, output_activation=None), F).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(B, L, F, device=DEV, generator=g)
+    y = torch.randint(0, 5, (B, L), device=DEV, generator=g).float()
+    y[1, 25:] = -1
+    x[1, 25:] = 0
+    ft = FusedTrainer(model, "approxNDCGLoss", {}, B, L, lr=1e-3, use_graph=True)
+    for i in range(5):
+        ft.step(x, y)                                   # training steps (dropout on) move the weights
+        sc = ft.score(x, y).clone()                     # i = 0, 1 eager warm-up, then capture, then replays
+        model.eval()
+        with torch.no_grad():
+            ref = model.score(x, y == -1, None)
+        model.train()
+        valid = y != -1
+        assert float((sc - ref)[valid].abs().max()) <= 2e-5 * max(1.0, float(ref[valid].abs().max())), i

@@ -301,18 +301,28 @@ def test_model_matches_reference_golden(model_golden):
         loss.backward()
         valid = ~mask.cpu().numpy()
         serr = float(np.abs(sc.detach().cpu().numpy() - g[pre + "scores"])[valid].max())
+        sscale = max(1.0, float(np.abs(g[pre + "scores"])[valid].max()))      # (scores relative to their scale: the nn.Linear layers run
+        #                                                                        the three-product split-bf16 GEMMs, 1.4e-6 of sum |a||b|)
         allg = np.concatenate([g[pre + "grad." + k].ravel() for k in params])
         scale = float(np.abs(allg).max())
         gerr = max(float(np.abs(p.grad.cpu().numpy() - g[pre + "grad." + n]).max()) for n, p in model.named_parameters())
-        rows.append(dict(model=mi, score_err=serr, loss=float(loss.item()), ref_loss=float(g[pre + "loss"]), grad_err=gerr, grad_scale=scale))
-        assert serr < 2e-5 and close(loss.item(), g[pre + "loss"]) and gerr <= 2e-4 * scale + 1e-8, rows[-1]
+        rows.append(dict(model=mi, score_err=serr, score_scale=sscale, loss=float(loss.item()), ref_loss=float(g[pre + "loss"]), grad_err=gerr,
+                         grad_scale=scale))
+        assert serr < 2e-5 * sscale and close(loss.item(), g[pre + "loss"]) and gerr <= 2e-4 * scale + 1e-8, rows[-1]
         assert torch.equal(model.score(x, mask, None), model(x, mask, None))
     _log("model_golden", rows)
 
 
-def test_model_config3_matches_oracle():
-    """BASELINE.json config (3): F=136, fc [512], N=2, h=8, d_ff=2048, slate 240 -- forward + backward vs the numpy oracle."""
+@pytest.mark.parametrize("backend", ["split_bf16", "hipblaslt"])
+def test_model_config3_matches_oracle(backend):
+    """BASELINE.json config (3): F=136, fc [512], N=2, h=8, d_ff=2048, slate 240 -- forward + backward of the nn.Module path vs
+    the numpy oracle, with its nn.Linear layers on the split-bf16 GEMMs (the default, ops.linear) and on hipBLASLt fp32.
+    Gradient bars: with exact-fp32 GEMMs the maximum error over all 6.4 M entries stays within 5e-4 of the largest gradient;
+    the three-product GEMMs' forward error (1.4e-6) flips a few more ReLU units whose pre-activation is within round-off of 0,
+    and each flip moves one row's contribution to dW_1 / db_1 (see tests/test_gpu_benchdims.py): maximum within 5e-2, rms
+    within 2e-3 of each tensor's own largest entry."""
     from allrank_amd import losses as E
+    from allrank_amd import ops
     cfg = dict(n_features=136, fc_sizes=[512], fc_activation=None, fc_input_norm=False, N=2, d_ff=2048, h=8, output_activation=None)
     params = M.init_params(cfg, seed=5)
     model = _make_engine_model(cfg, params)
@@ -325,17 +335,30 @@ def test_model_config3_matches_oracle():
     y[3, 17:] = -1
     x[3, 17:] = 0
     mask = y == -1
-    sc = model(_t(x), _t(mask), None)
-    loss = E.approxNDCGLoss(sc, _t(y))
-    loss.backward()
+    ops.set_linear_backend(backend)
+    try:
+        sc = model(_t(x), _t(mask), None)
+        loss = E.approxNDCGLoss(sc, _t(y))
+        loss.backward()
+    finally:
+        ops.set_linear_backend("split_bf16")
     so, cache = M.forward(params, cfg, x, mask)
     lo, gs, _ = O.approxndcg(so, y)
     grads = M.backward(params, cfg, cache, gs)
     serr = float(np.abs(sc.detach().cpu().numpy() - so)[~mask].max())
     scale = max(float(np.abs(v).max()) for v in grads.values())
     gerr = max(float(np.abs(p.grad.cpu().numpy() - grads[n]).max()) for n, p in model.named_parameters())
-    _log("model_cfg3", dict(score_err=serr, loss=float(loss.item()), oracle_loss=float(lo), grad_err=gerr, grad_scale=scale))
-    assert serr < 5e-5 and close(loss.item(), lo) and gerr <= 5e-4 * scale
+    # (rms of a tensor against its OWN largest entry; tensors whose true gradient is (numerically) zero -- the key bias under
+    #  softmax shift invariance -- are measured against the model's largest instead)
+    rms_rel = max(float(np.sqrt(np.mean((p.grad.cpu().numpy() - grads[n]) ** 2))) / max(float(np.abs(grads[n]).max()), 1e-4 * scale)
+                  for n, p in model.named_parameters())
+    _log("model_cfg3_%s" % backend, dict(score_err=serr, loss=float(loss.item()), oracle_loss=float(lo), grad_err=gerr, grad_scale=scale,
+                                         grad_rms_rel_own_max=rms_rel))
+    assert serr < 5e-5 and close(loss.item(), lo)
+    if backend == "hipblaslt":
+        assert gerr <= 5e-4 * scale, (gerr, scale)
+    else:
+        assert gerr <= 5e-2 * scale and rms_rel <= 2e-3, (gerr, scale, rms_rel)
 
 
 @pytest.mark.parametrize("gemm", ["split_bf16", "hipblaslt", "split_bf16_strict"])
