@@ -118,8 +118,9 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):
-        # (ReLU in the epilogue of the first GEMM)
-        return ops.linear(self.dropout(ops.linear(x, self.w_1.weight, self.w_1.bias, act=1)), self.w_2.weight, self.w_2.bias)
+        # one autograd node: ReLU + dropout in the epilogue of the first GEMM, their backward in the epilogue of w_2's input gradient
+        return ops.feed_forward(x, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias,
+                                self.dropout.p if self.training else 0.0)
 
 
 class EncoderLayer(nn.Module):

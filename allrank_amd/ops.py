@@ -185,6 +185,74 @@ def linear(x, w, b=None, act=0):
     return _LinearFn.apply(x, w, b, act)
 
 
+class _FFNFn(torch.autograd.Function):
+    """w_2(dropout(relu(w_1 x)))   (PositionwiseFeedForward.forward, transformer.py:221-227) as ONE autograd node: ReLU and
+    dropout live in the epilogue of the first GEMM (mask regenerated from (seed, element index), nothing stored), and the
+    backward applies the ReLU(+dropout) mask in the epilogue of the input-gradient GEMM of w_2 -- the block of the explicit step."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, p, seed):
+        L.require_device(x, w1, b1, w2, b2)
+        F_, K = w1.shape
+        N = w2.shape[0]
+        x2 = L.f32c(x).reshape(-1, K)
+        w1, b1, w2, b2 = L.f32c(w1), L.f32c(b1), L.f32c(w2), L.f32c(b2)
+        M = x2.shape[0]
+        lib, st = L.lib(), L.stream_of(x2)
+        r = torch.empty((M, F_), dtype=torch.float32, device=x.device)
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        L.check(lib.ltrx_gemm_nt(L.ptr(x2), K, L.ptr(w1), K, L.ptr(r), F_, M, F_, K, L.ptr(b1), 1, None, 0, float(p), int(seed), None, 0, st),
+                "gemm_nt(ffn w_1)")
+        L.check(lib.ltrx_gemm_nt(L.ptr(r), F_, L.ptr(w2), F_, L.ptr(y), N, M, N, F_, L.ptr(b2), 0, None, 0, 0.0, 0, None, 0, st),
+                "gemm_nt(ffn w_2)")
+        ctx.save_for_backward(x2, w1, w2, r)
+        ctx.p, ctx.xshape = float(p), x.shape
+        return y.view(x.shape[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, r = ctx.saved_tensors
+        F_, K = w1.shape
+        N = w2.shape[0]
+        M = x2.shape[0]
+        dy2 = L.f32c(dy).reshape(M, N)
+        lib, st, dev = L.lib(), L.stream_of(dy2), dy2.device
+
+        def wgrad(a, b_, n, k):
+            gw = torch.empty((n, k), dtype=torch.float32, device=dev)
+            gb = torch.empty(n, dtype=torch.float32, device=dev)
+            ws = torch.empty(max(int(lib.ltrx_gemm_tn_workspace_bytes(M, n, k)), 64), dtype=torch.uint8, device=dev)
+            L.check(lib.ltrx_gemm_tn(L.ptr(a), n, L.ptr(b_), k, L.ptr(gw), L.ptr(gb), M, n, k, 0, L.ptr(ws), st), "gemm_tn(ffn wgrad)")
+            return gw, gb
+
+        dw2, db2 = wgrad(dy2, r, N, F_)
+        w2T = w2.t().contiguous()                                # [F, N]
+        dr = torch.empty((M, F_), dtype=torch.float32, device=dev)
+        # d r = (dy w_2) * [r > 0] / (1 - p): r is the post-ReLU, post-dropout activation, so its sign pattern IS the combined mask
+        L.check(lib.ltrx_gemm_nt(L.ptr(dy2), N, L.ptr(w2T), N, L.ptr(dr), F_, M, F_, N, None, 2, L.ptr(r), F_, ctx.p, 0, None, 0, st),
+                "gemm_nt(ffn dgrad w_2)")
+        dw1, db1 = wgrad(dr, x2, F_, K)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w1T = w1.t().contiguous()                            # [K, F]
+            dx = torch.empty((M, K), dtype=torch.float32, device=dev)
+            L.check(lib.ltrx_gemm_nt(L.ptr(dr), F_, L.ptr(w1T), F_, L.ptr(dx), K, M, K, F_, None, 0, None, 0, 0.0, 0, None, 0, st),
+                    "gemm_nt(ffn dgrad w_1)")
+            dx = dx.view(ctx.xshape)
+        return dx, dw1, db1, dw2, db2, None, None
+
+
+def feed_forward(x, w1, b1, w2, b2, p_drop=0.0, seed=None):
+    """w_2(dropout_p(relu(w_1 x))) for device tensors; ``seed`` keys the dropout mask (default: drawn from torch's generator)."""
+    dims_ok = w1.shape[1] % 4 == 0 and w1.shape[0] % 4 == 0 and w2.shape[0] % 4 == 0
+    if _LINEAR_BACKEND != "split_bf16" or not x.is_cuda or not dims_ok or x.dtype != torch.float32:
+        h = torch.relu(torch.nn.functional.linear(x, w1, b1))
+        return torch.nn.functional.linear(torch.nn.functional.dropout(h, p_drop, p_drop > 0), w2, b2)
+    if p_drop and seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return _FFNFn.apply(x, w1, b1, w2, b2, float(p_drop), int(seed or 0))
+
+
 def mfma_selftest(A, Bm):
     """D = A[32,2] @ B[2,32] through one MFMA with the lane layout the attention kernels assume."""
     D = torch.empty((32, 32), dtype=torch.float32, device=A.device)

@@ -183,3 +183,38 @@ def test_fused_trainer_score_matches_module_eval_forward():
         model.train()
         valid = y != -1
         assert float((sc - ref)[valid].abs().max()) <= 2e-5 * max(1.0, float(ref[valid].abs().max())), i
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_ops_feed_forward_matches_fp64(p):
+    """ops.feed_forward (PositionwiseFeedForward as one autograd node): forward and all five gradients against fp64 torch.
+    The dropout mask depends only on (seed, element index): it is read off a first call whose second projection is the identity
+    (y = the dropped, rectified hidden activation itself) and then used in the fp64 restatement of a call with general weights."""
+    from allrank_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(11)
+    shape, K, Fh, seed = (6, 50), 32, 64, 12345
+    x = torch.randn(*shape, K, device=DEV, generator=g, requires_grad=True)
+    w1 = (torch.randn(Fh, K, device=DEV, generator=g) / K ** 0.5).requires_grad_(True)
+    b1 = torch.randn(Fh, device=DEV, generator=g, requires_grad=True)
+    eye, zero = torch.eye(Fh, device=DEV), torch.zeros(Fh, device=DEV)
+    with torch.no_grad():
+        r = ops.feed_forward(x, w1, b1, eye, zero, p, seed)
+        assert torch.equal(r, ops.feed_forward(x, w1, b1, eye, zero, p, seed))          # same seed, same mask
+    keep = (r != 0).double() / (1.0 - p)                 # ReLU and dropout combined (pre-activations at exactly 0 have measure 0)
+    if p:
+        pre = torch.nn.functional.linear(x.detach(), w1.detach(), b1.detach())
+        frac = float(((r == 0) & (pre > 1e-3)).double().sum() / (pre > 1e-3).double().sum())
+        assert abs(frac - p) < 0.03, frac                # the rate of the counter-based generator
+    N = 40
+    w2 = (torch.randn(N, Fh, device=DEV, generator=g) / Fh ** 0.5).requires_grad_(True)
+    b2 = torch.randn(N, device=DEV, generator=g, requires_grad=True)
+    go = torch.randn(*shape, N, device=DEV, generator=g)
+    y = ops.feed_forward(x, w1, b1, w2, b2, p, seed)
+    y.backward(go)
+    t64 = [t.detach().double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    h64 = torch.nn.functional.linear(t64[0], t64[1], t64[2]) * keep
+    y64 = torch.nn.functional.linear(h64, t64[3], t64[4])
+    y64.backward(go.double())
+    for name, a, ref in [("y", y, y64)] + [(n, t.grad, t6.grad) for n, t, t6 in zip(("dx", "dw1", "db1", "dw2", "db2"), (x, w1, b1, w2, b2), t64)]:
+        err = float((a.detach().double() - ref.detach()).abs().max())
+        assert err <= 2e-5 * max(1.0, float(ref.detach().abs().max())), (name, err)
