@@ -104,7 +104,7 @@ class MultiHeadedAttention(nn.Module):
         b = torch.cat([self.linears[i].bias for i in range(3)], dim=0)
         qkv = ops.linear(query, w, b)                                      # [B, L, 3d]
         p_drop = self.dropout.p if self.training else 0.0          # transformer.py:154-155, inside the fused kernel
-        o = ops.attention(qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:], mask, self.h, p_drop)
+        o = ops.attention_packed(qkv, mask, self.h, p_drop)
         return ops.linear(o, self.linears[3].weight, self.linears[3].bias)
 
 

@@ -107,6 +107,48 @@ class _AttentionFn(torch.autograd.Function):
         return dq, dkk, dv, None, None, None, None
 
 
+class _AttentionPackedFn(torch.autograd.Function):
+    """the same attention on ONE packed projection qkv [B, L, 3 h d_k] (q | k | v column blocks, what MultiHeadedAttention's fused
+    QKV GEMM produces): one input, one gradient -- autograd does not have to rebuild d qkv from three zero-padded slice gradients
+    (3 fills + 3 full-size adds per layer in the sliced form)."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_pad_mask, h, p_drop=0.0, seed=0):
+        L.require_device(qkv, key_pad_mask)
+        qkv = L.f32c(qkv)
+        B, SL, d3 = qkv.shape
+        d = d3 // 3
+        mask = key_pad_mask.to(torch.uint8).contiguous()
+        o = torch.empty((B, SL, d), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((B, h, SL), dtype=torch.float32, device=qkv.device)
+        L.check(L.lib().ltrx_mha_fwd(L.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, L.ptr(mask), B, SL, h, d // h, d3, L.ptr(o),
+                                     d, L.ptr(lse), float(p_drop), int(seed) & 0xFFFFFFFF, None, None, None, L.stream_of(qkv)), "mha_fwd")
+        ctx.save_for_backward(qkv, mask, o, lse)
+        ctx.h, ctx.p_drop, ctx.seed = h, float(p_drop), int(seed) & 0xFFFFFFFF
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, mask, o, lse = ctx.saved_tensors
+        B, SL, d = o.shape
+        h = ctx.h
+        do = L.f32c(do)
+        dqkv = torch.empty((B, SL, 3 * d), dtype=torch.float32, device=o.device)
+        lib = L.lib()
+        ws = L.workspace(lib.ltrx_mha_bwd_workspace_bytes(B, SL, h), o)
+        L.check(lib.ltrx_mha_bwd(L.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, L.ptr(mask), L.ptr(o), L.ptr(do), L.ptr(lse),
+                                 B, SL, h, d // h, 3 * d, d, L.ptr(dqkv), dqkv.data_ptr() + 4 * d, dqkv.data_ptr() + 8 * d, 3 * d,
+                                 ctx.p_drop, ctx.seed, None, None, None, L.ptr(ws), L.stream_of(o)), "mha_bwd")
+        return dqkv, None, None, None, None
+
+
+def attention_packed(qkv, key_pad_mask, h, p_drop=0.0, seed=None):
+    """``attention(qkv[..., :d], qkv[..., d:2d], qkv[..., 2d:], ...)`` with one input and one gradient (see _AttentionPackedFn)"""
+    if p_drop and seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    return _AttentionPackedFn.apply(qkv, key_pad_mask, h, float(p_drop or 0.0), int(seed or 0))
+
+
 def attention(q, k, v, key_pad_mask, h, p_drop=0.0, seed=None):
     """fused masked self-attention; with p_drop > 0 the softmax probabilities are dropped out inside the kernel (the seed
     is drawn from torch's CPU generator unless given, so torch.manual_seed controls it)."""

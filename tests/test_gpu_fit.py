@@ -218,3 +218,23 @@ def test_ops_feed_forward_matches_fp64(p):
     for name, a, ref in [("y", y, y64)] + [(n, t.grad, t6.grad) for n, t, t6 in zip(("dx", "dw1", "db1", "dw2", "db2"), (x, w1, b1, w2, b2), t64)]:
         err = float((a.detach().double() - ref.detach()).abs().max())
         assert err <= 2e-5 * max(1.0, float(ref.detach().abs().max())), (name, err)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_attention_packed_equals_sliced_attention(p):
+    """ops.attention_packed(qkv) == ops.attention(q, k, v) on the column blocks of the same tensor, bit for bit, output and gradient"""
+    from allrank_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(21)
+    B, L, h, dk = 3, 70, 4, 64
+    d = h * dk
+    qkv0 = torch.randn(B, L, 3 * d, device=DEV, generator=g)
+    mask = torch.zeros(B, L, dtype=torch.bool, device=DEV)
+    mask[1, 50:] = True
+    go = torch.randn(B, L, d, device=DEV, generator=g)
+    a = qkv0.clone().requires_grad_(True)
+    oa = ops.attention_packed(a, mask, h, p, seed=77)
+    oa.backward(go)
+    b = qkv0.clone().requires_grad_(True)
+    ob = ops.attention(b[:, :, :d], b[:, :, d:2 * d], b[:, :, 2 * d:], mask, h, p, seed=77)
+    ob.backward(go)
+    assert torch.equal(oa, ob) and torch.equal(a.grad, b.grad)
