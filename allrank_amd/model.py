@@ -224,6 +224,8 @@ class OutputLayer(nn.Module):
         self.w_1 = nn.Linear(d_model, d_output)
 
     def forward(self, x):
+        if self.d_output == 1 and x.dim() == 3:
+            return self.activation(ops.score_head(x, self.w_1.weight, self.w_1.bias))
         return self.activation(self.w_1(x).squeeze(dim=2))
 
     def score(self, x):

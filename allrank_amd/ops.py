@@ -295,6 +295,44 @@ def feed_forward(x, w1, b1, w2, b2, p_drop=0.0, seed=None):
     return _FFNFn.apply(x, w1, b1, w2, b2, float(p_drop), int(seed or 0))
 
 
+class _ScoreHeadFn(torch.autograd.Function):
+    """OutputLayer with d_output == 1 (model.py:111-117): s[m] = <x[m, :], w> + b as one pass over x (a GEMV is HBM-bound)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        L.require_device(x, w, b)
+        D = x.shape[-1]
+        x2 = L.f32c(x).reshape(-1, D)
+        w, b = L.f32c(w).reshape(-1), L.f32c(b).reshape(-1)
+        M = x2.shape[0]
+        sc = torch.empty(M, dtype=torch.float32, device=x.device)
+        L.check(L.lib().ltrx_score_head_fwd(L.ptr(x2), L.ptr(w), L.ptr(b), M, D, L.ptr(sc), L.stream_of(x2)), "score_head_fwd")
+        ctx.save_for_backward(x2, w)
+        ctx.xshape, ctx.wshape, ctx.bshape = x.shape, None, None
+        return sc.view(x.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, ds):
+        x2, w = ctx.saved_tensors
+        M, D = x2.shape
+        ds = L.f32c(ds).reshape(-1)
+        lib = L.lib()
+        dx = torch.empty_like(x2)
+        dw = torch.empty(D, dtype=torch.float32, device=x2.device)
+        db = torch.empty(1, dtype=torch.float32, device=x2.device)
+        ws = torch.empty(max(int(lib.ltrx_score_head_bwd_workspace_bytes(M, D)), 64), dtype=torch.uint8, device=x2.device)
+        L.check(lib.ltrx_score_head_bwd(L.ptr(ds), L.ptr(x2), L.ptr(w), M, D, L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws), L.stream_of(x2)),
+                "score_head_bwd")
+        return dx.view(ctx.xshape), dw.view(1, D), db
+
+
+def score_head(x, w, b):
+    """nn.Linear(d, 1)(x).squeeze(-1) for device tensors: w [1, d], b [1]"""
+    if _LINEAR_BACKEND != "split_bf16" or not x.is_cuda or x.dtype != torch.float32 or w.shape[0] != 1 or b is None:
+        return torch.nn.functional.linear(x, w, b).squeeze(-1)
+    return _ScoreHeadFn.apply(x, w, b)
+
+
 def mfma_selftest(A, Bm):
     """D = A[32,2] @ B[2,32] through one MFMA with the lane layout the attention kernels assume."""
     D = torch.empty((32, 32), dtype=torch.float32, device=A.device)
