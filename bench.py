@@ -570,6 +570,26 @@ def main():
                 del ta, tb, ma, mb
             except Exception as e:
                 out["throughput_mode_bf16"] = "failed: %r" % (e,)
+        if world == 1 and args.engine == "fused" and w["N"] and not args.no_side_pass and not args.compact:
+            # the PLAIN drop-in: allrank_amd.install() without fit=True -- the reference's own loss_batch (train_utils.py:18-29):
+            # nn.Module forward, torch autograd, torch.optim.Adam -- around the same HIP kernels (ops.linear / feed_forward /
+            # attention_packed / layer_norm / the fused loss)
+            try:
+                m3 = build_model(w, device, args.dropout)
+                o3 = torch.optim.Adam(m3.parameters(), lr=1e-3)
+                _lf3, _la3 = getattr(E, w["loss"]), w.get("loss_args", {})
+                t3 = Trainer(m3, (lambda sc, yt: _lf3(sc, yt, **_la3)), o3, None, 1, None)
+                for i in range(3):
+                    t3.step(x[:B], y[:B], idx[:B])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(10):
+                    t3.step(x[:B], y[:B], idx[:B])
+                torch.cuda.synchronize()
+                out["value_plain_dropin_autograd"] = round(10 * B * L / (time.perf_counter() - t0), 1)
+                del t3, o3, m3
+            except Exception as e:
+                out["value_plain_dropin_autograd"] = "failed: %r" % (e,)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, L)
         else:
