@@ -119,9 +119,10 @@ def _evaluate(model, loss_func, dl, device, metrics, trainer=None):
 
 
 def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, config, gradient_clipping_norm, early_stopping_patience,
-        device, output_dir, tensorboard_output_path, use_fused=True, compact=None):
-    """Same positional / keyword arguments as the reference ``fit``; ``use_fused`` / ``compact`` are extensions (compact=None:
-    variable-length execution when less than 80 % of the first batch's slots are valid items)."""
+        device, output_dir, tensorboard_output_path, use_fused=True, compact=None, gemm="split_bf16"):
+    """Same positional / keyword arguments as the reference ``fit``; ``use_fused`` / ``compact`` / ``gemm`` are extensions
+    (compact=None: variable-length execution when less than 80 % of the first batch's slots are valid items; gemm: the arithmetic
+    of the fused step, "split_bf16" = fp32-class parity arithmetic, "bf16" = the one-product throughput mode, see FusedTrainer)."""
     import torch.distributed as dist
     device = torch.device(device)
     if isinstance(model, torch.nn.DataParallel):
@@ -144,7 +145,7 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
             compact = float((first[1] != PADDED_Y_VALUE).float().mean()) < 0.8
         try:
             trainer = FusedTrainer(model, spec[0], spec[1], hi - lo, L, lr=spec[2], world_size=world, use_graph=True,
-                                   gradient_clipping_norm=gradient_clipping_norm, compact=bool(compact))
+                                   gradient_clipping_norm=gradient_clipping_norm, compact=bool(compact), gemm=gemm)
             fused = True
         except (NotImplementedError, KeyError) as e:
             reason = "FusedTrainer: %s" % (e,)
