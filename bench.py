@@ -469,8 +469,8 @@ def main():
             "unit": "slate-items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f32 (split-bf16x3 GEMMs)" if (args.engine == "fused" and args.gemm == "split_bf16") else
-                      "f32 (split-bf16x6 GEMMs)" if (args.engine == "fused" and args.gemm == "split_bf16_strict") else
+            "dtype": ("f32 (split-bf16x3 contractions: GEMMs and attention)" if (args.engine == "fused" and args.gemm == "split_bf16") else
+                      "f32 (split-bf16x6 GEMMs, split-bf16x3 attention)" if (args.engine == "fused" and args.gemm == "split_bf16_strict") else
                       "bf16 products, f32 storage/accumulate (throughput mode, NOT parity-grade)" if (args.engine == "fused" and args.gemm == "bf16") else "f32"),
             "data": "synthetic",
             "config": {"workload": w["desc"], "slates_per_gpu": B, "slate_len": L, "global_batch": B * world,
