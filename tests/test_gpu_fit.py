@@ -238,3 +238,26 @@ def test_attention_packed_equals_sliced_attention(p):
     ob = ops.attention(b[:, :, :d], b[:, :, d:2 * d], b[:, :, 2 * d:], mask, h, p, seed=77)
     ob.backward(go)
     assert torch.equal(oa, ob) and torch.equal(a.grad, b.grad)
+
+
+def test_fit_validation_with_longer_slates_than_training(tmp_path):
+    """the reference validates on slates padded to the longest query (dataset_loading.py:185-194), i.e. usually LONGER than the
+    training slate length: the static-shape scorer of the fused step does not apply and the validation pass goes through the
+    nn.Module forward (same kernels through ops.linear / feed_forward / attention_packed) -- values must equal a direct evaluation"""
+    from torch.utils.data import DataLoader, TensorDataset
+    from allrank_amd import losses as E, fit as EF, metrics as EM
+    cfg = types.SimpleNamespace(metrics={"ndcg": [5]}, val_metric="ndcg_5")
+    train_dl = DataLoader(TensorDataset(*_data(32, 30, 20, 1)), batch_size=16, shuffle=False)
+    xv, yv, iv = _data(20, 47, 20, 2)
+    val_dl = DataLoader(TensorDataset(xv, yv, iv), batch_size=16, shuffle=False)
+    model = _model(20)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    res = EF.fit(epochs=2, model=model, loss_func=partial(E.listNet), optimizer=opt, scheduler=None, train_dl=train_dl, valid_dl=val_dl,
+                 config=cfg, gradient_clipping_norm=None, early_stopping_patience=10, device=torch.device(DEV), output_dir=str(tmp_path),
+                 tensorboard_output_path=None)
+    assert EF.last_run["engine"] == "fused"
+    model.eval()
+    with torch.no_grad():
+        sc = model.score(xv.to(DEV), (yv == -1).to(DEV), iv.to(DEV))
+        ref = float(EM.ndcg(sc, yv.to(DEV), ats=[5]).mean())
+    assert abs(float(res["val_metrics"]["ndcg_5"]) - ref) < 1e-6
