@@ -290,7 +290,10 @@ struct Touch {
   float t[2];
 };
 // one dword of line `i` of the rows [0, nrows) x head slice of `base`; the destination register stays reserved (and unread) until
-// touch_join() at the very end of the kernel -- the compiler does not know this is a load, so it never waits for it
+// touch_join() at the very end of the kernel -- the compiler does not know this is a load, so it never waits for it.
+// (The value lives in ONE register between the two asm statements only as long as the allocator has no reason to copy it: the
+//  forward kernel uses 188 of its 256 VGPRs.  The build's resource remarks and the bit-exact attention tests are the check that
+//  this still holds after a change; LTRX_MHA_TOUCH=0 compiles the mechanism out.)
 __device__ __forceinline__ float touch_line(const float* __restrict__ base, int i, int nrows, int dk, size_t rs) {
   const int lpr = (dk * 4 + 127) >> 7;                       // 128-byte lines per row of a head slice
   float t = 0.f;
