@@ -261,3 +261,25 @@ def test_fit_validation_with_longer_slates_than_training(tmp_path):
         sc = model.score(xv.to(DEV), (yv == -1).to(DEV), iv.to(DEV))
         ref = float(EM.ndcg(sc, yv.to(DEV), ats=[5]).mean())
     assert abs(float(res["val_metrics"]["ndcg_5"]) - ref) < 1e-6
+
+
+def test_prefetcher_delivers_the_loader_batches_unchanged():
+    """allrank_amd.fit._Prefetcher: pinned double buffering + copy stream must hand over exactly the loader's batches, including a
+    short last batch, device-resident batches and a consumer that keeps launching work on the compute stream"""
+    from allrank_amd.fit import _Prefetcher
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(n, 17, 5, generator=g), torch.randint(0, 5, (n, 17), generator=g).float(), torch.randint(0, 17, (n, 17), generator=g))
+               for n in (8, 8, 8, 8, 8, 3)]
+    sink = torch.zeros(2048, 2048, device=DEV)
+    got = []
+    for xb, yb, ib in _Prefetcher(batches, DEV):
+        assert xb.is_cuda and yb.is_cuda and ib.is_cuda
+        got.append((xb.clone(), yb.clone(), ib.clone()))
+        for _ in range(3):
+            sink = sink @ sink * 1e-3                    # keep the compute stream busy behind the consumer's reads
+    assert len(got) == len(batches)
+    for (a, b, c), (x, y, i) in zip(got, batches):
+        assert torch.equal(a.cpu(), x) and torch.equal(b.cpu(), y) and torch.equal(c.cpu(), i)
+    dev_batches = [tuple(t.to(DEV) for t in b) for b in batches[:2]]
+    for (a, b, c), (x, y, i) in zip(_Prefetcher(dev_batches, DEV), dev_batches):
+        assert a is x and b is y and c is i
