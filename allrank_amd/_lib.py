@@ -2,7 +2,6 @@
 kernels fails loudly (the product path never routes through a CPU implementation)."""
 import ctypes
 import os
-import threading
 
 import torch
 
@@ -26,9 +25,8 @@ SIGNATURES = {
     "ltrx_lambdaloss_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_lambdaloss_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_neuralndcg_workspace_bytes": (_sz, [_i, _i, _i]),
-    "ltrx_neuralndcg_force_general": (None, [_i]),
     "ltrx_neuralndcg_prepare": (_i, [_vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp]),
-    "ltrx_neuralndcg_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_neuralndcg_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ltrx_ranknet_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_ranknet_fwd_bwd": (_i, [_vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_bce_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -44,9 +42,7 @@ SIGNATURES = {
     "ltrx_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, ctypes.c_uint32, _vp, _vp]),
     "ltrx_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
-    "ltrx_mha_set_mode": (None, [_i]),
-    "ltrx_mha_get_mode": (_i, []),
-    "ltrx_mha_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _f, ctypes.c_uint32, _vp, _vp, _vp, _vp]),
+    "ltrx_mha_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _f, ctypes.c_uint32, _vp, _vp, _vp, _i, _vp]),
     "ltrx_mha_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltrx_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp, _f, _vp, _vp]),
     "ltrx_clip_workspace_bytes": (_sz, [_sz]),
@@ -64,11 +60,10 @@ SIGNATURES = {
     "ltrx_score_head_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ltrx_score_head_bwd_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_score_head_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "ltrx_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _f, ctypes.c_uint32, _vp, _i, _vp]),
-    "ltrx_gemm_set_variant": (None, [_i]),
+    "ltrx_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _f, ctypes.c_uint32, _vp, _i, _i, _vp]),
     "ltrx_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltrx_gemm_tn_splits": (_i, [_i, _i, _i]),
-    "ltrx_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ltrx_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ltrx_layernorm_torch_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "ltrx_posenc_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "ltrx_posenc_table_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -79,11 +74,17 @@ SIGNATURES = {
     "ltrx_assemble_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ltrx_libsvm_parse": (_i, [_vp, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ltrx_selftest_mfma32x32x2": (_i, [_vp, _vp, _vp, _vp]),
-    "ltrx_mha_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, ctypes.c_uint32, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_mha_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, ctypes.c_uint32, _vp, _vp, _vp, _i, _vp, _vp]),
 }
 
 _lib = None
-_tls = threading.local()
+MAX_SLATE_LEN = 2048            # LTRX_MAX_SLATE_LEN (include/ltrx.h; checked against the header by tests/test_abi.py)
+MAX_METRIC_SLATE_LEN = 8192     # LTRX_MAX_METRIC_SLATE_LEN
+
+
+class _Stream(ctypes.c_void_p):
+    """a hipStream_t that remembers the device it belongs to (``launch_stream`` / ``stream_of``)"""
+    dev = None
 
 
 class _Bound(object):
@@ -91,14 +92,14 @@ class _Bound(object):
 
 
 def _on_stream_device(fn):
-    """Entry points that take a stream launch on it; HIP requires the stream's device to be the CURRENT device.  The
-    stream argument is produced by ``stream_of`` / ``launch_stream`` right before the call, which records the tensor's
-    device; if that is not the current device (explicit cuda:1 tensors while cuda:0 is current -- plain user code after
-    the reference's DataParallel gather) the launch is wrapped in a device guard.  A NULL stream is left alone."""
+    """Entry points that take a stream launch on it; HIP requires the stream's device to be the CURRENT device.  The stream
+    argument produced by ``stream_of`` / ``launch_stream`` carries its device; when that is not the current device (explicit
+    cuda:1 tensors while cuda:0 is current -- plain user code after the reference's DataParallel gather, or replica threads)
+    the launch is wrapped in a device guard.  Every launch made with that stream object is guarded, not only the first
+    (ADVICE r2).  A raw / NULL stream is left alone."""
     def call(*args):
-        dev = getattr(_tls, "dev", None)
-        _tls.dev = None
-        if dev is None or not args or args[-1] is None or dev == torch.cuda.current_device():
+        dev = getattr(args[-1], "dev", None) if args else None
+        if dev is None or dev == torch.cuda.current_device():
             return fn(*args)
         with torch.cuda.device(dev):
             return fn(*args)
@@ -128,7 +129,10 @@ def lib():
 
 def check(rc, what):
     if rc != 0:
-        kinds = {-1: "invalid argument", -2: "unsupported shape"}
+        kinds = {-1: "invalid argument",
+                 -2: "unsupported shape (slate length above LTRX_MAX_SLATE_LEN = %d for a loss / LTRX_MAX_METRIC_SLATE_LEN = %d for a "
+                     "metric, or an alignment the kernel needs -- see include/ltrx.h; there is no fallback path)" %
+                     (MAX_SLATE_LEN, MAX_METRIC_SLATE_LEN)}
         msg = kinds.get(rc, "HIP error %d" % (-rc - 1000) if rc <= -1000 else "error")
         raise RuntimeError("libltrx %s failed: %s (code %d)" % (what, msg, rc))
 
@@ -141,10 +145,11 @@ def ptr(t):
 
 
 def launch_stream(device):
-    """torch's current stream on ``device`` as a hipStream_t; remembers the device for the launch guard of ``lib()``."""
+    """torch's current stream on ``device`` as a hipStream_t that carries its device for the launch guard of ``lib()``."""
     device = torch.device(device)
-    _tls.dev = device.index if device.index is not None else torch.cuda.current_device()
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    st = _Stream(torch.cuda.current_stream(device).cuda_stream)
+    st.dev = device.index if device.index is not None else torch.cuda.current_device()
+    return st
 
 
 def stream_of(t):

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <atomic>
 
 #include "../../include/ltrx.h"
 
@@ -14,6 +15,19 @@
     hipError_t e__ = hipGetLastError();                       \
     if (e__ != hipSuccess) return LTRX_EHIP - (int)e__;       \
   } while (0)
+
+// One-time per-DEVICE setup (hipFuncSetAttribute applies to the current device's copy of a kernel): thread-safe, and the only
+// process state the library keeps -- idempotent facts about loaded code, never a mode that changes results (ltrx.h: re-entrant).
+template <typename F>
+static inline int ltrx_once_per_device(std::atomic<uint64_t>& done, F&& setup) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return LTRX_EHIP;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return LTRX_OK;
+  const int rc = setup();            // two threads racing here both set the same attribute: harmless
+  if (rc == LTRX_OK) done.fetch_or(bit, std::memory_order_release);
+  return rc;
+}
 
 // cut-off ranks of a metric call, passed to the kernel by value (ltrx_ndcg_at, ltrx_mrr_at)
 #define LTRX_MAX_ATS 16

@@ -705,10 +705,9 @@ static void launch_slab_reduce(const float* slabs, int splits, size_t n, float* 
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-// tile variant: 0 = auto; 1 = 128x128x32 (4 waves); 2 = 128x128x64; 3 = 256x128x32 (8 waves); 4 = 256x128x64;
-// 6 = 256x256x32 large-tile kernel (auto picks it for exact multiples with >= 360 tiles); 7 = its 128x256x32 form
-static int g_nt_variant = 0;
-extern "C" void ltrx_gemm_set_variant(int v) { g_nt_variant = v; }
+// `tile` argument of ltrx_gemm_nt / ltrx_gemm_tn (a per-call tuning argument, no process state): 0 = auto; 1 = 128x128x32
+// (4 waves); 2 = 128x128x64; 3 = 256x128x32 (8 waves); 4 = 256x128x64; 6 = 256x256x32 large-tile kernel (auto picks it for
+// exact multiples with >= 360 tiles); 7 = its 128x256x32 form; +100 = tuning experiment (every operand row aliases row 0)
 
 template <int NTERMS, int BM_, int BK_>
 static void launch_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
@@ -721,14 +720,14 @@ static void launch_nt(const float* A, int lda, const float* B, int ldb, float* C
 
 extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                             const float* bias, int act, const float* aux, int ldaux, float drop_p, uint32_t drop_seed,
-                            const uint32_t* drop_step, int strict, ltrx_stream_t stream) {
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return LTRX_EINVAL;
+                            const uint32_t* drop_step, int strict, int tile, ltrx_stream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2 || tile < 0) return LTRX_EINVAL;
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return LTRX_EINVAL;
   const ltrx::DropSpec drop = ltrx_make_drop(drop_p, drop_seed);
   if (act == 2 && (!aux || ldaux < N)) return LTRX_EINVAL;
   if ((K & 3) || (lda & 3) || (ldb & 3) || lda < K || ldb < K || ldc < N) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  int v = g_nt_variant;
+  int v = tile;
   if (v >= 100) {            // tuning experiment: all rows alias row 0 -> every operand load is an L2 hit (results are garbage)
     v -= 100;
     lda = 0;
@@ -750,10 +749,10 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
       // generated in the epilogue -- its hash is indexed by the row of THIS launch.
       const int m1 = (256 / (N / 256)) * 256;
       const int prec = plain ? 2 : strict;
-      int rc = ltrx_gemm_nt(A, lda, B, ldb, C, ldc, m1, N, K, bias, act, aux, ldaux, drop_p, drop_seed, drop_step, prec, stream);
+      int rc = ltrx_gemm_nt(A, lda, B, ldb, C, ldc, m1, N, K, bias, act, aux, ldaux, drop_p, drop_seed, drop_step, prec, 0, stream);
       if (rc != LTRX_OK) return rc;
       return ltrx_gemm_nt(A + (size_t)m1 * lda, lda, B, ldb, C + (size_t)m1 * ldc, ldc, M - m1, N, K, bias, act,
-                          aux ? aux + (size_t)m1 * ldaux : nullptr, ldaux, drop_p, drop_seed, drop_step, prec, stream);
+                          aux ? aux + (size_t)m1 * ldaux : nullptr, ldaux, drop_p, drop_seed, drop_step, prec, 0, stream);
     }
     if (t >= 360 || (t >= 168 && t <= 256)) v = 6;
     else if (t >= 136 && t < 168 && (size_t)((M + 127) / 128) * (N / 256) > 256) v = 6;   // one partial round still beats two rounds of smaller tiles
@@ -765,8 +764,8 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
   if (v == 0) v = 1;
   if (v == 6 || v == 7) {
     if ((N % 256) || (K % 32) || strict || !vec_epi) return LTRX_EUNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_done{0};
+    const int arc = ltrx_once_per_device(attr_done, []() {
 #define LTRX_NT256_ATTR(TAIL_, BM_, NT_)                                                                                     \
   (hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<TAIL_, BM_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                        (int)(2 * sizeof(SmemNT<BM_, NT_>))) != hipSuccess)
@@ -775,8 +774,9 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
           LTRX_NT256_ATTR(false, 128, 1) || LTRX_NT256_ATTR(true, 128, 1))
         return LTRX_EHIP;
 #undef LTRX_NT256_ATTR
-      attr_set = true;
-    }
+      return LTRX_OK;
+    });
+    if (arc != LTRX_OK) return arc;
     const int tiles_n = N / 256;
     const int bm = (v == 6) ? 256 : 128;
     const dim3 grid(((M + bm - 1) / bm) * tiles_n);
@@ -862,24 +862,25 @@ extern "C" size_t ltrx_gemm_tn_workspace_bytes(int M, int NP, int KP) {
 }
 
 extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, float* bias_out, int M, int NP,
-                            int KP, int strict, void* ws, ltrx_stream_t stream) {
-  if (!A || !B || !C || !ws || M <= 0 || NP <= 0 || KP <= 0) return LTRX_EINVAL;
+                            int KP, int strict, int tile, void* ws, ltrx_stream_t stream) {
+  if (!A || !B || !C || !ws || M <= 0 || NP <= 0 || KP <= 0 || tile < 0) return LTRX_EINVAL;
   if (lda < NP || ldb < KP) return LTRX_EUNSUPPORTED;
   const bool plain = strict == 2;                     // precision code as in ltrx_gemm_nt
   if (strict == 2) strict = 0;
-  if (!strict && g_nt_variant != 1 && tn256_ok(M, NP, KP) && (lda & 3) == 0 && (ldb & 3) == 0) {
+  if (!strict && tile != 1 && tn256_ok(M, NP, KP) && (lda & 3) == 0 && (ldb & 3) == 0) {
     hipStream_t s = (hipStream_t)stream;
     int splits, mps;
     tn256_plan(M, NP, KP, &splits, &mps);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_done{0};
+    const int arc = ltrx_once_per_device(attr_done, []() {
       if (hipFuncSetAttribute((const void*)ltrx_gemm_tn256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(2 * sizeof(SmemNT<256, 2>))) != hipSuccess ||
           hipFuncSetAttribute((const void*)ltrx_gemm_tn256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(2 * sizeof(SmemNT<256, 1>))) != hipSuccess)
         return LTRX_EHIP;
-      attr_set = true;
-    }
+      return LTRX_OK;
+    });
+    if (arc != LTRX_OK) return arc;
     float* bslabs = bias_out ? (float*)ws + (size_t)splits * NP * KP : nullptr;
     if (plain)
       hipLaunchKernelGGL(ltrx_gemm_tn256_kernel<1>, dim3((NP / 256) * (KP / 256), splits), dim3(512), 2 * sizeof(SmemNT<256, 1>), s, A,

@@ -249,13 +249,12 @@ extern "C" int ltrx_lambdaloss_fwd_bwd(const float* y_pred, const float* y_true,
   float* per_cnt = per_loss + B;
   float* scale = per_cnt + B;
   const size_t lds = (size_t)(13 * L + 2) * sizeof(float);
-  static bool attr_set = false;          // long slates need more than the default 64 KB of dynamic LDS
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)ltrx_lambdaloss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)((13 * LTRX_MAX_SLATE_LEN + 2) * sizeof(float))) != hipSuccess)
-      return LTRX_EHIP;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};   // long slates need more than the default 64 KB of dynamic LDS
+  const int arc = ltrx_once_per_device(attr_done, []() {
+    return hipFuncSetAttribute((const void*)ltrx_lambdaloss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)((13 * LTRX_MAX_SLATE_LEN + 2) * sizeof(float))) == hipSuccess ? LTRX_OK : LTRX_EHIP;
+  });
+  if (arc != LTRX_OK) return arc;
   hipLaunchKernelGGL(ltrx_lambdaloss_kernel, dim3(B), dim3(1024), lds, s, y_pred, y_true, L, eps, pad_value, scheme, k,
                      sigma, mu, logbase, per_loss, per_cnt, grad_out, order_out);
   LTRX_LAUNCH_CHECK();

@@ -510,15 +510,13 @@ extern "C" int ltrx_selftest_mfma32x32x2(const float* A, const float* Bm, float*
 // host wrappers
 // ------------------------------------------------------------------------------------------------------------------
 // arithmetic of the attention contractions:
-//   mode 1 (default): split-bf16 on the bf16 MFMA with the whole slate resident in LDS (ltrx_mha_res.hip) wherever the
+// (`mode` is an argument of every ltrx_mha_fwd / ltrx_mha_bwd call -- the library keeps no attention mode of its own)
+//   mode 1: split-bf16 on the bf16 MFMA with the whole slate resident in LDS (ltrx_mha_res.hip) wherever the
 //           shape fits (slate length <= 256, 32 < d_k <= 64); fp32-class (three bf16 products per fp32 product, like the dense
 //           projections).  Other shapes run the exact kernels of this file.
 //   mode 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-exact fp32 products) for every shape -- the strict reference.
 //   mode 2: the kernels of mode 1 with ONE bf16 product per contraction (plain bf16 operands, fp32 accumulate and softmax):
 //           the throughput mode, about 2^-9 relative error per product -- NOT the parity arithmetic.
-static int g_mha_mode = 1;
-extern "C" void ltrx_mha_set_mode(int mode) { g_mha_mode = (mode == 2) ? 2 : (mode ? 1 : 0); }
-extern "C" int ltrx_mha_get_mode(void) { return g_mha_mode; }
 bool ltrx_mha_res_fits(int L, int dk);
 int ltrx_mha_fwd_res_launch(const float* q, const float* k, const float* v, const uint8_t* kpm, int B, int L, int h, int dk, int rs,
                             float* o, int ors, float* lse, float p_drop, uint32_t seed, const uint32_t* seed_step, const int* cu,
@@ -548,14 +546,15 @@ static DropCfg make_drop(float p_drop, uint32_t seed) { return ltrx_make_drop(p_
 extern "C" int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L,
                             int h, int d_k, int row_stride, float* o, int o_row_stride, float* lse_out, float p_drop,
                             uint32_t seed, const uint32_t* seed_step, const int32_t* cu_seqlens, const int32_t* slate_order,
-                            ltrx_stream_t stream) {
+                            int mode, ltrx_stream_t stream) {
   if (!q || !k || !v || (!key_pad_mask && !cu_seqlens) || !o || !lse_out || !(p_drop >= 0.f) || p_drop >= 1.f) return LTRX_EINVAL;
+  if (mode < 0 || mode > 2) return LTRX_EINVAL;
   int rc = mha_check(B, L, h, d_k, row_stride, o_row_stride);
   if (rc != LTRX_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (g_mha_mode != 0 && ltrx_mha_res_fits(L, d_k))
+  if (mode != 0 && ltrx_mha_res_fits(L, d_k))
     return ltrx_mha_fwd_res_launch(q, k, v, key_pad_mask, B, L, h, d_k, row_stride, o, o_row_stride, lse_out, p_drop, seed, seed_step,
-                                   cu_seqlens, slate_order, g_mha_mode == 2, s);
+                                   cu_seqlens, slate_order, mode == 2, s);
   const DropCfg drop = make_drop(p_drop, seed);
   const dim3 grid(B * h, (L + 127) / 128);
   const float scale = 1.0f / sqrtf((float)d_k);
@@ -581,17 +580,18 @@ extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, cons
                             const float* dout, const float* lse, int B, int L, int h, int d_k, int row_stride,
                             int o_row_stride, float* dq, float* dk, float* dv, int d_row_stride, float p_drop,
                             uint32_t seed, const uint32_t* seed_step, const int32_t* cu_seqlens, const int32_t* slate_order,
-                            void* ws, ltrx_stream_t stream) {
+                            int mode, void* ws, ltrx_stream_t stream) {
   if (!q || !k || !v || (!key_pad_mask && !cu_seqlens) || !o || !dout || !lse || !dq || !dk || !dv || !ws) return LTRX_EINVAL;
+  if (mode < 0 || mode > 2) return LTRX_EINVAL;
   if (!(p_drop >= 0.f) || p_drop >= 1.f) return LTRX_EINVAL;
   int rc = mha_check(B, L, h, d_k, row_stride, o_row_stride);
   if (rc != LTRX_OK) return rc;
   if (d_row_stride % 4 != 0 || d_row_stride < h * d_k) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* delta = (float*)ws;
-  if (g_mha_mode != 0 && ltrx_mha_res_fits(L, d_k))
+  if (mode != 0 && ltrx_mha_res_fits(L, d_k))
     return ltrx_mha_bwd_res_launch(q, k, v, key_pad_mask, o, dout, lse, B, L, h, d_k, row_stride, o_row_stride, dq, dk, dv, d_row_stride,
-                                   delta, p_drop, seed, seed_step, cu_seqlens, slate_order, g_mha_mode == 2, s);
+                                   delta, p_drop, seed, seed_step, cu_seqlens, slate_order, mode == 2, s);
   const DropCfg drop = make_drop(p_drop, seed);
   const dim3 grid(B * h, (L + 127) / 128);
   const float scale = 1.0f / sqrtf((float)d_k);

@@ -79,7 +79,7 @@ __device__ __forceinline__ void tile_gload(TileRegs& r, const float* __restrict_
   if (row < nrows && c < dk) r.a = *reinterpret_cast<const float4*>(base + (size_t)row * rs + c);
   if (row < nrows && c + 4 < dk) r.b = *reinterpret_cast<const float4*>(base + (size_t)row * rs + c + 4);
 }
-// PL ("plain"): the one-product bf16 throughput mode (ltrx_mha_set_mode(2)): no lo planes, no lo products -- NOT parity arithmetic
+// PL ("plain"): the one-product bf16 throughput mode (mode 2 of ltrx_mha_fwd / ltrx_mha_bwd): no lo planes, no lo products -- NOT parity arithmetic
 template <bool PL>
 __device__ __forceinline__ void tile_sstore(unsigned char* img, int tile, const TileRegs& r) {
   const int idx = threadIdx.x & 255;
@@ -591,13 +591,14 @@ static int res_attr(K kernel) {
 int ltrx_mha_fwd_res_launch(const float* q, const float* k, const float* v, const uint8_t* kpm, int B, int L, int h, int dk, int rs,
                             float* o, int ors, float* lse, float p_drop, uint32_t seed, const uint32_t* seed_step, const int* cu,
                             const int* order, bool plain, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<uint64_t> attr_done{0};
+  const int arc = ltrx_once_per_device(attr_done, []() {
     if (res_attr(ltrx_mha_fwd_res_kernel<false, false>) != LTRX_OK || res_attr(ltrx_mha_fwd_res_kernel<true, false>) != LTRX_OK ||
         res_attr(ltrx_mha_fwd_res_kernel<false, true>) != LTRX_OK || res_attr(ltrx_mha_fwd_res_kernel<true, true>) != LTRX_OK)
       return LTRX_EHIP;
-    attr = true;
-  }
+    return LTRX_OK;
+  });
+  if (arc != LTRX_OK) return arc;
   const DropCfg drop = ltrx_make_drop(p_drop, seed);
   const float scale = 1.0f / sqrtf((float)dk);
   const dim3 grid(B * h, (L + RMAX - 1) / RMAX);
@@ -618,15 +619,16 @@ int ltrx_mha_bwd_res_launch(const float* q, const float* k, const float* v, cons
                             const float* lse, int B, int L, int h, int dk, int rs, int ors, float* dq, float* dkk, float* dv, int drs,
                             float* delta, float p_drop, uint32_t seed, const uint32_t* seed_step, const int* cu, const int* order,
                             bool plain, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<uint64_t> attr_done{0};
+  const int arc = ltrx_once_per_device(attr_done, []() {
     if (res_attr(ltrx_mha_bwd_dq_res_kernel<false, false>) != LTRX_OK || res_attr(ltrx_mha_bwd_dq_res_kernel<true, false>) != LTRX_OK ||
         res_attr(ltrx_mha_bwd_dkdv_res_kernel<false, false>) != LTRX_OK || res_attr(ltrx_mha_bwd_dkdv_res_kernel<true, false>) != LTRX_OK ||
         res_attr(ltrx_mha_bwd_dq_res_kernel<false, true>) != LTRX_OK || res_attr(ltrx_mha_bwd_dq_res_kernel<true, true>) != LTRX_OK ||
         res_attr(ltrx_mha_bwd_dkdv_res_kernel<false, true>) != LTRX_OK || res_attr(ltrx_mha_bwd_dkdv_res_kernel<true, true>) != LTRX_OK)
       return LTRX_EHIP;
-    attr = true;
-  }
+    return LTRX_OK;
+  });
+  if (arc != LTRX_OK) return arc;
   const DropCfg drop = ltrx_make_drop(p_drop, seed);
   const float scale = 1.0f / sqrtf((float)dk);
   const dim3 grid(B * h, (L + RMAX - 1) / RMAX);

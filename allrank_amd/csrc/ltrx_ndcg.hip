@@ -81,7 +81,15 @@ extern "C" int ltrx_ndcg_at(const float* y_pred, const float* y_true, int B, int
                             void* ws, ltrx_stream_t stream) {
   (void)ws;
   if (!y_pred || !y_true || !ats || !ndcg_out || B <= 0 || L <= 0 || n_ats <= 0) return LTRX_EINVAL;
-  if (n_ats > LTRX_MAX_ATS || L > LTRX_MAX_SLATE_LEN) return LTRX_EUNSUPPORTED;
+  if (n_ats > LTRX_MAX_ATS || L > LTRX_MAX_METRIC_SLATE_LEN) return LTRX_EUNSUPPORTED;
+  if (L > 4096) {                                   // more than the default 64 KB of dynamic LDS
+    static std::atomic<uint64_t> attr_done{0};
+    const int arc = ltrx_once_per_device(attr_done, []() {
+      return hipFuncSetAttribute((const void*)ltrx_ndcg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(4 * LTRX_MAX_METRIC_SLATE_LEN * sizeof(float))) == hipSuccess ? LTRX_OK : LTRX_EHIP;
+    });
+    if (arc != LTRX_OK) return arc;
+  }
   LtrxAts a;
   a.n = n_ats;
   for (int i = 0; i < n_ats; ++i) {

@@ -742,9 +742,6 @@ __global__ void __launch_bounds__(1024) ltrx_neural_backward_reg_kernel(
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
-// test hook: force the general (L2-streaming) kernels even when the register-resident fast path applies
-static int g_neural_force_general = 0;
-extern "C" void ltrx_neuralndcg_force_general(int on) { g_neural_force_general = on ? 1 : 0; }
 
 extern "C" size_t ltrx_neuralndcg_workspace_bytes(int B, int L, int max_iter) {
   if (B <= 0 || L <= 0 || max_iter < 0) return 0;
@@ -769,9 +766,9 @@ extern "C" int ltrx_neuralndcg_fwd_bwd(const float* y_pred, const float* y_true,
                                        const float* nonzero_count, int B, int L, float pad_value, float temperature,
                                        int powered_relevancies, int k, const int32_t* k_rows, int transposed,
                                        int max_iter, float tol, float* loss_out, float* per_slate_out, float* grad_out, int32_t* iters_out,
-                                       void* ws, ltrx_stream_t stream) {
+                                       int path, void* ws, ltrx_stream_t stream) {
   if (!y_pred || !y_true || !idcg || !nonzero_count || !loss_out || !ws || B <= 0 || L <= 0) return LTRX_EINVAL;
-  if (!(temperature > 0.f) || max_iter < 0) return LTRX_EINVAL;
+  if (!(temperature > 0.f) || max_iter < 0 || path < 0 || path > 1) return LTRX_EINVAL;
   if (L > LTRX_MAX_SLATE_LEN) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   const int mi = max_iter > 0 ? max_iter : 1;
@@ -781,7 +778,7 @@ extern "C" int ltrx_neuralndcg_fwd_bwd(const float* y_pred, const float* y_true,
   (void)transposed;
   const int threads = 1024;   // 16 waves per slate
   const size_t lds = LTRX_NEURAL_LDS_FLOATS(L) * sizeof(float);
-  const bool fast = (L <= 240) && !g_neural_force_general;
+  const bool fast = (L <= 240) && path == 0;     // path 1: the general (L2-streaming) kernels for every L
 #define LTRX_NEURAL_FWD(NR, NC)                                                                                          \
   hipLaunchKernelGGL((ltrx_neural_forward_reg_kernel<NR, NC>), dim3(B), dim3(1024), lds, s, y_pred, y_true, L, pad_value, \
                      temperature, max_iter, w.S, w.cn, w.rn, w.res)

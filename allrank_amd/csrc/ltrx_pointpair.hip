@@ -372,7 +372,7 @@ extern "C" size_t ltrx_mrr_workspace_bytes(int B, int L, int n_ats) {
 extern "C" int ltrx_mrr_at(const float* y_pred, const float* y_true, int B, int L, const int* ats, int n_ats, float pad_value,
                            float* mrr_out, void* ws, ltrx_stream_t stream) {
   if (!y_pred || !y_true || !ats || !mrr_out || !ws || B <= 0 || L <= 0 || n_ats <= 0) return LTRX_EINVAL;
-  if (n_ats > LTRX_MAX_ATS || L > LTRX_MAX_SLATE_LEN) return LTRX_EUNSUPPORTED;
+  if (n_ats > LTRX_MAX_ATS || L > LTRX_MAX_METRIC_SLATE_LEN) return LTRX_EUNSUPPORTED;   // 8 B of LDS per item: 64 KB at the limit
   hipStream_t s = (hipStream_t)stream;
   float* bv = (float*)ws;
   int* bi = (int*)(bv + B);

@@ -65,7 +65,8 @@ class FusedTrainer(object):
       the Q,K,V projection weights of a layer sit adjacently => ONE [3d, d] GEMM feeds the attention kernel in place.
     * every gradient is written exactly once per step straight into the flat gradient buffer (GEMM ``out=`` views):
       no zero_grad pass, no accumulation kernels, one collective for multi-GPU.
-    * dense projections are library GEMMs (torch.mm/addmm -> hipBLASLt); everything else is libltrx kernels.
+    * every launch of the sequence is a libltrx kernel: the dense projections are the split-bf16 MFMA GEMMs
+      (ltrx_gemm_nt / ltrx_gemm_tn; ``gemm="hipblaslt"`` swaps in torch.mm/addmm as a comparison arithmetic).
     * the whole sequence is captured in a hipGraph after warm-up (``use_graph=True``) -- at 64 slates/GPU the step is
       ~100 launches of 10-300 us, so launch latency matters.
     * dropout (every shipped transformer config trains with 0.1-0.4) is counter-based: a mask element is a hash of
@@ -102,6 +103,9 @@ class FusedTrainer(object):
             raise ValueError("gemm must be split_bf16, split_bf16_strict, hipblaslt or bf16")
         self.gemm = gemm
         self._prec = {"split_bf16_strict": 1, "bf16": 2}.get(gemm, 0)        # precision code of ltrx_gemm_nt / ltrx_gemm_tn
+        # attention arithmetic of THIS trainer, passed with every ltrx_mha_fwd / ltrx_mha_bwd call (the library keeps no mode):
+        # 1 = three bf16 products (fp32-class, parity), 2 = one product (the "bf16" throughput mode)
+        self._mha_mode = 2 if gemm == "bf16" else 1
         self._wT = {}
         self.model = model
         self.B, self.L, self.M = B, L, B * L
@@ -349,7 +353,11 @@ class FusedTrainer(object):
         self.use_graph = use_graph and not compact
         self.graph_fwd, self._warm_fwd = None, 0
         self.probe = None                                     # list collecting (start, end) events of the FFN1 GEMM (eager steps only)
-        self.graph = None
+        # captured steps: {(batch divisor, collectives on?): [(hipGraph segment, collective to launch after it | None), ...]}
+        self._graphs = {}
+        self._seg_break = None                                # set while capturing: ends the current segment (see _capture)
+        self._graph_pool = None
+        self._cap_stream = None
         self._warm = 0
 
     # ---- thin launch helpers -----------------------------------------------------------------------------------
@@ -416,12 +424,29 @@ class FusedTrainer(object):
 
     def _bucket_done(self, k):
         """gradient bucket k is final: start its all-reduce(SUM) now, behind the rest of the backward (the collective runs
-        on the process group's own stream; ``_full`` waits for all of them before the optimizer step)"""
+        on the process group's own stream; ``_full`` waits for all of them before the optimizer step).  While a step is being
+        captured the collective is not issued but handed to ``_seg_break``: it ends the hipGraph segment recorded so far and
+        is launched between that segment's replay and the next one's."""
         if self.world > 1 and self.comm_enabled:
             import torch.distributed as dist
             lo, hi = self._buckets[k]
             if hi > lo:
-                self._works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                def launch(lo=lo, hi=hi):
+                    self._works.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self._seg_break is not None:
+                    self._seg_break(launch)
+                else:
+                    launch()
+
+    def _wait_buckets(self):
+        def wait():
+            for w_ in self._works:                               # bucketed gradient all-reduces launched during the backward
+                w_.wait()
+            self._works = []
+        if self._seg_break is not None and self.world > 1 and self.comm_enabled:
+            self._seg_break(wait)
+        else:
+            wait()
 
     def _lin_fwd(self, x, w, b, out, act=0, p=0.0, seed=0):
         """out = drop_p(act(x w^T + b))   (nn.Linear forward, act 1 = ReLU; dropout in the epilogue)"""
@@ -436,7 +461,7 @@ class FusedTrainer(object):
         P = self.LB.ptr
         self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), P(out), out.stride(0), self.rows, w.shape[0],
                                             x.shape[1], P(b), act, None, 0, float(p), seed, P(self.drop_step),
-                                            self._prec, self._st()), "gemm_nt(fwd)")
+                                            self._prec, 0, self._st()), "gemm_nt(fwd)")
 
     def _lin_dgrad(self, dy, w, wT, out, relu_of=None, p=0.0, seed=0):
         """out = dy w   (input gradient of nn.Linear); wT = w^T contiguous.  With ``relu_of`` (the saved post-ReLU,
@@ -453,7 +478,7 @@ class FusedTrainer(object):
         self.LB.check(self.lib.ltrx_gemm_nt(P(dy), dy.stride(0), P(wT), wT.stride(0), P(out), out.stride(0), self.rows,
                                             wT.shape[0], dy.shape[1], None, 2 if relu_of is not None else 0, P(relu_of),
                                             relu_of.stride(0) if relu_of is not None else 0, float(p), seed, P(self.drop_step),
-                                            self._prec, self._st()), "gemm_nt(dgrad)")
+                                            self._prec, 0, self._st()), "gemm_nt(dgrad)")
 
     def _lin_wgrad(self, dy, x, gw, gb):
         """gw = dy^T x, gb = column sums of dy   (weight and bias gradients of nn.Linear)"""
@@ -463,7 +488,7 @@ class FusedTrainer(object):
             return
         P = self.LB.ptr
         self.LB.check(self.lib.ltrx_gemm_tn(P(dy), dy.stride(0), P(x), x.stride(0), P(gw), P(gb), self.rows, dy.shape[1],
-                                            x.shape[1], self._prec, P(self.ws_tn), self._st()),
+                                            x.shape[1], self._prec, 0, P(self.ws_tn), self._st()),
                       "gemm_tn(wgrad)")
 
     # ---- the step body (capturable) ----------------------------------------------------------------------------
@@ -505,7 +530,7 @@ class FusedTrainer(object):
             qkv = st["qkv"]
             self.LB.check(lib.ltrx_mha_fwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(kpm), B, L, self.h,
                                            d // self.h, 3 * d, P(st["o"]), d, P(st["lse"]), dp(st["p_att"]), st["s_att"],
-                                           P(self.drop_step), P(self.cu), P(self.order), self._st()), "mha_fwd")
+                                           P(self.drop_step), P(self.cu), P(self.order), self._mha_mode, self._st()), "mha_fwd")
             lo = lay.self_attn.linears[3]
             self._lin_fwd(st["o"], W(lo.weight), W(lo.bias), self.branch)
             self._ln_fwd(x, self.branch, W(n1.a_2), W(n1.b_2), st["x1"], st["xn1"], st["mean1"], st["rstd1"],
@@ -598,7 +623,7 @@ class FusedTrainer(object):
                 self.LB.check(lib.ltrx_mha_bwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(kpm), P(st["o"]),
                                                P(self.d_o), P(st["lse"]), B, L, self.h, d // self.h, 3 * d, d, P(dq),
                                                dq.data_ptr() + 4 * d, dq.data_ptr() + 8 * d, 3 * d, st["p_att"], st["s_att"],
-                                               P(self.drop_step), P(self.cu), P(self.order), P(self.ws_mha), self._st()),
+                                               P(self.drop_step), P(self.cu), P(self.order), self._mha_mode, P(self.ws_mha), self._st()),
                               "mha_bwd")
                 if self.compact and M > self.n_valid:              # alignment rows belong to no slate: no gradient
                     dq[self.n_valid:M].zero_()
@@ -655,18 +680,8 @@ class FusedTrainer(object):
 
     def _full(self):
         self.LB.check(self.lib.ltrx_bump_u32(self.LB.ptr(self.drop_step), self._st()), "bump_u32")   # fresh masks every step
-        if self.gemm == "bf16":          # the attention arithmetic is a library-wide switch: one-product kernels for this step only
-            prev = self.lib.ltrx_mha_get_mode()
-            self.lib.ltrx_mha_set_mode(2)
-            try:
-                loss = self._body()
-            finally:
-                self.lib.ltrx_mha_set_mode(prev)
-        else:
-            loss = self._body()
-        for w_ in self._works:                                   # bucketed gradient all-reduces launched during the backward
-            w_.wait()
-        self._works = []
+        loss = self._body()
+        self._wait_buckets()
         self._adam()
         self._refresh_transposes()
         return loss
@@ -676,7 +691,7 @@ class FusedTrainer(object):
         captured graph is dropped and re-captured on the next step"""
         if float(lr) != float(self.lr):
             self.lr = float(lr)
-            self.graph = None
+            self._graphs.clear()
 
     def _pack(self, xb, lengths):
         """compact mode: build idx / cu_seqlens for this batch and gather the valid rows of xb into x_in.  ``lengths`` (host
@@ -750,30 +765,71 @@ class FusedTrainer(object):
                 self.idx_rows[:self.n_valid] = indices.reshape(-1)[self.idx[:self.n_valid].long()]
             else:
                 self.idx_rows.copy_(indices.reshape(-1))
-        if not self.use_graph or self.world > 1:
-            with sharding.shard_context(int(self._divisor), self.group) if self.world > 1 else _null():
-                return self._full()
-        if self.graph is None:
-            if self._warm < 2:                        # warm up hipBLASLt heuristics / workspaces outside capture
-                self._warm += 1
-                return self._full()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._graph_loss = self._full()       # capture only records; the replay below executes this step
-        self.graph.replay()
+        if not self.use_graph:
+            return self._eager()
+        # The batch divisor is a by-value launch argument of the loss kernels (include/ltrx.h: `batch_divisor`), i.e. a captured
+        # step keeps the divisor it was captured with.  Captured steps are therefore keyed by the divisor: the short last batch of
+        # an epoch (DataLoader drop_last=False, dataset_loading.py:245; it arrives topped up with padded slates and global_batch =
+        # its real slate count) gets its own capture; beyond four distinct divisors a step runs eagerly.
+        key = (self._divisor, bool(self.comm_enabled))
+        segs = self._graphs.get(key)
+        if segs is None:
+            if self._warm < 2 or len(self._graphs) >= 4:
+                self._warm += 1                       # warm-up outside capture (lazy module loads, kernel attributes, workspaces)
+                return self._eager()
+            segs = self._graphs[key] = self._capture()
+        for g, after in segs:                         # (capture only records: the replay executes this step)
+            g.replay()
+            if after is not None:
+                after()
         return self._graph_loss
+
+    def _eager(self):
+        with sharding.shard_context(int(self._divisor), self.group) if self.world > 1 else _null():
+            return self._full()
+
+    @property
+    def graph(self):
+        """the captured full-batch step (None before capture)"""
+        return self._graphs.get((float(self.B * self.world), bool(self.comm_enabled)))
+
+    def _capture(self):
+        """Record the step as a chain of hipGraph segments.  On one GPU that is a single graph.  Sharded (world > 1), every
+        collective of the step -- the bucketed gradient all-reduces, the wait before Adam, and the one-float all-reduce of a
+        batch-global loss normaliser (sharding.allreduce_sum_) -- ends the segment being recorded and is kept as the host
+        action to run between two replays: the compute of a step is ~75 launches of 10-300 us at 64 slates per GPU (launch
+        latency matters exactly where 8-GPU runs sit), while the collectives stay ordinary torch.distributed calls on the
+        process group's stream, whatever the backend (RCCL on a node, gloo in the one-GPU tests)."""
+        if self._graph_pool is None:
+            self._graph_pool = torch.cuda.graph_pool_handle()
+            self._cap_stream = torch.cuda.Stream(device=self.dev)
+        segs = []
+        torch.cuda.synchronize(self.dev)
+        self._cap_stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self._cap_stream):
+            cur = [torch.cuda.CUDAGraph()]
+            cur[0].capture_begin(pool=self._graph_pool)
+
+            def seg_break(after):
+                cur[0].capture_end()
+                segs.append((cur[0], after))
+                cur[0] = torch.cuda.CUDAGraph()
+                cur[0].capture_begin(pool=self._graph_pool)
+
+            self._seg_break = seg_break
+            try:
+                with sharding.shard_context(int(self._divisor), self.group, deferred=seg_break) if self.world > 1 else _null():
+                    self._graph_loss = self._full()
+            finally:
+                self._seg_break = None
+                cur[0].capture_end()
+            segs.append((cur[0], None))
+        torch.cuda.current_stream(self.dev).wait_stream(self._cap_stream)
+        return segs
 
 
     def _fwd_only(self):
-        if self.gemm == "bf16":
-            prev = self.lib.ltrx_mha_get_mode()
-            self.lib.ltrx_mha_set_mode(2)
-            try:
-                self._forward(False)
-            finally:
-                self.lib.ltrx_mha_set_mode(prev)
-        else:
-            self._forward(False)
+        self._forward(False)
 
     def score(self, xb, yb, indices=None, lengths=None):
         """``model.score(xb, yb == PADDED_Y_VALUE, indices)`` in eval mode (model.py:82-92) through the kernels of the training

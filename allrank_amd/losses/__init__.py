@@ -6,6 +6,9 @@ supports ``.backward()`` / ``.item()``.  The arithmetic runs in ONE fused HIP ke
 d loss / d y_pred together; libltrx.so, include/ltrx.h); the autograd node only scales the stored gradient.
 Inputs are never mutated.  Device tensors only -- there is no CPU fallback.
 """
+import contextlib
+import threading
+
 import torch
 
 from .. import _lib as L
@@ -127,6 +130,23 @@ def lambdaLoss(y_pred, y_true, eps=DEFAULT_EPS, padded_value_indicator=PADDED_Y_
 
 
 _last_iters = {"t": None}
+_neural_tls = threading.local()
+
+
+@contextlib.contextmanager
+def neural_kernel_path(path):
+    """test hook (thread-local, scoped): 1 = run the general L2-streaming Sinkhorn kernels even where the register-resident
+    ones apply (L <= 240); the value is passed as the ``path`` argument of every ltrx_neuralndcg_fwd_bwd call in the region."""
+    prev = getattr(_neural_tls, "path", 0)
+    _neural_tls.path = int(path)
+    try:
+        yield
+    finally:
+        _neural_tls.path = prev
+
+
+def _neural_path():
+    return getattr(_neural_tls, "path", 0)
 
 
 def sinkhorn_iterations_used():
@@ -147,7 +167,7 @@ def _neural_call(yp, yt, idcg, cnt, kk, k_rows, padded_value_indicator, temperat
     L.check(lib.ltrx_neuralndcg_fwd_bwd(L.ptr(yp), L.ptr(yt), L.ptr(idcg), L.ptr(cnt), B, SL,
                                         float(padded_value_indicator), float(temperature),
                                         1 if powered_relevancies else 0, kk, L.ptr(k_rows), 1 if transposed else 0,
-                                        int(max_iter), float(tol), L.ptr(loss), None, L.ptr(grad), L.ptr(iters), L.ptr(ws),
+                                        int(max_iter), float(tol), L.ptr(loss), None, L.ptr(grad), L.ptr(iters), _neural_path(), L.ptr(ws),
                                         L.stream_of(yp)), "neuralndcg")
     _last_iters["t"] = iters
     return loss, grad
@@ -469,6 +489,6 @@ class FusedLoss(object):
             rc = lib.ltrx_neuralndcg_fwd_bwd(L.ptr(yp), L.ptr(yt), L.ptr(self.idcg), L.ptr(self.cnt), B, SL, self.pad,
                                              float(a.get("temperature", 1.)), 1 if pw else 0, kk, None, 1 if tr else 0, self.max_iter,
                                              float(a.get("tol", 1e-6)), L.ptr(self.loss), None, L.ptr(self.grad), None,
-                                             L.ptr(self.ws), st)
+                                             _neural_path(), L.ptr(self.ws), st)
         L.check(rc, n)
         return self.loss, self.grad

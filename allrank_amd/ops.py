@@ -3,9 +3,62 @@
 PyTorch owns the tensors and the autograd graph edges; all arithmetic happens in the HIP kernels behind the C ABI
 (include/ltrx.h).  Device tensors only, fp32, no CPU fallback.
 """
+import contextlib
+import threading
+
 import torch
 
 from . import _lib as L
+
+# ------------------------------------------------------------------------------------------------------------------
+# Arithmetic of the nn.Module path.  The C ABI keeps no mode of its own (every ltrx_* call carries its precision / mode
+# argument, include/ltrx.h); what the autograd bindings below pass is a PYTHON-side setting: a process default
+# (set_linear_backend / set_attention_mode) that a thread can override for a region with ``arithmetic(...)`` -- so the
+# reference's DataParallel replica threads, or a trainer beside a validation pass, never see each other's choice.
+#   attention mode 1 (default): three bf16 products per fp32 product on the bf16 MFMA (fp32-class, like the projections);
+#   0: exact fp32 MFMA everywhere (the strict reference); 2: ONE bf16 product (throughput mode, outside the parity contract).
+# ------------------------------------------------------------------------------------------------------------------
+_DEFAULT = {"linear": "split_bf16", "attention": 1}
+_tls = threading.local()
+
+
+def _setting(key):
+    ov = getattr(_tls, "override", None)
+    if ov and ov.get(key) is not None:
+        return ov[key]
+    return _DEFAULT[key]
+
+
+@contextlib.contextmanager
+def arithmetic(linear=None, attention=None):
+    """thread-local override of the nn.Module path's arithmetic for the enclosed region, e.g.
+    ``with ops.arithmetic(linear="hipblaslt", attention=0): ...`` = exact-fp32 projections and attention (the strict bar)."""
+    if linear is not None and linear not in ("split_bf16", "hipblaslt"):
+        raise ValueError("linear backend must be split_bf16 or hipblaslt")
+    if attention is not None and attention not in (0, 1, 2):
+        raise ValueError("attention mode must be 0 (exact fp32), 1 (split-bf16) or 2 (plain bf16)")
+    prev = getattr(_tls, "override", None)
+    cur = dict(prev or {})
+    if linear is not None:
+        cur["linear"] = linear
+    if attention is not None:
+        cur["attention"] = attention
+    _tls.override = cur
+    try:
+        yield
+    finally:
+        _tls.override = prev
+
+
+def set_attention_mode(mode):
+    """process default of the attention arithmetic of the nn.Module path (see ``arithmetic`` for a scoped, per-thread override)"""
+    if mode not in (0, 1, 2):
+        raise ValueError("attention mode must be 0, 1 or 2")
+    _DEFAULT["attention"] = int(mode)
+
+
+def get_attention_mode():
+    return int(_setting("attention"))
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -82,10 +135,11 @@ class _AttentionFn(torch.autograd.Function):
         mask = key_pad_mask.to(torch.uint8).contiguous()
         o = torch.empty((B, SL, d), dtype=torch.float32, device=q.device)
         lse = torch.empty((B, h, SL), dtype=torch.float32, device=q.device)
+        mode = get_attention_mode()
         L.check(L.lib().ltrx_mha_fwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), B, SL, h, dk, rs, L.ptr(o), d, L.ptr(lse),
-                                     float(p_drop), int(seed) & 0xFFFFFFFF, None, None, None, L.stream_of(q)), "mha_fwd")
+                                     float(p_drop), int(seed) & 0xFFFFFFFF, None, None, None, mode, L.stream_of(q)), "mha_fwd")
         ctx.save_for_backward(q, k, v, mask, o, lse)
-        ctx.h = h
+        ctx.h, ctx.mode = h, mode
         ctx.p_drop, ctx.seed = float(p_drop), int(seed) & 0xFFFFFFFF
         return o
 
@@ -102,7 +156,7 @@ class _AttentionFn(torch.autograd.Function):
         lib = L.lib()
         ws = L.workspace(lib.ltrx_mha_bwd_workspace_bytes(B, SL, h), o)
         L.check(lib.ltrx_mha_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), L.ptr(o), L.ptr(do), L.ptr(lse), B, SL, h, dk_,
-                                 q.stride(1), d, L.ptr(dq), L.ptr(dkk), L.ptr(dv), 3 * d, ctx.p_drop, ctx.seed, None, None, None, L.ptr(ws),
+                                 q.stride(1), d, L.ptr(dq), L.ptr(dkk), L.ptr(dv), 3 * d, ctx.p_drop, ctx.seed, None, None, None, ctx.mode, L.ptr(ws),
                                  L.stream_of(o)), "mha_bwd")
         return dq, dkk, dv, None, None, None, None
 
@@ -121,10 +175,11 @@ class _AttentionPackedFn(torch.autograd.Function):
         mask = key_pad_mask.to(torch.uint8).contiguous()
         o = torch.empty((B, SL, d), dtype=torch.float32, device=qkv.device)
         lse = torch.empty((B, h, SL), dtype=torch.float32, device=qkv.device)
+        mode = get_attention_mode()
         L.check(L.lib().ltrx_mha_fwd(L.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, L.ptr(mask), B, SL, h, d // h, d3, L.ptr(o),
-                                     d, L.ptr(lse), float(p_drop), int(seed) & 0xFFFFFFFF, None, None, None, L.stream_of(qkv)), "mha_fwd")
+                                     d, L.ptr(lse), float(p_drop), int(seed) & 0xFFFFFFFF, None, None, None, mode, L.stream_of(qkv)), "mha_fwd")
         ctx.save_for_backward(qkv, mask, o, lse)
-        ctx.h, ctx.p_drop, ctx.seed = h, float(p_drop), int(seed) & 0xFFFFFFFF
+        ctx.h, ctx.p_drop, ctx.seed, ctx.mode = h, float(p_drop), int(seed) & 0xFFFFFFFF, mode
         return o
 
     @staticmethod
@@ -138,7 +193,7 @@ class _AttentionPackedFn(torch.autograd.Function):
         ws = L.workspace(lib.ltrx_mha_bwd_workspace_bytes(B, SL, h), o)
         L.check(lib.ltrx_mha_bwd(L.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, L.ptr(mask), L.ptr(o), L.ptr(do), L.ptr(lse),
                                  B, SL, h, d // h, 3 * d, d, L.ptr(dqkv), dqkv.data_ptr() + 4 * d, dqkv.data_ptr() + 8 * d, 3 * d,
-                                 ctx.p_drop, ctx.seed, None, None, None, L.ptr(ws), L.stream_of(o)), "mha_bwd")
+                                 ctx.p_drop, ctx.seed, None, None, None, ctx.mode, L.ptr(ws), L.stream_of(o)), "mha_bwd")
         return dqkv, None, None, None, None
 
 
@@ -160,16 +215,17 @@ def attention(q, k, v, key_pad_mask, h, p_drop=0.0, seed=None):
 # ------------------------------------------------------------------------------------------------------------------
 # nn.Linear on the split-bf16 GEMMs (the drop-in nn.Module path: allrank's own fit() / loss_batch, model.score(), validation)
 # ------------------------------------------------------------------------------------------------------------------
-_LINEAR_BACKEND = "split_bf16"
-
-
 def set_linear_backend(name):
-    """"split_bf16" (default): ``linear()`` runs ltrx_gemm_nt / ltrx_gemm_tn (fp32-accurate three-product bf16 MFMA GEMMs, the
-    arithmetic of the explicit step); "hipblaslt": torch's F.linear (exact-fp32 library GEMMs, 2-2.5x slower on MI355X)."""
-    global _LINEAR_BACKEND
+    """process default: "split_bf16" -- ``linear()`` runs ltrx_gemm_nt / ltrx_gemm_tn (fp32-accurate three-product bf16 MFMA GEMMs,
+    the arithmetic of the explicit step); "hipblaslt": torch's F.linear (exact-fp32 library GEMMs, 2-2.5x slower on MI355X).
+    ``arithmetic(linear=...)`` overrides it for one thread and region."""
     if name not in ("split_bf16", "hipblaslt"):
         raise ValueError("linear backend must be split_bf16 or hipblaslt")
-    _LINEAR_BACKEND = name
+    _DEFAULT["linear"] = name
+
+
+def _split_linear():
+    return _setting("linear") == "split_bf16"
 
 
 class _LinearFn(torch.autograd.Function):
@@ -185,7 +241,7 @@ class _LinearFn(torch.autograd.Function):
         M = x2.shape[0]
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
         L.check(L.lib().ltrx_gemm_nt(L.ptr(x2), K, L.ptr(w), K, L.ptr(y), N, M, N, K, L.ptr(b), int(act), None, 0, 0.0, 0, None, 0,
-                                     L.stream_of(x2)), "gemm_nt(linear fwd)")
+                                     0, L.stream_of(x2)), "gemm_nt(linear fwd)")
         ctx.save_for_backward(x2, w, y if act else None)
         ctx.has_bias, ctx.act, ctx.xshape = b is not None, int(act), x.shape
         return y.view(x.shape[:-1] + (N,))
@@ -205,7 +261,7 @@ class _LinearFn(torch.autograd.Function):
                 wT = w.t().contiguous()                          # [K, N]: the NT kernel wants both operands contraction-contiguous
                 dx = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
                 L.check(lib.ltrx_gemm_nt(L.ptr(dy2), N, L.ptr(wT), N, L.ptr(dx), K, M, K, N, None, 0, None, 0, 0.0, 0, None, 0,
-                                         L.stream_of(dy2)), "gemm_nt(linear dgrad)")
+                                         0, L.stream_of(dy2)), "gemm_nt(linear dgrad)")
             else:
                 dx = dy2 @ w
             dx = dx.view(ctx.xshape)
@@ -213,7 +269,7 @@ class _LinearFn(torch.autograd.Function):
             dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
             db = torch.empty(N, dtype=torch.float32, device=dy2.device) if ctx.has_bias else None
             ws = torch.empty(max(int(lib.ltrx_gemm_tn_workspace_bytes(M, N, K)), 64), dtype=torch.uint8, device=dy2.device)
-            L.check(lib.ltrx_gemm_tn(L.ptr(dy2), N, L.ptr(x2), K, L.ptr(dw), L.ptr(db), M, N, K, 0, L.ptr(ws), L.stream_of(dy2)),
+            L.check(lib.ltrx_gemm_tn(L.ptr(dy2), N, L.ptr(x2), K, L.ptr(dw), L.ptr(db), M, N, K, 0, 0, L.ptr(ws), L.stream_of(dy2)),
                     "gemm_tn(linear wgrad)")
         return dx, dw, db, None
 
@@ -221,7 +277,7 @@ class _LinearFn(torch.autograd.Function):
 def linear(x, w, b=None, act=0):
     """F.linear(x, w, b) (followed by ReLU when act == 1) for device tensors on the split-bf16 GEMMs; shapes the kernels do not
     take (in_features not a multiple of 4) and the "hipblaslt" backend go through torch."""
-    if _LINEAR_BACKEND != "split_bf16" or not x.is_cuda or w.shape[1] % 4 != 0 or x.dtype != torch.float32:
+    if not _split_linear() or not x.is_cuda or w.shape[1] % 4 != 0 or x.dtype != torch.float32:
         y = torch.nn.functional.linear(x, w, b)
         return torch.relu(y) if act else y
     return _LinearFn.apply(x, w, b, act)
@@ -243,9 +299,9 @@ class _FFNFn(torch.autograd.Function):
         lib, st = L.lib(), L.stream_of(x2)
         r = torch.empty((M, F_), dtype=torch.float32, device=x.device)
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        L.check(lib.ltrx_gemm_nt(L.ptr(x2), K, L.ptr(w1), K, L.ptr(r), F_, M, F_, K, L.ptr(b1), 1, None, 0, float(p), int(seed), None, 0, st),
+        L.check(lib.ltrx_gemm_nt(L.ptr(x2), K, L.ptr(w1), K, L.ptr(r), F_, M, F_, K, L.ptr(b1), 1, None, 0, float(p), int(seed), None, 0, 0, st),
                 "gemm_nt(ffn w_1)")
-        L.check(lib.ltrx_gemm_nt(L.ptr(r), F_, L.ptr(w2), F_, L.ptr(y), N, M, N, F_, L.ptr(b2), 0, None, 0, 0.0, 0, None, 0, st),
+        L.check(lib.ltrx_gemm_nt(L.ptr(r), F_, L.ptr(w2), F_, L.ptr(y), N, M, N, F_, L.ptr(b2), 0, None, 0, 0.0, 0, None, 0, 0, st),
                 "gemm_nt(ffn w_2)")
         ctx.save_for_backward(x2, w1, w2, r)
         ctx.p, ctx.xshape = float(p), x.shape
@@ -264,21 +320,21 @@ class _FFNFn(torch.autograd.Function):
             gw = torch.empty((n, k), dtype=torch.float32, device=dev)
             gb = torch.empty(n, dtype=torch.float32, device=dev)
             ws = torch.empty(max(int(lib.ltrx_gemm_tn_workspace_bytes(M, n, k)), 64), dtype=torch.uint8, device=dev)
-            L.check(lib.ltrx_gemm_tn(L.ptr(a), n, L.ptr(b_), k, L.ptr(gw), L.ptr(gb), M, n, k, 0, L.ptr(ws), st), "gemm_tn(ffn wgrad)")
+            L.check(lib.ltrx_gemm_tn(L.ptr(a), n, L.ptr(b_), k, L.ptr(gw), L.ptr(gb), M, n, k, 0, 0, L.ptr(ws), st), "gemm_tn(ffn wgrad)")
             return gw, gb
 
         dw2, db2 = wgrad(dy2, r, N, F_)
         w2T = w2.t().contiguous()                                # [F, N]
         dr = torch.empty((M, F_), dtype=torch.float32, device=dev)
         # d r = (dy w_2) * [r > 0] / (1 - p): r is the post-ReLU, post-dropout activation, so its sign pattern IS the combined mask
-        L.check(lib.ltrx_gemm_nt(L.ptr(dy2), N, L.ptr(w2T), N, L.ptr(dr), F_, M, F_, N, None, 2, L.ptr(r), F_, ctx.p, 0, None, 0, st),
+        L.check(lib.ltrx_gemm_nt(L.ptr(dy2), N, L.ptr(w2T), N, L.ptr(dr), F_, M, F_, N, None, 2, L.ptr(r), F_, ctx.p, 0, None, 0, 0, st),
                 "gemm_nt(ffn dgrad w_2)")
         dw1, db1 = wgrad(dr, x2, F_, K)
         dx = None
         if ctx.needs_input_grad[0]:
             w1T = w1.t().contiguous()                            # [K, F]
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
-            L.check(lib.ltrx_gemm_nt(L.ptr(dr), F_, L.ptr(w1T), F_, L.ptr(dx), K, M, K, F_, None, 0, None, 0, 0.0, 0, None, 0, st),
+            L.check(lib.ltrx_gemm_nt(L.ptr(dr), F_, L.ptr(w1T), F_, L.ptr(dx), K, M, K, F_, None, 0, None, 0, 0.0, 0, None, 0, 0, st),
                     "gemm_nt(ffn dgrad w_1)")
             dx = dx.view(ctx.xshape)
         return dx, dw1, db1, dw2, db2, None, None
@@ -287,7 +343,7 @@ class _FFNFn(torch.autograd.Function):
 def feed_forward(x, w1, b1, w2, b2, p_drop=0.0, seed=None):
     """w_2(dropout_p(relu(w_1 x))) for device tensors; ``seed`` keys the dropout mask (default: drawn from torch's generator)."""
     dims_ok = w1.shape[1] % 4 == 0 and w1.shape[0] % 4 == 0 and w2.shape[0] % 4 == 0
-    if _LINEAR_BACKEND != "split_bf16" or not x.is_cuda or not dims_ok or x.dtype != torch.float32:
+    if not _split_linear() or not x.is_cuda or not dims_ok or x.dtype != torch.float32:
         h = torch.relu(torch.nn.functional.linear(x, w1, b1))
         return torch.nn.functional.linear(torch.nn.functional.dropout(h, p_drop, p_drop > 0), w2, b2)
     if p_drop and seed is None:
@@ -328,7 +384,7 @@ class _ScoreHeadFn(torch.autograd.Function):
 
 def score_head(x, w, b):
     """nn.Linear(d, 1)(x).squeeze(-1) for device tensors: w [1, d], b [1]"""
-    if _LINEAR_BACKEND != "split_bf16" or not x.is_cuda or x.dtype != torch.float32 or w.shape[0] != 1 or b is None:
+    if not _split_linear() or not x.is_cuda or x.dtype != torch.float32 or w.shape[0] != 1 or b is None:
         return torch.nn.functional.linear(x, w, b).squeeze(-1)
     return _ScoreHeadFn.apply(x, w, b)
 

@@ -10,7 +10,7 @@ across ranks by allrank_amd.parallel -- each rank already divides by the global 
 """
 import contextlib
 
-_state = {"global_batch": None, "group": None, "active": False}
+_state = {"global_batch": None, "group": None, "active": False, "deferred": None}
 
 
 def active():
@@ -30,15 +30,24 @@ def allreduce_sum_(t):
     """in-place all-reduce(sum) of a small device tensor across the shard group (no-op when not sharded)."""
     if _state["active"]:
         import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_state["group"])
+        grp = _state["group"]
+
+        def launch():
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=grp)
+        if _state["deferred"] is not None:     # a step is being captured: the collective runs between two hipGraph segments
+            _state["deferred"](launch)
+        else:
+            launch()
     return t
 
 
 @contextlib.contextmanager
-def shard_context(global_batch, group=None):
-    """with shard_context(global_batch=G): loss = approxNDCGLoss(scores_local, y_local)  # -> this rank's share"""
+def shard_context(global_batch, group=None, deferred=None):
+    """with shard_context(global_batch=G): loss = approxNDCGLoss(scores_local, y_local)  # -> this rank's share
+    ``deferred(launch)``: instead of issuing a normaliser all-reduce, hand it to this callback (FusedTrainer._capture: the
+    collective becomes the host action between two captured segments of the step)."""
     prev = dict(_state)
-    _state.update(global_batch=int(global_batch), group=group, active=True)
+    _state.update(global_batch=int(global_batch), group=group, active=True, deferred=deferred)
     try:
         yield
     finally:

@@ -116,7 +116,7 @@ def time_kernels(w, B, L, device):
         C_ = torch.empty(Mrows, Nn, device=device)
         st = LB.stream_of(A_)
         t_g = ev(lambda: LB.check(lib.ltrx_gemm_nt(LB.ptr(A_), Kk, LB.ptr(W_), Kk, LB.ptr(C_), Nn, Mrows, Nn, Kk, LB.ptr(b_), 1,
-                                                   None, 0, 0.0, 0, None, 0, st), "gemm_nt"))
+                                                   None, 0, 0.0, 0, None, 0, 0, st), "gemm_nt"))
         n_nt = 1 + 8 * w["N"] - 1          # fwd: fc + 4/layer; dgrad: 4/layer  (head GEMV is a separate kernel)
         _t256 = ((Mrows + 255) // 256) * (Nn // 256)
         big = (Nn % 256 == 0 and Kk % 32 == 0 and (_t256 >= 360 or 168 <= _t256 <= 256))   # ltrx_gemm.hip dispatch
@@ -141,11 +141,11 @@ def time_kernels(w, B, L, device):
         ws_ = torch.empty(max(lib.ltrx_mha_bwd_workspace_bytes(B, L, h), 64), dtype=torch.uint8, device=device)
         st2 = LB.stream_of(qkv)
         t_f = ev(lambda: LB.check(lib.ltrx_mha_fwd(LB.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, LB.ptr(m8), B, L, h, dk,
-                                                   3 * d, LB.ptr(o_), d, LB.ptr(lse_), 0.0, 0, None, None, None, st2), "mha_fwd"))
+                                                   3 * d, LB.ptr(o_), d, LB.ptr(lse_), 0.0, 0, None, None, None, 1, st2), "mha_fwd"))
         res["ltrx_mha_fwd (res split-bf16)"] = dict(sec=t_f, flops=fl, launches_per_step=w["N"])
         t_b = ev(lambda: LB.check(lib.ltrx_mha_bwd(LB.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, LB.ptr(m8), LB.ptr(o_),
                                                    LB.ptr(go), LB.ptr(lse_), B, L, h, dk, 3 * d, d, LB.ptr(dqkv), dqkv.data_ptr() + 4 * d,
-                                                   dqkv.data_ptr() + 8 * d, 3 * d, 0.0, 0, None, None, None, LB.ptr(ws_), st2), "mha_bwd"))
+                                                   dqkv.data_ptr() + 8 * d, 3 * d, 0.0, 0, None, None, None, 1, LB.ptr(ws_), st2), "mha_bwd"))
         res["ltrx_mha_bwd (dq+dkdv, res split-bf16)"] = dict(sec=t_b, flops=2.5 * fl, launches_per_step=w["N"])
         x = torch.randn(B * L, d, device=device)
         r = torch.randn(B * L, d, device=device)
@@ -296,7 +296,7 @@ def gemm_error_vs_fp64(w, B, L, device, gemm):
         torch.addmm(b_, A_, W_.t(), out=C_)
     else:
         LB.check(lib.ltrx_gemm_nt(LB.ptr(A_), Kk, LB.ptr(W_), Kk, LB.ptr(C_), Nn, Mrows, Nn, Kk, LB.ptr(b_), 0, None, 0, 0.0, 0, None,
-                                  {"split_bf16_strict": 1, "bf16": 2}.get(gemm, 0), LB.stream_of(A_)), "gemm_nt")
+                                  {"split_bf16_strict": 1, "bf16": 2}.get(gemm, 0), 0, LB.stream_of(A_)), "gemm_nt")
     rows = torch.linspace(0, Mrows - 1, min(4096, Mrows), device=device).long()
     ref = A_[rows].double() @ W_.double().t() + b_.double()
     scale = (A_[rows].abs().double() @ W_.abs().double().t()).max()

@@ -12,8 +12,11 @@
  *   - every tensor is caller-owned, dense row-major fp32 unless stated; kernels never allocate, never
  *     retain pointers, never synchronise the device, and enqueue on the given stream only.
  *   - y_true uses `pad_value` (-1 in allRank, allrank/data/dataset_loading.py:15) to mark padded slots.
+ *   - re-entrant: no entry point reads or writes process-global mode switches; arithmetic / path / tile choices are
+ *     arguments of the call that uses them.  (The only state kept is a per-device "kernel attributes already set" bit.)
  *   - return value: 0 = ok; LTRX_EINVAL bad argument; LTRX_EUNSUPPORTED shape outside the supported
- *     range; LTRX_EHIP a HIP launch error (hipGetLastError code is returned as -(1000+code)).
+ *     range (slate length above LTRX_MAX_SLATE_LEN for a loss, LTRX_MAX_METRIC_SLATE_LEN for a metric -- the
+ *     Python wrappers name the limit in the exception; there is no silent fallback); LTRX_EHIP a HIP launch error (hipGetLastError code is returned as -(1000+code)).
  *   - `batch_divisor`: the number of slates the reference would have averaged over.  On one GPU it is B;
  *     under slate sharding it is the GLOBAL batch so that summing per-rank results reproduces the
  *     reference's loss on the gathered batch.
@@ -29,14 +32,16 @@
 extern "C" {
 #endif
 
-#define LTRX_VERSION 100 /* 0.1.0 */
+#define LTRX_VERSION 110 /* 0.1.1: mode / tile / path are call arguments (round 3) */
 
 #define LTRX_OK 0
 #define LTRX_EINVAL (-1)
 #define LTRX_EUNSUPPORTED (-2)
 #define LTRX_EHIP (-1000)
 
-#define LTRX_MAX_SLATE_LEN 2048 /* loss / metric kernels stage a slate in LDS */
+#define LTRX_MAX_SLATE_LEN 2048        /* loss kernels stage a slate (and its per-item work arrays) in LDS */
+#define LTRX_MAX_METRIC_SLATE_LEN 8192 /* ltrx_ndcg_at / ltrx_mrr_at: validation sets are padded to their longest slate
+                                          (allrank/data/dataset_loading.py:185-194); 16 B per item of the 160 KB LDS */
 
 typedef void* ltrx_stream_t;
 
@@ -103,16 +108,16 @@ int ltrx_lambdaloss_fwd_bwd(const float* y_pred, const float* y_true, int B, int
  * (loss_utils.py:25) is batch-global as in the reference; iters_out[1] (int32, optional) = iterations used.
  * k_rows[B] (int32, device, optional): a per-slate cap on the ranks that carry a discount (min(k, k_rows[b])) -- the
  * stochastic variant (loss_utils.py:84-112) masks the permutation rows by the TRUE slate's padding (neuralNDCG.py:44)
- * while sorting each perturbed copy under another slate's mask (mask.repeat_interleave, :36/:41). */
+ * while sorting each perturbed copy under another slate's mask (mask.repeat_interleave, :36/:41).
+ * path: 0 = automatic (register-resident Sinkhorn kernels when L <= 240), 1 = always the general L2-streaming kernels (same
+ * results; a per-call argument so that tests can pin either path without any process state). */
 size_t ltrx_neuralndcg_workspace_bytes(int B, int L, int max_iter);
-/* test hook: 1 = always use the general L2-streaming kernels (default 0: register-resident fast path when L <= 240) */
-void ltrx_neuralndcg_force_general(int on);
 int ltrx_neuralndcg_prepare(const float* y_true, int B, int L, float pad_value, int k, int idcg_powered,
                             float* idcg_out, float* nonzero_count_out, void* ws, ltrx_stream_t stream);
 int ltrx_neuralndcg_fwd_bwd(const float* y_pred, const float* y_true, const float* idcg, const float* nonzero_count,
                             int B, int L, float pad_value, float temperature, int powered_relevancies, int k,
                             const int32_t* k_rows, int transposed, int max_iter, float tol, float* loss_out, float* per_slate_out,
-                            float* grad_out, int32_t* iters_out, void* ws, ltrx_stream_t stream);
+                            float* grad_out, int32_t* iters_out, int path, void* ws, ltrx_stream_t stream);
 
 /* allrank/models/metrics.py:7-77   ndcg(y_pred, y_true, ats, gain=2^x-1, padding_indicator, filler_value)
  * ats[n_ats] is a HOST array.  ndcg_out[B,n_ats]; dcg_out[B,n_ats] optional; order_out[B,L] (int64, optional)
@@ -192,23 +197,26 @@ int ltrx_layernorm_bwd(const float* dy, const float* xsum, const float* a, const
  * lse / delta); key_pad_mask may be NULL in that layout (every packed row is a valid key).
  * slate_order (i32[B] in device memory, or NULL): a permutation of the slates giving the order in which their workgroups are
  * launched -- longest first balances the CUs on ragged batches; results do not depend on it. */
-/* arithmetic of the attention contractions: 1 (default) = split-bf16 on the bf16 MFMA (3 products per fp32 product, fp32-class,
+/* `mode` = arithmetic of the attention contractions OF THIS CALL (the library keeps no mode; the backward must be given the
+ * mode of its forward): 1 = split-bf16 on the bf16 MFMA (3 products per fp32 product, fp32-class,
  * like the dense projections) with the whole slate resident in LDS, used wherever the shape fits (slate length <= 256,
  * 32 < d_k <= 64; dropout and variable-length batches included); 0 = exact fp32 MFMA (bit-exact fp32 products) for every
  * shape -- the strict reference; 2 = the kernels of mode 1 with ONE bf16 product per contraction (plain-bf16 throughput mode,
  * about 2^-9 relative error per product: outside the parity contract, reported separately by bench.py).  Shapes that do not
  * fit always run the exact kernels. */
-void ltrx_mha_set_mode(int mode);
-int ltrx_mha_get_mode(void);
+#define LTRX_MHA_EXACT_FP32 0
+#define LTRX_MHA_SPLIT_BF16 1
+#define LTRX_MHA_PLAIN_BF16 2
 int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, int B, int L, int h,
                  int d_k, int row_stride, float* o, int o_row_stride, float* lse_out, float p_drop, uint32_t seed,
-                 const uint32_t* seed_step, const int32_t* cu_seqlens, const int32_t* slate_order, ltrx_stream_t stream);
+                 const uint32_t* seed_step, const int32_t* cu_seqlens, const int32_t* slate_order, int mode,
+                 ltrx_stream_t stream);
 /* backward: dq,dk,dv from do; delta_ws[B,h,L] scratch (rowsum(do*o)). */
 size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h);
 int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, const float* o,
                  const float* dout, const float* lse, int B, int L, int h, int d_k, int row_stride, int o_row_stride,
                  float* dq, float* dk, float* dv, int d_row_stride, float p_drop, uint32_t seed,
-                 const uint32_t* seed_step, const int32_t* cu_seqlens, const int32_t* slate_order, void* ws,
+                 const uint32_t* seed_step, const int32_t* cu_seqlens, const int32_t* slate_order, int mode, void* ws,
                  ltrx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -283,16 +291,18 @@ int ltrx_score_head_bwd(const float* dscores, const float* x, const float* w, in
  *                 bias_out[NP] (optional) = column sums of A = the bias gradient, produced in the same pass. */
 int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,
                  int act, const float* aux, int ldaux, float drop_p, uint32_t drop_seed, const uint32_t* drop_step, int strict,
-                 ltrx_stream_t stream);
-/* tuning hook: tile variant of ltrx_gemm_nt (0 auto, 1 128x128x32, 2 128x128x64, 3 256x128x32, 4 256x128x64) */
-void ltrx_gemm_set_variant(int variant);
+                 int tile, ltrx_stream_t stream);
+/* `tile` (both GEMMs) is a per-call tuning argument: 0 = automatic choice per shape (what every product call passes);
+ * ltrx_gemm_nt: 1 128x128x32, 2 128x128x64, 3 256x128x32, 4 256x128x64, 6 256x256x32, 7 128x256x32 (the large-tile forms
+ * need N % 256 == 0, K % 32 == 0); ltrx_gemm_tn: 1 = the 128x128 kernel even where the 256x256 one applies.  Results do not
+ * depend on it beyond fp32 summation order. */
 /* workspace for ltrx_gemm_tn sized for M rows: sufficient for EVERY call with the same NP, KP and any row count <= M
  * (variable-length batches re-use one workspace); ltrx_gemm_tn_splits = the split count a call with exactly M rows uses
  * (each split owns an [NP,KP] slab + 2 bias rows of the workspace). */
 size_t ltrx_gemm_tn_workspace_bytes(int M, int NP, int KP);
 int ltrx_gemm_tn_splits(int M, int NP, int KP);
 int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, float* bias_out, int M, int NP, int KP, int strict,
-                 void* ws, ltrx_stream_t stream);
+                 int tile, void* ws, ltrx_stream_t stream);
 
 /* Model options around the encoder on the explicit step (allrank_amd/csrc/ltrx_extras.hip):
  *   ltrx_layernorm_torch_fwd: FCModel.input_norm = nn.LayerNorm(n_features) (model.py:27,39): biased variance, eps inside the

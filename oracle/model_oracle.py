@@ -190,8 +190,13 @@ def forward(p, cfg, x, mask):
     return y, cache
 
 
-def backward(p, cfg, cache, gscores):
-    """returns dict of parameter gradients (same keys as p)."""
+def backward(p, cfg, cache, gscores, relu_masks=None, fc_relu_masks=None):
+    """returns dict of parameter gradients (same keys as p).  relu_masks (optional, one bool [B, L, d_ff] array per encoder
+    layer): the feed-forward ReLU derivative pattern to differentiate through instead of this forward's own (z > 0).  ReLU is
+    not differentiable at 0, so two fp32-class evaluations of the same weights legitimately pick different branches for the
+    few units whose pre-activation is within round-off of 0; a parity test that hands in the ENGINE's pattern compares the two
+    gradients on the same branch (and counts the differing units separately).  fc_relu_masks: the same for the FCModel
+    activations (one bool array per FC layer, ReLU stacks only)."""
     grads = {}
     B, L = gscores.shape
     _, oact_b = ACTS[cfg.get("output_activation")]
@@ -206,7 +211,7 @@ def backward(p, cfg, cache, gscores):
         d = lc["x0"].shape[-1]
         dk = d // H
         gr = linear_bwd(lc["r"], p[pre + "feed_forward.w_2.weight"], g, grads, pre + "feed_forward.w_2")
-        gzz = gr * (lc["z"] > 0)
+        gzz = gr * ((lc["z"] > 0) if relu_masks is None else relu_masks[n])
         gxn = linear_bwd(lc["xn1"], p[pre + "feed_forward.w_1.weight"], gzz, grads, pre + "feed_forward.w_1")
         g = g + custom_ln_bwd(lc["ln1"], p[pre + "sublayer.1.norm.a_2"], gxn, grads, pre + "sublayer.1.norm")
         goc = linear_bwd(lc["oc"], p[pre + "self_attn.linears.3.weight"], g, grads, pre + "self_attn.linears.3")
@@ -223,7 +228,7 @@ def backward(p, cfg, cache, gscores):
     nfc = len(cfg.get("fc_sizes") or [])
     for i in reversed(range(nfc)):
         hin, z, y = cache["fc"][i]
-        g = act_b(z, y, g)
+        g = act_b(z, y, g) if fc_relu_masks is None else g * fc_relu_masks[i]
         g = linear_bwd(hin, p["input_layer.layers.%d.weight" % i], g, grads, "input_layer.layers.%d" % i)
     if cfg.get("fc_input_norm"):
         torch_ln_bwd(cache["in_ln"], p["input_layer.input_norm.weight"], g, grads, "input_layer.input_norm")

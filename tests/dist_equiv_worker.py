@@ -46,6 +46,28 @@ def main():
         assert gerr < 1e-4, (loss_name, "grad", gerr)
         werr = (ft.flat_p - f1.flat_p).abs().max().item()
         assert werr <= 2.1e-3, (loss_name, "weights", werr)   # one Adam step of lr=1e-3; ~0-gradient params may flip sign
+    # the CAPTURED sharded step (hipGraph segments with the collectives between them, engine.FusedTrainer._capture) == the
+    # eager sharded step, bit for bit, step after step (same kernels, same order, same collectives), and == the one-rank step
+    # on the gathered batch; five steps = two eager warm-ups, the capture step, two replays
+    lo, hi = parallel.shard_slates(G, rank, world)
+    for loss_name, args in (("approxNDCGLoss", {}), ("neuralNDCG", {}), ("lambdaLoss", dict(weighing_scheme="lambdaRank_scheme", reduction="mean"))):
+        m_g, m_e, m_1 = build(), build(), build()
+        tg = FusedTrainer(m_g, loss_name, args, hi - lo, L, lr=1e-3, world_size=world, use_graph=True)
+        te = FusedTrainer(m_e, loss_name, args, hi - lo, L, lr=1e-3, world_size=world, use_graph=False)
+        t1 = FusedTrainer(m_1, loss_name, args, G, L, lr=1e-3, world_size=1, use_graph=True)
+        for step in range(5):
+            lg = tg.step(x[lo:hi], y[lo:hi], global_batch=G).clone()
+            le = te.step(x[lo:hi], y[lo:hi], global_batch=G).clone()
+            l1 = t1.step(x, y).clone()
+            assert torch.equal(lg, le), (loss_name, step, "graph vs eager loss", lg.item(), le.item())
+            assert torch.equal(tg.flat_p, te.flat_p), (loss_name, step, "graph vs eager weights")
+            tot = lg.clone()
+            dist.all_reduce(tot)
+            if step == 0:          # (free-running Adam trajectories decorrelate after the first update; step 0 is exact algebra)
+                assert abs(tot.item() - l1.item()) <= 1e-5 * (1 + abs(l1.item())), (loss_name, tot.item(), l1.item())
+                gerr = (tg.flat_g - t1.flat_g).abs().max().item() / max(t1.flat_g.abs().max().item(), 1e-12)
+                assert gerr < 2e-4, (loss_name, "grad vs one rank", gerr)
+        assert tg.graph is not None and len(tg.graph) >= 1 + len(tg._buckets), (loss_name, "segments", None if tg.graph is None else len(tg.graph))
     # count-normalised pointwise losses through the plugin functions: the rank shares (each divided by the GLOBAL count,
     # all-reduced inside the loss) add up to the single-process value, and so do the gradients
     from allrank_amd import losses as E, sharding

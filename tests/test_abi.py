@@ -29,13 +29,29 @@ def test_header_symbols_are_exported(libpath):
     for n in names:
         assert hasattr(h, n), "libltrx.so does not export %s declared in include/ltrx.h" % n
     h.ltrx_version.restype = ctypes.c_int
-    assert h.ltrx_version() == 100
+    assert h.ltrx_version() == 110
 
 
 def test_binding_table_matches_header(libpath):
     from allrank_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
-    assert _lib.lib().ltrx_version() == 100
+    assert _lib.lib().ltrx_version() == 110
+
+
+def test_slate_length_limits_are_stated_once_and_reported(libpath):
+    """the limits of include/ltrx.h, the constants the Python error message quotes, and the status code of an over-long slate
+    (returned before any HIP call, so this runs without a GPU)"""
+    from allrank_amd import _lib
+    src = open(os.path.join(ROOT, "include", "ltrx.h")).read()
+    assert int(re.search(r"#define LTRX_MAX_SLATE_LEN (\d+)", src).group(1)) == _lib.MAX_SLATE_LEN
+    assert int(re.search(r"#define LTRX_MAX_METRIC_SLATE_LEN (\d+)", src).group(1)) == _lib.MAX_METRIC_SLATE_LEN
+    lib = _lib.lib()
+    fake = ctypes.c_void_p(4096)                       # never dereferenced: the shape check comes first
+    ats = (ctypes.c_int * 1)(5)
+    assert lib.ltrx_ndcg_at(fake, fake, 1, _lib.MAX_METRIC_SLATE_LEN + 1, ats, 1, -1.0, 1.0, fake, None, None, None, None) == -2
+    assert lib.ltrx_listnet_fwd_bwd(fake, fake, 1, _lib.MAX_SLATE_LEN + 1, 1e-10, -1.0, 1.0, fake, None, None, fake, None) == -2
+    with pytest.raises(RuntimeError, match="LTRX_MAX_METRIC_SLATE_LEN = %d" % _lib.MAX_METRIC_SLATE_LEN):
+        _lib.check(-2, "ndcg_at")
 
 
 def test_workspace_queries_and_argument_validation_run_without_a_gpu(libpath):
@@ -46,7 +62,7 @@ def test_workspace_queries_and_argument_validation_run_without_a_gpu(libpath):
     assert lib.ltrx_mha_bwd_workspace_bytes(64, 240, 8) == 64 * 240 * 8 * 4
     # NULL pointers / bad shapes are rejected before any HIP call
     assert lib.ltrx_listnet_fwd_bwd(None, None, 1, 1, 1e-10, -1.0, 1.0, None, None, None, None, None) == -1
-    assert lib.ltrx_mha_fwd(None, None, None, None, 1, 1, 1, 64, 64, None, 64, None, 0.0, 0, None, None, None, None) == -1
+    assert lib.ltrx_mha_fwd(None, None, None, None, 1, 1, 1, 64, 64, None, 64, None, 0.0, 0, None, None, None, 1, None) == -1
 
 
 def test_wgrad_workspace_covers_every_smaller_row_count(libpath):

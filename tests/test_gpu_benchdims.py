@@ -7,7 +7,9 @@ large-tile kernels, and of configs[4] (F=1024, L=1024, ListMLE), against an fp64
 (oracle/model_oracle.py + oracle/ltr_oracle.py, the restatement of allrank/models/transformer.py:137-227, model.py:35-44):
 
   * at EVERY step the oracle is evaluated at the engine's current weights: loss within 1e-5 (north_star), scores
-    within 2e-5 of the score scale, EVERY parameter gradient compared relative to the largest entry of its OWN tensor;
+    within 2e-5 of the score scale, EVERY parameter gradient compared relative to the largest entry of its OWN tensor
+    (on the engine's ReLU branch; the units on the other branch are counted), NDCG@5 and the top-5 order of the engine's
+    scores against the oracle's;
   * after each step the updated weights are compared, every entry, with an fp64 replica of torch.optim.Adam driven by the
     engine's own gradients (tolerance: fp32 round-off of one update) -- see ``_run``.
 
@@ -38,15 +40,6 @@ def _log(name, obj):
         json.dump(obj, fh, indent=1, default=float)
 
 
-def _model(cfg, params):
-    from allrank_amd.model import make_model
-    tr = dict(N=cfg["N"], d_ff=cfg["d_ff"], h=cfg["h"], positional_encoding=None, dropout=0.0)
-    fc = dict(sizes=list(cfg["fc_sizes"]), input_norm=False, activation=None, dropout=0.0)
-    model = make_model(fc, tr, dict(d_output=1, output_activation=None), cfg["n_features"])
-    model.load_state_dict({k: torch.tensor(v) for k, v in params.items()}, strict=True)
-    return model.to(DEV)
-
-
 def _batch(rng, B, L, F, ragged):
     x = rng.standard_normal((B, L, F)).astype(np.float32)
     y = rng.choice(5, size=(B, L), p=[0.52, 0.32, 0.13, 0.02, 0.01]).astype(np.float32)
@@ -56,21 +49,70 @@ def _batch(rng, B, L, F, ragged):
     return x, y
 
 
-def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=None):
+def _model_any(cfg, params):
+    """the engine model of an oracle cfg (encoder optional, FC activation None / ReLU)"""
+    from allrank_amd.model import make_model
+    tr = dict(N=cfg["N"], d_ff=cfg["d_ff"], h=cfg["h"], positional_encoding=None, dropout=0.0) if cfg.get("N", 0) else None
+    fc = dict(sizes=list(cfg["fc_sizes"]), input_norm=False, activation=cfg.get("fc_activation"), dropout=0.0)
+    model = make_model(fc, tr, dict(d_output=1, output_activation=None), cfg["n_features"])
+    model.load_state_dict({k: torch.tensor(v) for k, v in params.items()}, strict=True)
+    return model.to(DEV)
+
+
+def _ndcg5_row(sc_engine, so, y, mask, score_err):
+    """NDCG@5 and the sort of the ENGINE's scores (through the engine's metric kernel) against the oracle's on the oracle's
+    fp64 scores, same weights (north_star: "NDCG@5 matching within 1e-5", metrics.py:7-28).  A slate is ILL-CONDITIONED for
+    this comparison when two of its six best items carry different labels and scores closer than twice the measured score
+    error: their order -- and with it NDCG@5 -- is decided below the resolution of ANY fp32 forward.  Everywhere else the
+    top-5 order must be identical and NDCG@5 within 1e-5; the ill-conditioned slates are counted and logged, never excused
+    silently."""
+    from allrank_amd import metrics as EM
+    B, L = y.shape
+    nd_e, ord_e = EM.ndcg(sc_engine, torch.tensor(y, device=DEV), ats=[5], return_order=True)
+    nd_e, ord_e = nd_e.cpu().numpy().astype(np.float64)[:, 0], ord_e.cpu().numpy()
+    nd_o, ord_o = O.ndcg(so, y, ats=[5], dtype=np.float64)
+    nd_o = nd_o[:, 0]
+    nv = (~mask).sum(1)
+    ill = np.zeros(B, dtype=bool)
+    top_same = np.ones(B, dtype=bool)
+    full_same = 0
+    for b in range(B):
+        n = int(nv[b])
+        top = ord_o[b, :min(6, n)]
+        ss, yy = so[b, top], y[b, top]
+        for i in range(len(top) - 1):
+            if ss[i] - ss[i + 1] < 2.0 * score_err and yy[i] != yy[i + 1]:
+                ill[b] = True
+        top_same[b] = np.array_equal(ord_e[b, :min(5, n)], ord_o[b, :min(5, n)])
+        full_same += int(np.array_equal(ord_e[b, :n], ord_o[b, :n]))
+    d = np.abs(nd_e - nd_o)
+    return dict(ndcg5_engine_mean=float(nd_e.mean()), ndcg5_oracle_mean=float(nd_o.mean()),
+                ndcg5_batch_mean_abs_delta=float(abs(nd_e.mean() - nd_o.mean())),
+                ndcg5_max_delta_well_conditioned=float(d[~ill].max()) if (~ill).any() else 0.0,
+                ndcg5_max_delta_all=float(d.max()), slates=B, slates_ill_conditioned=int(ill.sum()),
+                slates_top5_order_differs=int((~top_same).sum()),
+                slates_top5_order_differs_well_conditioned=int((~top_same & ~ill).sum()),
+                slates_full_valid_order_identical=full_same)
+
+
+def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=None, loss_args=None):
     """Per step: (a) the fp64 oracle's forward/backward AT THE ENGINE'S CURRENT WEIGHTS vs the engine's loss, scores and
     gradients -- identical weights on both sides at every step, so the 1e-5 loss bar applies to every step, not only the
-    first; (b) an fp64 Adam replica (torch.optim.Adam's recurrences, oracle/model_oracle.py:Adam) driven by the engine's
+    first; the oracle differentiates through the ENGINE's ReLU pattern (the saved activations of this very step;
+    oracle/model_oracle.py backward(relu_masks=)), the units on which the two patterns differ are counted; (b) an fp64 Adam
+    replica (torch.optim.Adam's recurrences, oracle/model_oracle.py:Adam) driven by the engine's
     own gradients vs the engine's updated weights -- every entry, to fp32 round-off: a moment / bias-correction error of
-    0.1 % of a step would show.  (Comparing two free-running trajectories instead is meaningless beyond the first step:
+    0.1 % of a step would show; (c) NDCG@5 and the sort of the engine's scores vs the oracle's (``_ndcg5_row``).
+    (Comparing two free-running trajectories instead is meaningless beyond the first step:
     Adam's first update is lr * sign(g), so the ~1 % of the 6.4 M entries whose gradient is below its own round-off move
     by +-lr with a random sign in ANY implementation and the scores drift apart by O(0.1) within three steps.)"""
     from allrank_amd.engine import FusedTrainer
     params32 = M.init_params(cfg, seed=seed)
-    model = _model(cfg, params32)
+    model = _model_any(cfg, params32)
     rng = np.random.default_rng(seed + 1)
     x, y = _batch(rng, B, L, cfg["n_features"], ragged)
     mask = y == -1
-    ft = FusedTrainer(model, loss_name, {}, B, L, lr=LR, use_graph=True, gemm=gemm)
+    ft = FusedTrainer(model, loss_name, dict(loss_args or {}), B, L, lr=LR, use_graph=True, gemm=gemm)
     if set_perm is not None:
         ft.shuffle_ties = False
         ft.loss.set_perm(torch.tensor(set_perm))
@@ -83,15 +125,29 @@ def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=
     for step in range(steps):
         w_before = {k: named[k].detach().cpu().numpy().astype(np.float64) for k in keys}
         loss = float(ft.step(xt, yt).item())
-        sc = ft.scores.detach().cpu().numpy().astype(np.float64)
+        sc_t = ft.scores.detach().clone()
+        sc = sc_t.cpu().numpy().astype(np.float64)
         g_eng = {k: named[k].grad.detach().cpu().numpy().astype(np.float64) for k in keys}
         w_after = {k: named[k].detach().cpu().numpy().astype(np.float64) for k in keys}
         so, cache = M.forward(w_before, cfg, x64, mask)
         out = oracle_loss(so, y)
         lo, gs = float(out[0]), out[1]
-        g_or = M.backward(w_before, cfg, cache, gs.astype(np.float64))
+        # the engine's ReLU branch pattern of THIS step (saved activations: feed-forward r, FC stack outputs)
+        pats = [(st["r"] > 0).view(B, L, -1).cpu().numpy() for st in ft.layers]
+        fc_pats = [(t > 0).view(B, L, -1).cpu().numpy() for t in ft.fc_out] if ft.fc_act == 1 else None
+        flips, units, zmax = 0, 0, 0.0
+        for zref, pat in ([(lc["z"], p_) for lc, p_ in zip(cache["layers"], pats)] +
+                          ([(fz[1], p_) for fz, p_ in zip(cache["fc"], fc_pats)] if fc_pats is not None else [])):
+            diff = pat != (zref > 0)
+            flips, units = flips + int(diff.sum()), units + int(diff.size)
+            if diff.any():
+                zmax = max(zmax, float(np.abs(zref[diff]).max()))
+        g_or = M.backward(w_before, cfg, cache, gs.astype(np.float64), relu_masks=pats, fc_relu_masks=fc_pats)
+        serr = float(np.abs(sc - so)[~mask].max())
         row = dict(step=step, loss=loss, oracle_loss=lo, loss_err=abs(loss - lo),
-                   score_err=float(np.abs(sc - so)[~mask].max()), score_scale=float(np.abs(so[~mask]).max()), grads={})
+                   score_err=serr, score_scale=float(np.abs(so[~mask]).max()), grads={},
+                   relu_units=units, relu_units_on_other_branch=flips, max_abs_preact_of_those=zmax)
+        row.update(_ndcg5_row(sc_t, so, y, mask, serr))
         gmax = max(float(np.abs(g_or[k]).max()) for k in keys)
         for k in keys:
             own = float(np.abs(g_or[k]).max())
@@ -111,37 +167,47 @@ def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=
     return rows
 
 
-# Gradient tolerances, relative to the largest entry of the tensor's OWN fp64 gradient (measured on MI355X, round 2,
-# gpurun_out/parity_benchdims_*.json):
-#   * rms error  <= 2e-3: measured <= 5.2e-4 (split-bf16; the 512-entry LayerNorm / bias vectors, whose rms is kink-dominated
-#     too), 1e-4 (hipBLASLt fp32);
-#   * max error  <= 5e-2: measured <= 1.8e-2 (split-bf16), 9e-4 (hipBLASLt fp32).  The max is NOT round-off of the
-#     gradient GEMMs -- it is ReLU kinks: of the 94 M hidden units of a 23040-row batch, the few dozen whose
-#     pre-activation lies within the forward round-off of 0 (1e-6 relative for the three-product GEMM, 2e-7 for fp32)
-#     get the opposite mask from the fp64 oracle, and each such unit moves one row's full contribution to dW_1 / db_1
-#     (the worst tensors in every run are feed_forward.w_1.{weight,bias}; the bias gradient is an exact fp32 column sum, so
-#     its error can only come from the masked input).  Any finite-precision forward has them (the fp32 library path shows
-#     the same outliers, 5x rarer, in proportion to its 5x smaller forward error).
-GRAD_TOL = 5e-2
-GRAD_RMS_TOL = 2e-3
+# Gradient tolerances (round 3).  Every parameter gradient is compared with the fp64 oracle's gradient ON THE SAME ReLU BRANCH
+# (the oracle differentiates through the engine's activation pattern; see _run).  Round 2 compared across branches and had to
+# allow 5e-2 of a tensor's largest entry for the handful of feed-forward units whose pre-activation lies within the forward
+# round-off of 0 (each moves one row's whole contribution to dW_1 / db_1, in any arithmetic).  With the kink taken out of the
+# comparison what is left is round-off of the gradient GEMMs themselves:
+#   * max error  <= 5e-4 of the LARGEST gradient of the model (the bar the exact-fp32 library path was held to in round 1) and
+#                <= 3e-3 of the tensor's own largest entry;
+#   * rms error  <= 3e-4 of the tensor's own largest entry;
+#   * the units on the other branch are counted: at most 2e-4 of all units, every one with |pre-activation| < 2e-4.
+GRAD_TOL = 3e-3
+GRAD_TOL_MODEL = 5e-4
+GRAD_RMS_TOL = 3e-4
 CFG3 = dict(n_features=136, fc_sizes=[512], fc_activation=None, fc_input_norm=False, N=2, d_ff=2048, h=8, output_activation=None)
 CFG5 = dict(n_features=1024, fc_sizes=[512], fc_activation=None, fc_input_norm=False, N=2, d_ff=2048, h=8, output_activation=None)
+CFG1_FC = dict(n_features=136, fc_sizes=[96], fc_activation=None, fc_input_norm=False, N=0, d_ff=0, h=1, output_activation=None)
+CFG1_MLP = dict(n_features=136, fc_sizes=[256, 512, 1024, 512, 256], fc_activation="ReLU", fc_input_norm=False, N=0, d_ff=0, h=1,
+                output_activation=None)          # the reference's reproducibility/configs/ndcgloss2pp_mlp.json stack
 
 
-def _check(rows, name, grad_tol):
+def _check(rows, name, grad_tol=GRAD_TOL, ndcg=True):
     for r in rows:
         s = r["step"]
         assert r["loss_err"] <= 1e-5 * (1 + abs(r["oracle_loss"])), (name, s, r["loss"], r["oracle_loss"])
         assert r["score_err"] <= 2e-5 * max(1.0, r["score_scale"]), (name, s, r["score_err"], r["score_scale"])
+        assert r["relu_units_on_other_branch"] <= 2e-4 * max(r["relu_units"], 1) and r["max_abs_preact_of_those"] < 2e-4, \
+            (name, s, r["relu_units_on_other_branch"], r["relu_units"], r["max_abs_preact_of_those"])
         # every parameter gradient, relative to the largest entry of its own tensor (tensors whose true gradient is
         # identically 0 -- key bias, output bias under a shift-invariant loss -- are bounded relative to the model's largest)
         bad = {k: v for k, v in r["grads"].items()
                if (v["own_max"] > 1e-6 * r["grad_model_scale"] and (v["rel"] > grad_tol or v["rms_err"] > GRAD_RMS_TOL * v["own_max"]))
-               or v["rel_model"] > grad_tol}
+               or v["rel_model"] > GRAD_TOL_MODEL}
         assert not bad, (name, s, bad)
         # Adam: every entry of every tensor to fp32 round-off of the update (|w| <= ~2, update <= lr)
         assert r["adam_err"] <= 3e-7, (name, s, r["adam_err"])
         assert 0.5 * LR <= r["adam_move"] <= 1.01 * LR * 10, (name, s, r["adam_move"])
+        if ndcg:
+            # NDCG@5 of the engine's scores == the oracle's on every slate whose top-6 is resolved by fp32 at all
+            assert r["ndcg5_max_delta_well_conditioned"] <= 1e-5, (name, s, r["ndcg5_max_delta_well_conditioned"])
+            assert r["slates_top5_order_differs_well_conditioned"] == 0, (name, s, r["slates_top5_order_differs_well_conditioned"])
+            if r["slates_ill_conditioned"] == 0:
+                assert r["ndcg5_batch_mean_abs_delta"] <= 1e-5, (name, s, r["ndcg5_batch_mean_abs_delta"])
 
 
 @pytest.mark.parametrize("gemm", ["split_bf16", "hipblaslt", "split_bf16_strict"])
@@ -152,7 +218,7 @@ def test_fused_step_at_config3_dimensions_matches_fp64_oracle(gemm):
     rows = _run(CFG3, B, L, gemm, "approxNDCGLoss", lambda s, t: O.approxndcg(s, t, dtype=np.float64), steps=4,
                 ragged=[(1, 200), (3, 17), (50, 1)], seed=21)
     _log("cfg3_%s" % gemm, rows)
-    _check(rows, "cfg3/" + gemm, grad_tol=GRAD_TOL)
+    _check(rows, "cfg3/" + gemm)
 
 
 def test_fused_step_at_config5_dimensions_matches_fp64_oracle():
@@ -162,7 +228,7 @@ def test_fused_step_at_config5_dimensions_matches_fp64_oracle():
     rows = _run(CFG5, B, L, "split_bf16", "listMLE", lambda s, t: O.listmle(s, t, perm, dtype=np.float64), steps=2,
                 ragged=[(1, 700)], seed=31, set_perm=perm)
     _log("cfg5_split_bf16", rows)
-    _check(rows, "cfg5", grad_tol=GRAD_TOL)
+    _check(rows, "cfg5")
 
 
 def test_fused_step_at_config5_bench_batch_matches_fp64_oracle():
@@ -172,7 +238,7 @@ def test_fused_step_at_config5_bench_batch_matches_fp64_oracle():
     rows = _run(CFG5, B, L, "split_bf16", "listMLE", lambda s, t: O.listmle(s, t, perm, dtype=np.float64), steps=1,
                 ragged=[(1, 700), (7, 3)], seed=32, set_perm=perm)
     _log("cfg5_b16_split_bf16", rows)
-    _check(rows, "cfg5/b16", grad_tol=GRAD_TOL)
+    _check(rows, "cfg5/b16")
 
 
 def test_adam_tracks_oracle_tightly_on_entries_with_real_gradients():
@@ -181,7 +247,47 @@ def test_adam_tracks_oracle_tightly_on_entries_with_real_gradients():
     rows = _run(cfg, 8, 70, "split_bf16", "approxNDCGLoss", lambda s, t: O.approxndcg(s, t, dtype=np.float64), steps=6,
                 ragged=[(2, 40)], seed=41)
     _log("small_adam", rows)
-    _check(rows, "small", grad_tol=GRAD_TOL)
+    _check(rows, "small")
+
+
+# ---- round 3: the other BASELINE configs through the benchmarked arithmetic at benchmark dimensions ----
+@pytest.mark.parametrize("loss_name,loss_args,oracle", [
+    ("neuralNDCG", dict(temperature=1.0, powered_relevancies=True, k=None, stochastic=False),
+     lambda s, t: O.neuralndcg(s, t, temperature=1.0, powered_relevancies=True, k=None, dtype=np.float64)),
+    ("lambdaLoss", dict(weighing_scheme="lambdaRank_scheme", k=None, mu=10.0, sigma=1.0),
+     lambda s, t: O.lambdaloss(s, t, weighing_scheme="lambdaRank_scheme", k=None, mu=10.0, sigma=1.0, dtype=np.float64)),
+])
+def test_fused_step_at_config4_losses_matches_fp64_oracle(loss_name, loss_args, oracle):
+    """BASELINE configs[3]: the config-3 model (96 x 240 rows: large-tile kernels) with NeuralNDCG (tau 1, k None;
+    neuralNDCG.py:10-70 + loss_utils.py:8-67) and lambdaLoss(lambdaRank_scheme) (lambdaLoss.py:7-81), loss arguments of
+    reproducibility/configs/{neuralndcg,lambdarank}_atmax.json -- loss, scores, every gradient, Adam replica, NDCG@5; three
+    steps = eager warm-up twice, then capture + replay of the hipGraph."""
+    B, L = 96, 240
+    rows = _run(CFG3, B, L, "split_bf16", loss_name, oracle, steps=3, ragged=[(1, 200), (3, 17), (50, 1)], seed=23,
+                loss_args=loss_args)
+    _log("cfg4_%s_split_bf16" % loss_name, rows)
+    _check(rows, "cfg4/" + loss_name)
+
+
+@pytest.mark.parametrize("name,cfg", [("fc96", CFG1_FC), ("mlp", CFG1_MLP)])
+def test_fused_step_at_config2_dimensions_matches_fp64_oracle(name, cfg):
+    """BASELINE configs[1]: F=136, slate 240, 256 slates, FCModel + ListNet (model.py:35-44, listNet.py:8-30): FC[96] (what
+    bench.py --workload fc_listnet runs) and the reference's MLP [256, 512, 1024, 512, 256] + ReLU."""
+    B, L = 256, 240
+    rows = _run(cfg, B, L, "split_bf16", "listNet", lambda s, t: O.listnet(s, t, dtype=np.float64), steps=3,
+                ragged=[(1, 200), (3, 17), (50, 1), (200, 100)], seed=25)
+    _log("cfg2_%s_split_bf16" % name, rows)
+    _check(rows, "cfg2/" + name)
+
+
+def test_fused_step_at_64_slates_graph_path_matches_fp64_oracle():
+    """the reference's batch_size 64 (reproducibility/configs/*.json) = 15360 rows: the 128 x 256 tile form for the N = 512
+    projections, and four steps so that steps 2 and 3 are hipGraph replays."""
+    B, L = 64, 240
+    rows = _run(CFG3, B, L, "split_bf16", "approxNDCGLoss", lambda s, t: O.approxndcg(s, t, dtype=np.float64), steps=4,
+                ragged=[(1, 200), (3, 17), (50, 1)], seed=27)
+    _log("cfg3_b64_graph_split_bf16", rows)
+    _check(rows, "cfg3/b64")
 
 
 # Throughput mode (gemm="bf16": ONE bf16 product per contraction, GEMMs and attention).  Its arithmetic is outside the parity
@@ -212,6 +318,3 @@ def test_bf16_throughput_mode_has_its_measured_tolerance_at_config3_dimensions()
         assert r["adam_err"] <= 3e-7, (r["step"], r["adam_err"])
     # and it really is a different arithmetic from the parity mode: its loss error is far above the three-product one
     assert rows[0]["loss_err"] > 10 * ref[0]["loss_err"], (rows[0]["loss_err"], ref[0]["loss_err"])
-    # the library-wide attention switch is back where it was
-    from allrank_amd import _lib as LB
-    assert LB.lib().ltrx_mha_get_mode() == 1

@@ -93,6 +93,41 @@ def test_fit_fused_and_autograd_paths_agree_and_learn(tmp_path):
     assert res["epochs"] < 29
 
 
+def test_fused_step_short_last_batch_is_normalised_by_its_real_slate_count():
+    """an epoch of 16 / 16 / 8 slates (DataLoader drop_last=False, dataset_loading.py:245).  The short batch
+    arrives topped up with fully padded slates and global_batch = 8; its loss, gradients and the weights after it must equal
+    the autograd Trainer's on the real 8 slates -- also when it falls on the step at which the hipGraph would be captured
+    (step 3) and when a graph captured on full batches is already live (step 6).  Both mean-normalised losses whose divisor
+    is a launch scalar are covered."""
+    import copy
+    from allrank_amd import losses as E
+    from allrank_amd.engine import FusedTrainer
+    L, F, bs = 30, 20, 16
+    x, y, idx = (t.to(DEV) for t in _data(40, L, F, 5))
+    for loss_name in ("listNet", "approxNDCGLoss"):
+        m_f = _model(F)
+        m_a = copy.deepcopy(m_f)                     # autograd reference: the reference's own loss_batch arithmetic on the REAL slates
+        ft = FusedTrainer(m_f, loss_name, {}, bs, L, lr=1e-3, use_graph=True)
+        for epoch in range(2):
+            for j in (0, 16, 32):
+                xb, yb = x[j:j + bs], y[j:j + bs]
+                real = xb.shape[0]
+                m_a.load_state_dict(m_f.state_dict())               # same weights on both sides at every step
+                m_a.zero_grad(set_to_none=True)
+                la = getattr(E, loss_name)(m_a(xb, yb == -1, None), yb)
+                la.backward()
+                if real < bs:
+                    padn = bs - real
+                    xb = torch.cat([xb, xb.new_zeros((padn, L, F))])
+                    yb = torch.cat([yb, yb.new_full((padn, L), -1.0)])
+                lf = ft.step(xb, yb, None, global_batch=real)
+                assert abs(float(lf.item()) - float(la.item())) <= 2e-6 * (1 + abs(float(la.item()))), (loss_name, epoch, j, float(lf), float(la))
+                gmax = max(float(pa.grad.abs().max()) for pa in m_a.parameters())
+                for (n, pf), (_, pa) in zip(m_f.named_parameters(), m_a.named_parameters()):
+                    assert float((pf.grad - pa.grad).abs().max()) <= 2e-4 * gmax, (loss_name, epoch, j, n)
+        assert ft.graph is not None          # the full batches did get their graph
+
+
 def test_fit_falls_back_to_the_autograd_trainer(tmp_path):
     from allrank_amd import losses as E, fit as EF
     cfg = types.SimpleNamespace(metrics={"ndcg": [5]}, val_metric="ndcg_5")

@@ -12,7 +12,7 @@ for big, tau in ((-1e10, 1.0), (-1e10, 0.01)):
     loss = torch.empty(1, device="cuda"); per = torch.empty(B, device="cuda")
     st = L.stream_of(yp)
     L.check(lib.ltrx_neuralndcg_prepare(L.ptr(yt), B, SL, -1.0, 0, 1, L.ptr(idcg), L.ptr(cnt), L.ptr(ws), st), "p")
-    L.check(lib.ltrx_neuralndcg_fwd_bwd(L.ptr(yp), L.ptr(yt), L.ptr(idcg), L.ptr(cnt), B, SL, -1.0, tau, 1, 0, 0, mi, 1e-6, L.ptr(loss), L.ptr(per), None, L.ptr(it), L.ptr(ws), st), "f")
+    L.check(lib.ltrx_neuralndcg_fwd_bwd(L.ptr(yp), L.ptr(yt), L.ptr(idcg), L.ptr(cnt), B, SL, -1.0, tau, 1, 0, 0, mi, 1e-6, L.ptr(loss), L.ptr(per), None, L.ptr(it), 0, L.ptr(ws), st), "f")
     torch.cuda.synchronize()
     o_per = 0; o_res = a64(B*4); o_t = o_res + a64(B*mi*4); o_cn = o_t + 64; o_rn = o_cn + a64(B*mi*SL*4); o_S = o_rn + a64(B*mi*SL*4)
     f = ws.view(torch.float32)

@@ -23,17 +23,15 @@ for (m, n, k) in shapes:
     fl = 2.0 * m * n * k
     row = dict(shape=(m, n, k))
     for v in (1, 2, 3, 5):
-        lib.ltrx_gemm_set_variant(v)
-        us = ev(lambda: LB.check(lib.ltrx_gemm_nt(LB.ptr(A), k, LB.ptr(B), k, LB.ptr(C), n, m, n, k, LB.ptr(bias), 0, None, 0, 0.0, 0, None, 0, None), "nt"))
+        us = ev(lambda: LB.check(lib.ltrx_gemm_nt(LB.ptr(A), k, LB.ptr(B), k, LB.ptr(C), n, m, n, k, LB.ptr(bias), 0, None, 0, 0.0, 0, None, 0, v, None), "nt"))
         row["nt_v%d" % v] = "%.1fus %.0fTF" % (us, fl / us / 1e6)
-    lib.ltrx_gemm_set_variant(0)
     us = ev(lambda: torch.addmm(bias, A, B.t(), out=C))
     row["hipblaslt_fp32"] = "%.1fus %.0fTF" % (us, fl / us / 1e6)
     # wgrad: dW[n,k] = dY[m,n]^T X[m,k]
     dY = torch.randn(m, n, device=DEV); X = torch.randn(m, k, device=DEV)
     gW = torch.empty(n, k, device=DEV); gb = torch.empty(n, device=DEV)
     ws = torch.empty(max(lib.ltrx_gemm_tn_workspace_bytes(m, n, k), 64), dtype=torch.uint8, device=DEV)
-    us = ev(lambda: LB.check(lib.ltrx_gemm_tn(LB.ptr(dY), n, LB.ptr(X), k, LB.ptr(gW), LB.ptr(gb), m, n, k, 0, LB.ptr(ws), None), "tn"))
+    us = ev(lambda: LB.check(lib.ltrx_gemm_tn(LB.ptr(dY), n, LB.ptr(X), k, LB.ptr(gW), LB.ptr(gb), m, n, k, 0, 0, LB.ptr(ws), None), "tn"))
     row["tn"] = "%.1fus %.0fTF" % (us, fl / us / 1e6)
     us = ev(lambda: torch.mm(dY.t(), X, out=gW))
     row["hipblaslt_tn"] = "%.1fus %.0fTF" % (us, fl / us / 1e6)

@@ -23,7 +23,7 @@ mask = torch.zeros(B, L, dtype=torch.bool, device=DEV)
 go = torch.randn(B, L, d, device=DEV)
 q, k, v = qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:]
 for mode in (0, 1, 0, 1):
-    lib.ltrx_mha_set_mode(mode)
+    ops.set_attention_mode(mode)
     with torch.no_grad():
         f = timeit(lambda: ops.attention(q, k, v, mask, h))
 
@@ -32,4 +32,4 @@ for mode in (0, 1, 0, 1):
         ops.attention(q, k, v, mask, h).backward(go)
     fbt = timeit(fb)
     print(json.dumps(dict(mode=mode, fwd_us=round(f, 1), fwd_bwd_us=round(fbt, 1))), flush=True)
-lib.ltrx_mha_set_mode(0)
+ops.set_attention_mode(1)

@@ -21,12 +21,12 @@ for ln in (16, 32, 64, 96, 112, 128, 160, 192, 240):
 
     def fwd():
         LB.check(lib.ltrx_mha_fwd(LB.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, None, B, Lmax, h, dk, 3 * d, LB.ptr(o), d,
-                                  LB.ptr(lse), 0.0, 0, None, LB.ptr(cu), None, st), "fwd")
+                                  LB.ptr(lse), 0.0, 0, None, LB.ptr(cu), None, 1, st), "fwd")
 
     def bwd():
         LB.check(lib.ltrx_mha_bwd(LB.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, None, LB.ptr(o), LB.ptr(do), LB.ptr(lse), B,
                                   Lmax, h, dk, 3 * d, d, LB.ptr(dqkv), dqkv.data_ptr() + 4 * d, dqkv.data_ptr() + 8 * d, 3 * d, 0.0, 0,
-                                  None, LB.ptr(cu), None, LB.ptr(ws), st), "bwd")
+                                  None, LB.ptr(cu), None, 1, LB.ptr(ws), st), "bwd")
     res = []
     for fn in (fwd, bwd):
         for _ in range(3):
