@@ -708,6 +708,9 @@ static void launch_slab_reduce(const float* slabs, int splits, size_t n, float* 
 // `tile` argument of ltrx_gemm_nt / ltrx_gemm_tn (a per-call tuning argument, no process state): 0 = auto; 1 = 128x128x32
 // (4 waves); 2 = 128x128x64; 3 = 256x128x32 (8 waves); 4 = 256x128x64; 6 = 256x256x32 large-tile kernel (auto picks it for
 // exact multiples with >= 360 tiles); 7 = its 128x256x32 form; +100 = tuning experiment (every operand row aliases row 0)
+// (a PERSISTENT form of the 256x256x32 kernel -- one workgroup per CU walking its tiles, next tile's first K-steps prefetched
+//  behind the epilogue -- was built and measured in round 3: bit-identical results, 0 ... -13 % in speed; tools/lab/gemm_persist.inc,
+//  profiles/r03_gemm_persist_ab.md)
 
 template <int NTERMS, int BM_, int BK_>
 static void launch_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,

@@ -692,6 +692,7 @@ class FusedTrainer(object):
         if float(lr) != float(self.lr):
             self.lr = float(lr)
             self._graphs.clear()
+            self._graph_pool = None      # (a pool whose graphs are all gone cannot be captured into again: fresh handle)
 
     def _pack(self, xb, lengths):
         """compact mode: build idx / cu_seqlens for this batch and gather the valid rows of xb into x_in.  ``lengths`` (host

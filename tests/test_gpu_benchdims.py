@@ -173,12 +173,16 @@ def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=
 # round-off of 0 (each moves one row's whole contribution to dW_1 / db_1, in any arithmetic).  With the kink taken out of the
 # comparison what is left is round-off of the gradient GEMMs themselves:
 #   * max error  <= 5e-4 of the LARGEST gradient of the model (the bar the exact-fp32 library path was held to in round 1) and
-#                <= 3e-3 of the tensor's own largest entry;
-#   * rms error  <= 3e-4 of the tensor's own largest entry;
-#   * the units on the other branch are counted: at most 2e-4 of all units, every one with |pre-activation| < 2e-4.
-GRAD_TOL = 3e-3
+#                <= 1e-3 of the tensor's own largest entry   (measured on MI355X, round 3: <= 2.4e-4, NeuralNDCG; 2-4e-5 typical);
+#   * rms error  <= 2e-4 of the tensor's own largest entry   (measured: <= 7.2e-5);
+#   * the units on the other branch are counted: at most 2e-4 of all units, every one with |pre-activation| < 2e-4
+#     (measured: 14-226 of 8-157 M units, i.e. ~2e-6 of them, largest |pre-activation| 1.6e-5; hipBLASLt fp32: 26-51 units).
+# NDCG@5 (measured, same runs): identical top-5 order and |delta| <= 1e-7 on every well-conditioned slate; of the 2500 slate
+# evaluations of this file three were ill-conditioned (two of their six best items, different labels, scores closer than twice
+# the score error) and one of those changed its NDCG@5 (cfg2/mlp step 1: batch mean moved by 3.7e-5).
+GRAD_TOL = 1e-3
 GRAD_TOL_MODEL = 5e-4
-GRAD_RMS_TOL = 3e-4
+GRAD_RMS_TOL = 2e-4
 CFG3 = dict(n_features=136, fc_sizes=[512], fc_activation=None, fc_input_norm=False, N=2, d_ff=2048, h=8, output_activation=None)
 CFG5 = dict(n_features=1024, fc_sizes=[512], fc_activation=None, fc_input_norm=False, N=2, d_ff=2048, h=8, output_activation=None)
 CFG1_FC = dict(n_features=136, fc_sizes=[96], fc_activation=None, fc_input_norm=False, N=0, d_ff=0, h=1, output_activation=None)
