@@ -22,10 +22,11 @@
 // runs the backward from T*.  At training shapes (L >= 40) fp32 never reaches 1e-6, so T* = max_iter and the
 // rewind is empty.
 //
-// Layout: one workgroup per slate; the n x n state S and adjoint A live in a global workspace (L2 / Infinity
-// Cache resident: 2 * 230 KB per slate at L = 240).  Column phases: one thread per column, lanes read
-// consecutive addresses of a row (coalesced).  Row phases: one wave per row, lane-strided, wave-shuffle sums.
-// (A register-resident variant for L <= 256 is the planned optimisation; this kernel is general in L.)
+// Two kernel families, same math and workspace contract.  GENERAL (any L <= 2048): one workgroup per slate; the n x n state S and
+// adjoint A live in a global workspace (L2 / Infinity Cache resident: 2 * 230 KB per slate at L = 240); column phases: one thread
+// per column, lanes read consecutive addresses of a row (coalesced); row phases: one wave per row, lane-strided, wave-shuffle sums.
+// BLOCK-RESIDENT (L <= 240, the default there): state and adjoint-product in registers + LDS as a 2-D block decomposition -- see
+// the section further down.
 #include "ltrx_device.h"
 
 // No FMA contraction in this file: the row max of P_max/tau and the exponent argument must be the SAME rounded
@@ -56,7 +57,7 @@ inline NeuralWs carve(void* ws, int B, int L, int max_iter) {
   w.per = (float*)p;   p += align64((size_t)B * 4);
   w.res = (float*)p;   p += align64((size_t)B * max_iter * 4);
   w.titer = (int*)p;   p += 64;
-  w.cn = (float*)p;    p += align64((size_t)B * max_iter * L * 4);
+  w.cn = (float*)p;    p += align64((size_t)B * (max_iter + 1) * L * 4);   // (+1: the block path also keeps the sums after the last step)
   w.rn = (float*)p;    p += align64((size_t)B * max_iter * L * 4);
   w.S = (float*)p;     p += align64((size_t)B * L * L * 4);
   w.A = (float*)p;
@@ -386,341 +387,402 @@ __global__ void __launch_bounds__(1024) ltrx_neural_backward_kernel(
 
 
 // ---------------------------------------------------------------------------------------------------------
-// Register-resident fast path (n_valid <= 16 * NR, L <= 64 * NC; L <= 240 -> NR = 15, NC = 4):
-// a 1024-thread workgroup (16 waves) holds the whole n x n Sinkhorn state in VGPRs -- wave w owns rows
-// w, w+16, ..., lane l owns columns l, l+64, ... (60 registers at L = 240; 240^2 fp32 = 230 KB would not fit the
-// 160 KB LDS).  Row sums are lane-local adds + one wave shuffle reduction per row; column sums are per-wave partials
-// exchanged through a 16 KB LDS array and combined in a fixed order.  The backward kernel carries the adjoint the
-// same way (120 state registers).  Normalisers are applied as x * (1/c) (<= 1 ulp from the reference's x / c).
-// Same outputs / workspace contract as the general kernels above (cn, rn, res, S), so pick_iter and the batch-global
-// early-exit replay are shared.
+// Block-resident path (round 3; L <= 240): the n x n Sinkhorn state in VGPRs as a 2-D BLOCK decomposition.
+// (Round 2 kept the state in registers too, but gave a wave whole rows (lane = column): every row sum was a 6-step DPP chain (15 per
+// wave and iteration, serialised to stay under 128 VGPRs), every column sum went through a 16 KB LDS exchange that 768 of the 1024
+// threads waited for, and the batch-global residual cost two more block reductions -- 6 barriers and ~18 k cycles per iteration for
+// 57.6 k elements: forward 459 us, backward 1173 us at 256 x 240, profiles/r03_bench_attn_neuralndcg_kernel_stats.md "before";
+// same-box A/B of the whole plugin call 2074 -> 686 us, profiles/r03_neuralndcg_ab.md.)
+// Here the 16 waves form a 4 x 4 grid of blocks and the 64 lanes of a wave an LRN x LCN grid of TBR x TBC register tiles: thread
+// (wr, wc, lr, lc) owns rows LRN TBR wr + TBR lr + (0..TBR-1) and columns LCN TBC wc + TBC lc + (0..TBC-1).  Geometries: 8 x 8
+// lanes with square tiles of 2 / 4 / 6 on 4 x 4 waves (L <= 64 / 128 / 192); 4 x 16 lanes with 15 x 5 tiles on 4 x 3 waves (768
+// threads, 170 registers each) for L <= 240: an exact fit of the WEB30K slate length.
+//   * a row sum = in-thread adds, a DPP all-reduce over the LCN consecutive lanes lc, and 4 wave partials through LDS; a column
+//     sum the same over the LRN lanes lr (stride LCN: row_ror:8 / xor 16 / xor 32 exchanges);
+//   * every thread adds the four wave partials of its own rows / columns in the SAME fixed order (bitwise identical normalisers
+//     in every thread, deterministic) and takes the reciprocal itself: no combine phase, two barriers per iteration;
+//   * the residual trace of the batch-global early exit (loss_utils.py:25) is NOT computed in the loop: the normaliser trace that
+//     the backward needs anyway (column sums -- stored unclamped, plus the sums after the last step -- and clamped row sums)
+//     determines it, and ltrx_neural_residual_kernel derives res[b][it] from it afterwards.
+// Same arithmetic per element as the kernels above (x * (1/c), clamp at 1e-10, softmax as exp(z - max) / sum); only the order of
+// the partial sums inside a row / column differs.  Workspace: cn has max_iter + 1 rows per slate on this path.
 // ---------------------------------------------------------------------------------------------------------
-template <int NR, int NC>
-struct RegMat {
-  float v[NR][NC];
+template <int LCN>
+__device__ __forceinline__ float sum_lc(float v) {       // all-reduce over the LCN consecutive lanes that share lr
+  v += LTRX_DPP_F(0.f, v, 0xB1, 0xF, true);               // quad_perm [1,0,3,2]
+  v += LTRX_DPP_F(0.f, v, 0x4E, 0xF, true);               // quad_perm [2,3,0,1]
+  v += LTRX_DPP_F(0.f, v, 0x141, 0xF, true);              // row_half_mirror: the other quad of the 8-lane group
+  if (LCN == 16) v += LTRX_DPP_F(0.f, v, 0x140, 0xF, true);   // row_mirror: the other half of the 16-lane row
+  return v;
+}
+template <int LCN>
+__device__ __forceinline__ float max_lc(float v) {
+  v = fmaxf(v, LTRX_DPP_F(v, v, 0xB1, 0xF, false));
+  v = fmaxf(v, LTRX_DPP_F(v, v, 0x4E, 0xF, false));
+  v = fmaxf(v, LTRX_DPP_F(v, v, 0x141, 0xF, false));
+  if (LCN == 16) v = fmaxf(v, LTRX_DPP_F(v, v, 0x140, 0xF, false));
+  return v;
+}
+template <int LCN>
+__device__ __forceinline__ float sum_lr(float v) {       // all-reduce over the 64 / LCN lanes lc, lc + LCN, ... (same lc)
+  if (LCN == 8) v += LTRX_DPP_F(0.f, v, 0x128, 0xF, true);    // row_ror:8 = lane ^ 8 inside a 16-lane row
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <int LRN, int TBR, int TBC, int NWC>
+struct BlkGeom {
+  static constexpr int LCN = 64 / LRN;
+  static constexpr int WR = 4 * LRN * TBR;      // rows covered (4 wave rows)
+  static constexpr int WC = NWC * LCN * TBC;    // columns covered (NWC wave columns)
+  int wr, wc, lr, lc, r0, c0;
+  __device__ __forceinline__ BlkGeom() {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    wr = wave / NWC;
+    wc = wave % NWC;
+    lr = lane / LCN;
+    lc = lane % LCN;
+    r0 = LRN * TBR * wr + TBR * lr;
+    c0 = LCN * TBC * wc + TBC * lc;
+  }
 };
+#define LTRX_PART4(part, idx) (((part[0][idx] + part[1][idx]) + part[2][idx]) + part[3][idx])     /* fixed order */
+// the NWC wave partials of a row (fixed order)
+template <int NWC, int W>
+__device__ __forceinline__ float part_rows(const float (*part)[W], int idx) {
+  float a = part[0][idx] + part[1][idx];
+  if (NWC >= 3) a += part[2][idx];
+  if (NWC == 4) a += part[3][idx];
+  return a;
+}
+template <int NWC, int W>
+__device__ __forceinline__ float part_rows_max(const float (*part)[W], int idx) {
+  float a = fmaxf(part[0][idx], part[1][idx]);
+  if (NWC >= 3) a = fmaxf(a, part[2][idx]);
+  if (NWC == 4) a = fmaxf(a, part[3][idx]);
+  return a;
+}
 
-#define LTRX_FOR_RC for (int ri = 0; ri < NR; ++ri) for (int cj = 0; cj < NC; ++cj)
-
-template <int NR, int NC>
-__global__ void __launch_bounds__(1024) ltrx_neural_forward_reg_kernel(const float* __restrict__ y_pred,
+template <int LRN, int TBR, int TBC, int NWC>
+__global__ void __launch_bounds__(256 * NWC) ltrx_neural_forward_blk_kernel(const float* __restrict__ y_pred,
                                                                        const float* __restrict__ y_true, int L, float pad,
                                                                        float tau, int max_iter, float* __restrict__ Sws,
-                                                                       float* __restrict__ cnws, float* __restrict__ rnws,
-                                                                       float* __restrict__ resws) {
+                                                                       float* __restrict__ cnws, float* __restrict__ rnws) {
+  typedef BlkGeom<LRN, TBR, TBC, NWC> G;
+  constexpr int LCN = G::LCN, W = (G::WC > G::WR ? G::WC : G::WR);
   extern __shared__ float lds[];
-  __shared__ float red[LTRX_MAX_WAVES];
   __shared__ int redi[LTRX_MAX_WAVES];
-  __shared__ float colpart[16][64 * NC];
-  __shared__ float cvec[64 * NC];
+  __shared__ __attribute__((aligned(16))) float part_r[NWC][W];    // row partials: one per wave column
+  __shared__ __attribute__((aligned(16))) float part_c[4][W];      // column partials: one per wave row (also the softmax sums)
   const SlateLds t = carve_lds(lds, L);
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x;
   const int n = load_slate(t, y_pred + (size_t)b * L, y_true + (size_t)b * L, L, pad, 0, 0, redi);
+  if (n == 0) return;                                   // (the residual kernel writes res = 0 for an empty slate)
   float* S = Sws + (size_t)b * L * L;
-  float* cn = cnws + (size_t)b * max_iter * L;
+  float* cn = cnws + (size_t)b * (max_iter + 1) * L;
   float* rn = rnws + (size_t)b * max_iter * L;
-  float* res = resws + (size_t)b * max_iter;
-  const int lane = lane_id(), w = wave_id();
-  if (n == 0) {
-    for (int it = threadIdx.x; it < max_iter; it += blockDim.x) res[it] = 0.f;
-    return;
-  }
-  RegMat<NR, NC> m;
-  // ---- P0 = row softmax ----
+  const G g;
+  float m[TBR][TBC];
+  // ---- P0 = row softmax of (scaling_i s_j - Bsum_j) / tau, two passes over the same expression (clamped table indices +
+  //      selects: no branches around the reads) ----
+  {
 #pragma unroll
-  for (int ri = 0; ri < NR; ++ri) {
-    const int i = w + 16 * ri;
-    const float sc_i = (i < n) ? t.scal[i] : 0.f;
-    float z[NC];
-    float mx = -INFINITY;
+    for (int i = 0; i < TBR; ++i) {
+      const float sc_i = t.scal[min(g.r0 + i, n - 1)];
+      float a = -INFINITY;
 #pragma unroll
-    for (int cj = 0; cj < NC; ++cj) {
-      const int j = lane + 64 * cj;
-      z[cj] = (i < n && j < n) ? (sc_i * t.sc[j] - t.bs[j]) / tau : -INFINITY;
-      mx = fmaxf(mx, z[cj]);
+      for (int j = 0; j < TBC; ++j) {
+        const int jc = min(g.c0 + j, n - 1);
+        const float z0 = (sc_i * t.sc[jc] - t.bs[jc]) / tau;
+        a = fmaxf(a, (g.r0 + i < n && g.c0 + j < n) ? z0 : -INFINITY);
+      }
+      a = max_lc<LCN>(a);
+      if (g.lc == 0) part_r[g.wc][g.r0 + i] = a;
     }
-    mx = wave_max(mx);
-    float sum = 0.f;
+    __syncthreads();
 #pragma unroll
-    for (int cj = 0; cj < NC; ++cj) {
-      const float e = (z[cj] == -INFINITY) ? 0.f : expf(z[cj] - mx);
-      m.v[ri][cj] = e;
-      sum += e;
-    }
-    sum = wave_sum(sum);
-    const float inv = (sum > 0.f) ? 1.0f / sum : 0.f;
-#pragma unroll
-    for (int cj = 0; cj < NC; ++cj) m.v[ri][cj] = (sum > 0.f) ? m.v[ri][cj] / sum : 0.f;
-    (void)inv;
-    __builtin_amdgcn_sched_barrier(0);     // keep the rows sequential: interleaving all 15 blows the 128-VGPR budget
-  }
-  // ---- Sinkhorn ----
-  float rowres_prev = 0.f;
-  for (int it = 0; it <= max_iter; ++it) {
-    float* cn_it = cn + (size_t)it * L;
-    float* rn_it = rn + (size_t)it * L;
-    // column sums: per-wave partials -> LDS -> fixed-order combine
-#pragma unroll
-    for (int cj = 0; cj < NC; ++cj) {
+    for (int i = 0; i < TBR; ++i) {
+      const float sc_i = t.scal[min(g.r0 + i, n - 1)];
+      const float mx = part_rows_max<NWC, W>(part_r, g.r0 + i);
       float a = 0.f;
 #pragma unroll
-      for (int ri = 0; ri < NR; ++ri) a += m.v[ri][cj];
-      colpart[w][lane + 64 * cj] = a;
+      for (int j = 0; j < TBC; ++j) {
+        const int jc = min(g.c0 + j, n - 1);
+        const float z0 = (sc_i * t.sc[jc] - t.bs[jc]) / tau;
+        const float z = (g.r0 + i < n && g.c0 + j < n) ? z0 : -INFINITY;
+        const float e = (z == -INFINITY) ? 0.f : expf(z - mx);
+        m[i][j] = e;
+        a += e;
+      }
+      a = sum_lc<LCN>(a);
+      if (g.lc == 0) part_c[g.wc][g.r0 + i] = a;       // (second exchange buffer: part_r is still being read)
     }
     __syncthreads();
-    float cres = 0.f;
-    if (threadIdx.x < 64 * NC) {
-      const int j = threadIdx.x;
-      float c = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < 16; ++ww) c += colpart[ww][j];
-      if (j < n) {
-        cres = fabsf(c - 1.0f);
-        if (it < max_iter) {
-          c = fmaxf(c, kSinkEps);
-          cn_it[j] = c;
-        }
-      }
-      cvec[j] = (j < n) ? 1.0f / c : 0.f;
+    for (int i = 0; i < TBR; ++i) {
+      const float sum = part_rows<NWC, W>(part_c, g.r0 + i);
+#pragma unroll
+      for (int j = 0; j < TBC; ++j) m[i][j] = (sum > 0.f) ? m[i][j] / sum : 0.f;
     }
-    if (it > 0) {
-      cres = block_max(cres, red);
-      if (threadIdx.x == 0) res[it - 1] = fmaxf(cres, rowres_prev);
+    __syncthreads();                                    // part_c is rewritten by the first column phase
+  }
+  // ---- Sinkhorn ----
+  for (int it = 0; it <= max_iter; ++it) {
+#pragma unroll
+    for (int j = 0; j < TBC; ++j) {
+      float a = m[0][j];
+#pragma unroll
+      for (int i = 1; i < TBR; ++i) a += m[i][j];
+      a = sum_lr<LCN>(a);
+      if (g.lr == 0) part_c[g.wr][g.c0 + j] = a;
     }
+    __syncthreads();
+    if (tid < n) cn[(size_t)it * L + tid] = LTRX_PART4(part_c, tid);      // BEFORE the clamp: normaliser trace + residual trace
     if (it == max_iter) break;
-    __syncthreads();
-    float rcj[NC];
 #pragma unroll
-    for (int cj = 0; cj < NC; ++cj) rcj[cj] = cvec[lane + 64 * cj];
-    float rres = 0.f;
+    for (int j = 0; j < TBC; ++j) {
+      const float rc = 1.0f / fmaxf(LTRX_PART4(part_c, g.c0 + j), kSinkEps);
 #pragma unroll
-    for (int ri = 0; ri < NR; ++ri) {
-      const int i = w + 16 * ri;
-      float r = 0.f;
-#pragma unroll
-      for (int cj = 0; cj < NC; ++cj) {
-        m.v[ri][cj] *= rcj[cj];
-        r += m.v[ri][cj];
-      }
-      r = fmaxf(wave_sum(r), kSinkEps);
-      const float rr = 1.0f / r;
-#pragma unroll
-      for (int cj = 0; cj < NC; ++cj) m.v[ri][cj] *= rr;
-      if (i < n) {
-        if (lane == 0) rn_it[i] = r;
-        rres = fmaxf(rres, fabsf(r * rr - 1.0f));
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < TBR; ++i) m[i][j] *= rc;
     }
-    rowres_prev = block_max(rres, red);     // (barriers: colpart / cvec may be overwritten next iteration)
+#pragma unroll
+    for (int i = 0; i < TBR; ++i) {
+      float a = m[i][0];
+#pragma unroll
+      for (int j = 1; j < TBC; ++j) a += m[i][j];
+      a = sum_lc<LCN>(a);
+      if (g.lc == 0) part_r[g.wc][g.r0 + i] = a;
+    }
+    __syncthreads();
+    if (tid >= 256 && tid - 256 < n) rn[(size_t)it * L + tid - 256] = fmaxf(part_rows<NWC, W>(part_r, tid - 256), kSinkEps);
+#pragma unroll
+    for (int i = 0; i < TBR; ++i) {
+      const float rr = 1.0f / fmaxf(part_rows<NWC, W>(part_r, g.r0 + i), kSinkEps);
+#pragma unroll
+      for (int j = 0; j < TBC; ++j) m[i][j] *= rr;
+    }
   }
   // ---- publish the final state for the backward kernel ----
 #pragma unroll
-  for (int ri = 0; ri < NR; ++ri) {
-    const int i = w + 16 * ri;
+  for (int i = 0; i < TBR; ++i)
 #pragma unroll
-    for (int cj = 0; cj < NC; ++cj) {
-      const int j = lane + 64 * cj;
-      if (i < n && j < n) S[(size_t)i * n + j] = m.v[ri][cj];
-    }
-  }
+    for (int j = 0; j < TBC; ++j)
+      if (g.r0 + i < n && g.c0 + j < n) S[(size_t)(g.r0 + i) * n + g.c0 + j] = m[i][j];
 }
 
-// Backward: state m (NR x NC registers) + adjoint.  NCL of the NC adjoint column slots live in LDS (a_lds[slot][tid],
-// conflict-free: consecutive threads -> consecutive banks) so that the 1024-thread workgroup stays under its
-// 128-VGPR budget: at L = 240 (NR 15, NC 4, NCL 2) that is 60 + 30 registers + 123 KB of the 160 KB LDS.
-template <int NR, int NC, int NCL>
-__global__ void __launch_bounds__(1024) ltrx_neural_backward_reg_kernel(
+// Backward of the block path.  Two matrices have to stay on chip: the state m and, instead of the adjoint a itself, the
+// elementwise product b = a (.) m, in which the reversed Sinkhorn needs no division and no product per dot:
+//   row step  Y2 = Y1 / r:  d_i = [r_i > eps] sum_j b_ij;  b_ij <- b_ij - d_i m_ij;  m_ij <- m_ij r_i      (a1 (.) Y1 = (a2 - d) (.) Y2)
+//   col step  Y1 = X / c :  d_j = [c_j > eps] sum_i b_ij;  b_ij <- b_ij - d_j m_ij;  m_ij <- m_ij c_j
+//   softmax   gz_ij = (b_ij - P0_ij sum_j b_ij) / tau                                                     (= P0 (a - <a, P0>) / tau)
+// Two tiles per thread do not fit the 128 registers of a 1024-thread workgroup at L > 192, so TLC of the TBC columns of b live
+// in LDS there (b_lds[row i][tid][TLC]: consecutive threads -> consecutive banks; 120 KB at 15 x 4, TLC = 2).  Both sweeps of a step
+// go row by row; the row step accumulates the column sums of the new b, the column step publishes its row sums per row, so
+// every element of b is read and written once per half-step and the last sweep leaves exactly the row sums the softmax backward
+// starts from.  Padded rows / columns use r = c = 1, d = 0.
+template <int LRN, int TBR, int TBC, int NWC, int TLC>
+__global__ void __launch_bounds__(256 * NWC) ltrx_neural_backward_blk_kernel(
     const float* __restrict__ y_pred, const float* __restrict__ y_true, const float* __restrict__ idcg,
     const float* __restrict__ nonzero_count, int L, float pad, float inv_tau, int gain_powered, int k,
-    const int* __restrict__ k_rows, int max_iter,
-    const int* __restrict__ titer, const float* __restrict__ Sws, const float* __restrict__ cnws,
-    const float* __restrict__ rnws, float* __restrict__ per_ws, float* __restrict__ per_out, float* __restrict__ grad) {
-  constexpr int NCR = NC - NCL;                         // adjoint column slots kept in registers
-  __shared__ float tables[7 * 64 * NC];
+    const int* __restrict__ k_rows, int max_iter, const int* __restrict__ titer, const float* __restrict__ Sws,
+    const float* __restrict__ cnws, const float* __restrict__ rnws, float* __restrict__ per_ws, float* __restrict__ per_out,
+    float* __restrict__ grad) {
+  typedef BlkGeom<LRN, TBR, TBC, NWC> G;
+  constexpr int LCN = G::LCN, W = (G::WC > G::WR ? G::WC : G::WR), NT = 256 * NWC;
+  constexpr int TRC = TBC - TLC;                        // columns of b kept in registers
+  __shared__ float tables[7 * W];
   __shared__ float red[LTRX_MAX_WAVES];
   __shared__ int redi[LTRX_MAX_WAVES];
-  __shared__ float colpart[16][64 * NC];
-  __shared__ float cvec[64 * NC];
-  __shared__ float dvec[64 * NC];
-  __shared__ float a_lds[(NCL > 0 ? NR * NCL : 1) * 1024];
+  __shared__ __attribute__((aligned(16))) float part_r[4][W];      // row partials: NWC of the 4 slots (all 4 in the epilogue)
+  __shared__ __attribute__((aligned(16))) float part_c[4][W];
+  __shared__ float cvec[W];
+  __shared__ float dvec[W];
+  __shared__ float nrm[2][2][W];                        // [step parity][row normalisers | unclamped column sums] of a step
+  __shared__ float dump[NT];                            // where the lanes that do not publish a partial sum write (branch-free stores)
+  __shared__ __attribute__((aligned(16))) float b_lds[TBR * NT * (TLC > 0 ? TLC : 1)];
   const SlateLds t = carve_lds(tables, L);
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x;
   int kk = (k <= 0 || k > L) ? L : k;
   if (k_rows) kk = min(kk, k_rows[b]);
   const int n = load_slate(t, y_pred + (size_t)b * L, y_true + (size_t)b * L, L, pad, kk, gain_powered, redi);
   const float* S = Sws + (size_t)b * L * L;
-  const float* cn = cnws + (size_t)b * max_iter * L;
+  const float* cn = cnws + (size_t)b * (max_iter + 1) * L;
   const float* rn = rnws + (size_t)b * max_iter * L;
-  const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
   const int T = titer[0];
   float* gp = grad ? grad + (size_t)b * L : nullptr;
   if (gp)
     for (int i = tid; i < L; i += blockDim.x) gp[i] = 0.f;
   const float id = idcg[b];
   const float cnt = nonzero_count[0];
-  if (n == 0 || id == 0.f) {
+  if (n == 0 || id == 0.f) {                            // neuralNDCG.py:62-63: excluded from the mean, zero gradient
     if (tid == 0) {
       per_ws[b] = 0.f;
       if (per_out) per_out[b] = 0.f;
     }
     return;
   }
-  float m[NR][NC];
-  float ar[NR][NCR > 0 ? NCR : 1];
-#define LTRX_A_GET(ri, cj) ((cj) < NCR ? ar[ri][(cj) < NCR ? (cj) : 0] : a_lds[((ri) * NCL + ((cj) - NCR)) * 1024 + tid])
-#define LTRX_A_SET(ri, cj, val)                                        \
-  do {                                                                 \
-    if ((cj) < NCR) ar[ri][(cj) < NCR ? (cj) : 0] = (val);             \
-    else a_lds[((ri) * NCL + ((cj) - NCR)) * 1024 + tid] = (val);      \
+  const G g;
+  // partial sums are published by the lanes lc == 0 (rows) / lr == 0 (columns); the others store to `dump`: a store whose
+  // ADDRESS is selected keeps the sweeps free of branches (with a branch per row the compiler moves the state updates of all rows
+  // into one block and doubles their register footprint)
+  float* const rdst = (g.lc == 0) ? &part_r[g.wc][g.r0] : &dump[tid];
+  const int rstep = (g.lc == 0) ? 1 : 0;
+  float* const cdst = (g.lr == 0) ? &part_c[g.wr][g.c0] : &dump[tid];
+  const int cstep = (g.lr == 0) ? 1 : 0;
+  float m[TBR][TBC];
+  float br[TBR][TRC > 0 ? TRC : 1];
+#define LTRX_BL(i, jj) b_lds[((i) * NT + tid) * TLC + (jj)]
+#define LTRX_B_GET(i, j) ((j) < TRC ? br[i][(j) < TRC ? (j) : 0] : LTRX_BL(i, (j) - TRC))
+#define LTRX_B_SET(i, j, val)                                   \
+  do {                                                          \
+    if ((j) < TRC) br[i][(j) < TRC ? (j) : 0] = (val);          \
+    else LTRX_BL(i, (j) - TRC) = (val);                         \
   } while (0)
 #pragma unroll
-  for (int ri = 0; ri < NR; ++ri)
+  for (int i = 0; i < TBR; ++i)
 #pragma unroll
-    for (int cj = 0; cj < NC; ++cj) {
-      const int i = w + 16 * ri, j = lane + 64 * cj;
-      m[ri][cj] = (i < n && j < n) ? S[(size_t)i * n + j] : 0.f;
+    for (int j = 0; j < TBC; ++j) {
+      const float sv = S[(size_t)min(g.r0 + i, n - 1) * n + min(g.c0 + j, n - 1)];      // clamped address + select: no branch
+      m[i][j] = (g.r0 + i < n && g.c0 + j < n) ? sv : 0.f;
     }
-  // ---- rewind the steps max_iter-1 .. T ----
+  // ---- rewind the steps max_iter-1 .. T (batch-global early exit): undo the row scaling, then the column scaling ----
   for (int it = max_iter - 1; it >= T; --it) {
-    const float* cn_it = cn + (size_t)it * L;
-    const float* rn_it = rn + (size_t)it * L;
-    float cj_[NC];
 #pragma unroll
-    for (int cj = 0; cj < NC; ++cj) cj_[cj] = (lane + 64 * cj < n) ? cn_it[lane + 64 * cj] : 0.f;
+    for (int i = 0; i < TBR; ++i) {
+      const float r = rn[(size_t)it * L + min(g.r0 + i, n - 1)];
 #pragma unroll
-    for (int ri = 0; ri < NR; ++ri) {
-      const int i = w + 16 * ri;
-      const float r = (i < n) ? rn_it[i] : 0.f;
-#pragma unroll
-      for (int cj = 0; cj < NC; ++cj) m[ri][cj] = (m[ri][cj] * r) * cj_[cj];
+      for (int j = 0; j < TBC; ++j) {
+        const float c = fmaxf(cn[(size_t)it * L + min(g.c0 + j, n - 1)], kSinkEps);
+        m[i][j] = (m[i][j] * r) * c;                     // (padded entries are 0 and stay 0)
+      }
     }
   }
-  // ---- read-out ----
+  // ---- read-out: value_b = sum_i dk_i sum_j m_ij g_j / (idcg + eps) ----
   float v = 0.f;
-  {
-    float gcj[NC];
 #pragma unroll
-    for (int cj = 0; cj < NC; ++cj) gcj[cj] = (lane + 64 * cj < n) ? t.gc[lane + 64 * cj] : 0.f;
+  for (int i = 0; i < TBR; ++i) {
+    float acc = 0.f;
 #pragma unroll
-    for (int ri = 0; ri < NR; ++ri) {
-      const int i = w + 16 * ri;
-      float acc = 0.f;
+    for (int j = 0; j < TBC; ++j) acc += m[i][j] * t.gc[min(g.c0 + j, n - 1)];          // (m is 0 on padded entries)
+    v += ((g.r0 + i < n) ? t.dk[min(g.r0 + i, n - 1)] : 0.f) * acc;
+  }
+  v = block_sum(v, red);
+  const float value = v / (id + kSinkEps);
+  if (tid == 0) {
+    per_ws[b] = value;
+    if (per_out) per_out[b] = value;
+  }
+  if (!gp) return;
+  const float coef = -1.0f / (cnt * (id + kSinkEps));
+  // seed b = a (.) m and publish the row sums of b (per wave) that the first row step -- or, with T == 0, the softmax backward -- reduces
 #pragma unroll
-      for (int cj = 0; cj < NC; ++cj) acc += m[ri][cj] * gcj[cj];
-      acc = wave_sum(acc);
-      if (lane == 0 && i < n) v += t.dk[i] * acc;
+  for (int i = 0; i < TBR; ++i) {
+    const float d = (g.r0 + i < n) ? coef * t.dk[min(g.r0 + i, n - 1)] : 0.f;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < TBC; ++j) {
+      const float a = d * ((g.c0 + j < n) ? t.gc[min(g.c0 + j, n - 1)] : 0.f);
+      const float bv = a * m[i][j];
+      LTRX_B_SET(i, j, bv);
+      acc += bv;
     }
-    v = block_sum(v, red);
-    const float value = v / (id + kSinkEps);
-    if (tid == 0) {
-      per_ws[b] = value;
-      if (per_out) per_out[b] = value;
-    }
-    if (!gp) return;
-    const float coef = -1.0f / (cnt * (id + kSinkEps));
-#pragma unroll
-    for (int ri = 0; ri < NR; ++ri) {
-      const int i = w + 16 * ri;
-      const float d = (i < n) ? coef * t.dk[i] : 0.f;
-#pragma unroll
-      for (int cj = 0; cj < NC; ++cj) LTRX_A_SET(ri, cj, d * gcj[cj]);
-    }
+    acc = sum_lc<LCN>(acc);
+    rdst[i * rstep] = acc;
+    __builtin_amdgcn_sched_barrier(0);
   }
   // ---- reverse Sinkhorn ----
   for (int it = T - 1; it >= 0; --it) {
-    const float* cn_it = cn + (size_t)it * L;
-    const float* rn_it = rn + (size_t)it * L;
-    // row step:  Y2 = Y1 / r
+    // this step's normalisers -> LDS (one global load per thread, in flight until the barrier; padded rows / columns: 1);
+    // double-buffered by step parity: a wave that is ahead writes the other buffer than the one a slower wave still reads
+    float* rvec = nrm[it & 1][0];
+    float* cnv = nrm[it & 1][1];
+    if (tid < W && tid < 256) rvec[tid] = (tid < n) ? rn[(size_t)it * L + min(tid, n - 1)] : 1.0f;
+    else if (tid >= 256 && tid - 256 < W) cnv[tid - 256] = (tid - 256 < n) ? cn[(size_t)it * L + min(tid - 256, n - 1)] : 1.0f;
+    __syncthreads();                                    // row sums of b (part_r) and the normalisers are complete
+    // row step: b_ij -= d_i m_ij; m_ij *= r_i; accumulate the column sums of the new b
+    float colsum[TBC];
 #pragma unroll
-    for (int ri = 0; ri < NR; ++ri) {
-      const int i = w + 16 * ri;
-      const float r = (i < n) ? rn_it[i] : 1.0f;
-      float av[NC];
-      float d = 0.f;
+    for (int j = 0; j < TBC; ++j) colsum[j] = 0.f;
 #pragma unroll
-      for (int cj = 0; cj < NC; ++cj) {
-        av[cj] = LTRX_A_GET(ri, cj);
-        d += av[cj] * m[ri][cj];
+    for (int i = 0; i < TBR; ++i) {
+      const float r = rvec[g.r0 + i];
+      float d = part_rows<NWC, W>(part_r, g.r0 + i);
+      d = (r > kSinkEps) ? d : 0.f;
+#pragma unroll
+      for (int j = 0; j < TBC; ++j) {
+        const float b1 = LTRX_B_GET(i, j) - d * m[i][j];
+        LTRX_B_SET(i, j, b1);
+        m[i][j] *= r;
+        colsum[j] += b1;
       }
-      d = (r > kSinkEps) ? wave_sum(d) : 0.f;
-      const float rr = 1.0f / r;
-#pragma unroll
-      for (int cj = 0; cj < NC; ++cj) {
-        const bool live = (i < n) && (lane + 64 * cj < n);
-        LTRX_A_SET(ri, cj, live ? (av[cj] - d) * rr : 0.f);
-        m[ri][cj] *= r;
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);                 // rows one after the other: no register room for several in flight
     }
-    // column step:  Y1 = X / c
 #pragma unroll
-    for (int cj = 0; cj < NC; ++cj) {
-      float d = 0.f;
-#pragma unroll
-      for (int ri = 0; ri < NR; ++ri) d += LTRX_A_GET(ri, cj) * m[ri][cj];
-      colpart[w][lane + 64 * cj] = d;
-      __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < TBC; ++j) {
+      cdst[j * cstep] = sum_lr<LCN>(colsum[j]);
     }
     __syncthreads();
-    if (tid < 64 * NC) {
-      float d = 0.f;
+    // column step: b_ij -= d_j m_ij; m_ij *= c_j; publish the row sums of the new b
+    float dj[TBC], cj[TBC];
 #pragma unroll
-      for (int ww = 0; ww < 16; ++ww) d += colpart[ww][tid];
-      const float c = (tid < n) ? cn_it[tid] : 1.0f;
-      dvec[tid] = (c > kSinkEps) ? d : 0.f;
-      cvec[tid] = c;
+    for (int j = 0; j < TBC; ++j) {
+      const float craw = cnv[g.c0 + j];
+      const float d = LTRX_PART4(part_c, g.c0 + j);
+      dj[j] = (craw > kSinkEps) ? d : 0.f;               // clamp active: no dependence on the column sum
+      cj[j] = fmaxf(craw, kSinkEps);
     }
-    __syncthreads();
 #pragma unroll
-    for (int cj = 0; cj < NC; ++cj) {
-      const int j = lane + 64 * cj;
-      const float c = cvec[j], d = dvec[j];
-      const float rc = 1.0f / c;
+    for (int i = 0; i < TBR; ++i) {
+      float acc = 0.f;
 #pragma unroll
-      for (int ri = 0; ri < NR; ++ri) {
-        const bool live = (w + 16 * ri < n) && (j < n);
-        LTRX_A_SET(ri, cj, live ? (LTRX_A_GET(ri, cj) - d) * rc : 0.f);
-        m[ri][cj] *= c;
+      for (int j = 0; j < TBC; ++j) {
+        const float b1 = LTRX_B_GET(i, j) - dj[j] * m[i][j];
+        LTRX_B_SET(i, j, b1);
+        m[i][j] *= cj[j];
+        acc += b1;
       }
+      acc = sum_lc<LCN>(acc);
+      rdst[i * rstep] = acc;                             // (part_r: its readers of this step are behind the barrier above)
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();      // colpart / cvec / dvec are rewritten by the next step
   }
-  // ---- row softmax backward (m holds P0 again): gz = P0 (g0 - <g0, P0>) / tau ----
+  // ---- row softmax backward (m holds P0 again, part_r the row sums of b per wave): gz = (b - P0 sum_j b) / tau; its column sums
+  //      weighted by the row scaling (direct term) and plain (Q) ----
+  {
+    __syncthreads();
+    float c1[TBC], c2[TBC];
 #pragma unroll
-  for (int ri = 0; ri < NR; ++ri) {
-    float av[NC];
-    float d = 0.f;
+    for (int j = 0; j < TBC; ++j) c1[j] = c2[j] = 0.f;
 #pragma unroll
-    for (int cj = 0; cj < NC; ++cj) {
-      av[cj] = LTRX_A_GET(ri, cj);
-      d += av[cj] * m[ri][cj];
-    }
-    d = wave_sum(d);
+    for (int i = 0; i < TBR; ++i) {
+      const float sc = (g.r0 + i < n) ? t.scal[min(g.r0 + i, n - 1)] : 0.f;
+      const float d = part_rows<NWC, W>(part_r, g.r0 + i);
 #pragma unroll
-    for (int cj = 0; cj < NC; ++cj) LTRX_A_SET(ri, cj, m[ri][cj] * (av[cj] - d) * inv_tau);
-  }
-  // ---- column sums of gz: weighted by the row scaling (direct term), then plain (Q) ----
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-    for (int cj = 0; cj < NC; ++cj) {
-      float s1 = 0.f;
-#pragma unroll
-      for (int ri = 0; ri < NR; ++ri) {
-        const int i = w + 16 * ri;
-        const float g = LTRX_A_GET(ri, cj);
-        s1 += (pass == 0) ? ((i < n) ? g * t.scal[i] : 0.f) : g;
+      for (int j = 0; j < TBC; ++j) {
+        const float gz = (LTRX_B_GET(i, j) - m[i][j] * d) * inv_tau;
+        c1[j] += gz * sc;
+        c2[j] += gz;
       }
-      colpart[w][lane + 64 * cj] = s1;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < TBC; ++j) {
+      c1[j] = sum_lr<LCN>(c1[j]);
+      c2[j] = sum_lr<LCN>(c2[j]);
+    }
+    __syncthreads();                                    // part_r readers (just above) and the last part_c readers are done
+    if (g.lr == 0) {
+#pragma unroll
+      for (int j = 0; j < TBC; ++j) {
+        part_c[g.wr][g.c0 + j] = c1[j];
+        part_r[g.wr][g.c0 + j] = c2[j];                 // (part_r reused, indexed by column here)
+      }
     }
     __syncthreads();
-    if (tid < 64 * NC) {
-      float s1 = 0.f;
-#pragma unroll
-      for (int ww = 0; ww < 16; ++ww) s1 += colpart[ww][tid];
-      if (pass == 0) cvec[tid] = s1; else dvec[tid] = s1;
+    if (tid < W) {
+      cvec[tid] = LTRX_PART4(part_c, tid);
+      dvec[tid] = LTRX_PART4(part_r, tid);
     }
     __syncthreads();
   }
@@ -735,8 +797,34 @@ __global__ void __launch_bounds__(1024) ltrx_neural_backward_reg_kernel(
     }
     gp[t.vidx[j]] = cvec[j] - dvec[j] * sgn_sum + cross;
   }
-#undef LTRX_A_GET
-#undef LTRX_A_SET
+#undef LTRX_BL
+#undef LTRX_B_GET
+#undef LTRX_B_SET
+}
+
+// residual trace of the block path: res[b][it] = max( max_j |colsum_{it+1}[j] - 1|, max_i |r_it[i] * (1 / r_it[i]) - 1| ) -- the
+// column sums of the state after step `it` are the ones step it + 1 starts from (slot max_iter = after the last step)
+__global__ void __launch_bounds__(256) ltrx_neural_residual_kernel(const float* __restrict__ y_true, int L, float pad, int max_iter,
+                                                                   const float* __restrict__ cnws, const float* __restrict__ rnws,
+                                                                   float* __restrict__ resws) {
+  __shared__ int redi[LTRX_MAX_WAVES];
+  const int b = blockIdx.x;
+  int cnt = 0;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) cnt += (y_true[(size_t)b * L + i] != pad);
+  const int n = block_sum_i(cnt, redi);
+  const float* cn = cnws + (size_t)b * (max_iter + 1) * L;
+  const float* rn = rnws + (size_t)b * max_iter * L;
+  const int wave = wave_id(), lane = lane_id(), nw = blockDim.x >> 6;
+  for (int it = wave; it < max_iter; it += nw) {        // one wave per step
+    float a = 0.f;
+    for (int j = lane; j < n; j += 64) {
+      a = fmaxf(a, fabsf(cn[(size_t)(it + 1) * L + j] - 1.0f));
+      const float r = rn[(size_t)it * L + j];
+      a = fmaxf(a, fabsf(r * (1.0f / r) - 1.0f));
+    }
+    a = wave_max(a);
+    if (lane == 0) resws[(size_t)b * max_iter + it] = (n > 0) ? a : 0.f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -746,8 +834,8 @@ __global__ void __launch_bounds__(1024) ltrx_neural_backward_reg_kernel(
 extern "C" size_t ltrx_neuralndcg_workspace_bytes(int B, int L, int max_iter) {
   if (B <= 0 || L <= 0 || max_iter < 0) return 0;
   const int mi = max_iter > 0 ? max_iter : 1;
-  return align64((size_t)B * 4) + align64((size_t)B * mi * 4) + 64 + 2 * align64((size_t)B * mi * L * 4) +
-         2 * align64((size_t)B * L * L * 4) + 64;
+  return align64((size_t)B * 4) + align64((size_t)B * mi * 4) + 64 + align64((size_t)B * (mi + 1) * L * 4) +
+         align64((size_t)B * mi * L * 4) + 2 * align64((size_t)B * L * L * 4) + 64;
 }
 
 extern "C" int ltrx_neuralndcg_prepare(const float* y_true, int B, int L, float pad_value, int k, int idcg_powered,
@@ -778,38 +866,42 @@ extern "C" int ltrx_neuralndcg_fwd_bwd(const float* y_pred, const float* y_true,
   (void)transposed;
   const int threads = 1024;   // 16 waves per slate
   const size_t lds = LTRX_NEURAL_LDS_FLOATS(L) * sizeof(float);
-  const bool fast = (L <= 240) && path == 0;     // path 1: the general (L2-streaming) kernels for every L
-#define LTRX_NEURAL_FWD(NR, NC)                                                                                          \
-  hipLaunchKernelGGL((ltrx_neural_forward_reg_kernel<NR, NC>), dim3(B), dim3(1024), lds, s, y_pred, y_true, L, pad_value, \
-                     temperature, max_iter, w.S, w.cn, w.rn, w.res)
-  if (fast) {
-    if (L <= 64) LTRX_NEURAL_FWD(4, 1);
-    else if (L <= 128) LTRX_NEURAL_FWD(8, 2);
-    else if (L <= 192) LTRX_NEURAL_FWD(12, 3);
-    else LTRX_NEURAL_FWD(15, 4);
+  // path 0: block-resident kernels (L <= 240, the WEB30K slate length; longer slates run the general kernels); 1: always the
+  // general L2-streaming kernels
+  const bool blk = (L <= 240) && path == 0;
+#define LTRX_NEURAL_FWD_BLK(LRN_, TBR_, TBC_, NWC_)                                                                        \
+  hipLaunchKernelGGL((ltrx_neural_forward_blk_kernel<LRN_, TBR_, TBC_, NWC_>), dim3(B), dim3(256 * NWC_), lds, s, y_pred,     \
+                     y_true, L, pad_value, temperature, max_iter, w.S, w.cn, w.rn)
+  if (blk) {       // 16 waves of small square tiles up to L = 192; above, 12 waves (4 x 3) of 15 x 5 tiles at 170 registers per thread
+    if (L <= 64) LTRX_NEURAL_FWD_BLK(8, 2, 2, 4);
+    else if (L <= 128) LTRX_NEURAL_FWD_BLK(8, 4, 4, 4);
+    else if (L <= 192) LTRX_NEURAL_FWD_BLK(8, 6, 6, 4);
+    else LTRX_NEURAL_FWD_BLK(4, 15, 5, 3);
+    LTRX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ltrx_neural_residual_kernel, dim3(B), dim3(256), 0, s, y_true, L, pad_value, max_iter, w.cn, w.rn, w.res);
   } else {
     hipLaunchKernelGGL(ltrx_neural_forward_kernel, dim3(B), dim3(threads), lds, s, y_pred, y_true, L, pad_value,
                        temperature, max_iter, w.S, w.cn, w.rn, w.res);
   }
-#undef LTRX_NEURAL_FWD
+#undef LTRX_NEURAL_FWD_BLK
   LTRX_LAUNCH_CHECK();
   hipLaunchKernelGGL(ltrx_neural_pick_iter_kernel, dim3(1), dim3(256), 0, s, w.res, B, max_iter, tol, w.titer, iters_out);
   LTRX_LAUNCH_CHECK();
-#define LTRX_NEURAL_BWD(NR, NC, NCL)                                                                                      \
-  hipLaunchKernelGGL((ltrx_neural_backward_reg_kernel<NR, NC, NCL>), dim3(B), dim3(1024), 0, s, y_pred, y_true, idcg,      \
-                     nonzero_count, L, pad_value, 1.0f / temperature, powered_relevancies, k, k_rows, max_iter, w.titer, w.S, w.cn, \
-                     w.rn, w.per, per_slate_out, grad_out)
-  if (fast) {
-    if (L <= 64) LTRX_NEURAL_BWD(4, 1, 0);
-    else if (L <= 128) LTRX_NEURAL_BWD(8, 2, 0);
-    else if (L <= 192) LTRX_NEURAL_BWD(12, 3, 0);
-    else LTRX_NEURAL_BWD(15, 4, 2);
+#define LTRX_NEURAL_BWD_BLK(LRN_, TBR_, TBC_, NWC_, TLC_)                                                                  \
+  hipLaunchKernelGGL((ltrx_neural_backward_blk_kernel<LRN_, TBR_, TBC_, NWC_, TLC_>), dim3(B), dim3(256 * NWC_), 0, s, y_pred, \
+                     y_true, idcg, nonzero_count, L, pad_value, 1.0f / temperature, powered_relevancies, k, k_rows, max_iter,       \
+                     w.titer, w.S, w.cn, w.rn, w.per, per_slate_out, grad_out)
+  if (blk) {
+    if (L <= 64) LTRX_NEURAL_BWD_BLK(8, 2, 2, 4, 0);
+    else if (L <= 128) LTRX_NEURAL_BWD_BLK(8, 4, 4, 4, 0);
+    else if (L <= 192) LTRX_NEURAL_BWD_BLK(8, 6, 6, 4, 0);
+    else LTRX_NEURAL_BWD_BLK(4, 15, 5, 3, 2);
   } else {
     hipLaunchKernelGGL(ltrx_neural_backward_kernel, dim3(B), dim3(threads), lds, s, y_pred, y_true, idcg, nonzero_count, L,
                        pad_value, 1.0f / temperature, powered_relevancies, k, k_rows, max_iter, w.titer, w.S, w.A, w.cn, w.rn,
                        w.per, per_slate_out, grad_out);
   }
-#undef LTRX_NEURAL_BWD
+#undef LTRX_NEURAL_BWD_BLK
   LTRX_LAUNCH_CHECK();
   // loss = -sum_b value_b / nonzero_count  (device scalar) -> two tiny kernels: sum, then scale
   int rc = ltrx_launch_finalize_sum(w.per, B, -1.0f, loss_out, s);
