@@ -778,7 +778,18 @@ class FusedTrainer(object):
             if self._warm < 2 or len(self._graphs) >= 4:
                 self._warm += 1                       # warm-up outside capture (lazy module loads, kernel attributes, workspaces)
                 return self._eager()
-            segs = self._graphs[key] = self._capture()
+            try:
+                segs = self._graphs[key] = self._capture()
+            except Exception as exc:                  # noqa: BLE001
+                if self.world == 1:
+                    raise
+                # sharded: a collective backend that cannot live next to a stream capture must not take the job down --
+                # the eager step is the same arithmetic (tests/dist_equiv_worker.py), only with launch overhead
+                import warnings
+                warnings.warn("allrank_amd: hipGraph capture of the sharded step failed (%r); running eagerly" % (exc,))
+                self.use_graph = False
+                self._graphs.clear()
+                return self._eager()
         for g, after in segs:                         # (capture only records: the replay executes this step)
             g.replay()
             if after is not None:
@@ -808,22 +819,30 @@ class FusedTrainer(object):
         torch.cuda.synchronize(self.dev)
         self._cap_stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self._cap_stream):
+            # "thread_local": only this thread's calls are checked against the capture -- a process group's watchdog thread or a
+            # data-loader thread touching the runtime must not invalidate it
             cur = [torch.cuda.CUDAGraph()]
-            cur[0].capture_begin(pool=self._graph_pool)
+            cur[0].capture_begin(pool=self._graph_pool, capture_error_mode="thread_local")
 
             def seg_break(after):
                 cur[0].capture_end()
                 segs.append((cur[0], after))
                 cur[0] = torch.cuda.CUDAGraph()
-                cur[0].capture_begin(pool=self._graph_pool)
+                cur[0].capture_begin(pool=self._graph_pool, capture_error_mode="thread_local")
 
             self._seg_break = seg_break
+            ok = False
             try:
                 with sharding.shard_context(int(self._divisor), self.group, deferred=seg_break) if self.world > 1 else _null():
                     self._graph_loss = self._full()
+                ok = True
             finally:
                 self._seg_break = None
-                cur[0].capture_end()
+                try:
+                    cur[0].capture_end()
+                except Exception:                     # noqa: BLE001 -- the original error (if any) is the one to report
+                    if ok:
+                        raise
             segs.append((cur[0], None))
         torch.cuda.current_stream(self.dev).wait_stream(self._cap_stream)
         return segs

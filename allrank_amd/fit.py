@@ -149,6 +149,43 @@ class _Prefetcher(object):
                 nxt = None
 
 
+def make_result(epoch, train_metrics, val_metrics, num_params):
+    """the dict main.py:90 receives, with the VALUE TYPES the reference's fit returns: main.py:104 hands it to
+    dump_experiment_result (utils/experiments.py:20-24), which calls ``.item()`` on every metric and on num_params -- numpy scalars in
+    the reference (np.mean in train_utils.py:38-43, np.sum in model_utils.py:21-28), so numpy scalars here"""
+    return {"epochs": epoch,
+            "train_metrics": {k: np.float64(v) for k, v in train_metrics.items()},
+            "val_metrics": {k: np.float64(v) for k, v in val_metrics.items()},
+            "num_params": np.int64(num_params)}
+
+
+def _batch_shape(dl):
+    """(slates per batch, slate length) of a loader without consuming a batch: DataLoader.batch_size and the shape of one dataset
+    item ([L, F] features, dataset_loading.py:19-29); loaders that do not expose them are asked for their first batch instead.
+    Also returns the fraction of valid (non-padded) slots over a sample of the set (the auto choice of variable-length execution)."""
+    try:
+        bsz, ds = int(dl.batch_size), dl.dataset
+        items = [ds[i] for i in range(0, len(ds), max(1, len(ds) // 32))][:32]
+        ys = torch.stack([torch.as_tensor(it[1]).float() for it in items])
+        return bsz, int(items[0][0].shape[0]), float((ys != PADDED_Y_VALUE).float().mean())
+    except Exception:                                     # noqa: BLE001 -- any custom iterable
+        first = next(iter(dl))
+        return int(first[0].shape[0]), int(first[0].shape[1]), float((first[1] != PADDED_Y_VALUE).float().mean())
+
+
+def _check_same_batch(xb, yb, world):
+    """sharded runs: every rank must see the SAME global batch for shard_slates to partition it (the reference's DataLoader
+    shuffles per process; give the ranks one sampler seed) -- checked on the first batch with an all-gathered checksum"""
+    import torch.distributed as dist
+    chk = torch.stack([xb.double().sum(), yb.double().sum(), torch.tensor(float(xb.shape[0]), device=xb.device, dtype=torch.float64)])
+    allc = [torch.empty_like(chk) for _ in range(world)]
+    dist.all_gather(allc, chk)
+    if any(not torch.equal(c, allc[0]) for c in allc):
+        raise RuntimeError("allrank_amd.fit: the ranks received different first batches -- under torch.distributed every rank must "
+                           "iterate the same global batches (same DataLoader sampler seed / shuffle order); rank r trains on its "
+                           "contiguous block of each of them")
+
+
 def _evaluate(model, loss_func, dl, device, metrics, trainer=None):
     """validation pass of train_utils.py:101-107: mean loss (weighted by batch size) and metric means, no autograd.  With a
     FusedTrainer the scores come from its forward-only pass (``FusedTrainer.score``: the kernels of the training step, dropout
@@ -156,7 +193,7 @@ def _evaluate(model, loss_func, dl, device, metrics, trainer=None):
     tot, num = torch.zeros((), device=device), 0
     acc = {name: [] for name in metrics}
     with torch.no_grad():
-        for xb, yb, idx in _Prefetcher(dl, device):
+        for xb, yb, idx in (dl if isinstance(dl, _Prefetcher) else _Prefetcher(dl, device)):
             n = int(xb.shape[0])
             if trainer is not None and n <= trainer.B and tuple(xb.shape[1:2]) == (trainer.L,):
                 xs, ys, ids = _pad_batch(xb, yb, idx, trainer.B)
@@ -196,12 +233,11 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
 
     spec, reason = _fused_spec(model, loss_func, optimizer) if use_fused else (None, "use_fused=False")
     trainer, fused = None, False
-    first = next(iter(train_dl))
-    B_glob, L = int(first[0].shape[0]), int(first[0].shape[1])
+    B_glob, L, valid_frac = _batch_shape(train_dl)
     lo, hi = shard_slates(B_glob, rank, world)
     if spec is not None:
         if compact is None:
-            compact = float((first[1] != PADDED_Y_VALUE).float().mean()) < 0.8
+            compact = valid_frac < 0.8
         try:
             trainer = FusedTrainer(model, spec[0], spec[1], hi - lo, L, lr=spec[2], world_size=world, use_graph=True,
                                    gradient_clipping_norm=gradient_clipping_norm, compact=bool(compact), gemm=gemm)
@@ -215,12 +251,17 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
     log.info("allrank_amd.fit: %s step%s", last_run["engine"], (" (" + reason + ")") if reason else "")
 
     epoch, train_metrics, val_metrics = -1, {}, {}
+    train_pf, valid_pf = _Prefetcher(train_dl, device), _Prefetcher(valid_dl, device)     # one per loader: stream and staging sets persist
+    checked = world == 1
     for epoch in range(epochs):
         model.train()
         tot, num = torch.zeros((), device=device), 0
         tm = {name: None for name in metrics}
-        for xb, yb, idx in _Prefetcher(train_dl, device):
+        for xb, yb, idx in train_pf:
             real_glob = int(xb.shape[0])
+            if not checked:
+                _check_same_batch(xb, yb, world)
+                checked = True
             if world > 1:
                 a, b = shard_slates(real_glob, rank, world)
                 xb, yb, idx = xb[a:b], yb[a:b], idx[a:b]
@@ -252,7 +293,7 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
                 off += 1
 
         model.eval()
-        val_loss, val_metrics = _evaluate(model, loss_func, valid_dl, device, metrics, trainer if fused else None)
+        val_loss, val_metrics = _evaluate(model, loss_func, valid_pf, device, metrics, trainer if fused else None)
 
         lr_now = optimizer.param_groups[0]["lr"]
         if writer is not None:
@@ -284,4 +325,4 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
         torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, os.path.join(output_dir, "model.pkl"))
     if writer is not None:
         writer.close_all_writers()
-    return {"epochs": epoch, "train_metrics": train_metrics, "val_metrics": val_metrics, "num_params": num_params}
+    return make_result(epoch, train_metrics, val_metrics, num_params)

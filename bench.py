@@ -15,8 +15,10 @@ dense slates, 256 slates per GPU by default (the reference's batch_size 64 point
 `--slates-per-gpu` slates, losses are normalised by the global batch and gradients summed over RCCL.
 
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant hand-written kernel of the step (timed live with
-HIP events on the launch stream, in a side pass after the timed region); `cpu_baseline` is the numpy oracle's
-training step (oracle/model_oracle.py, kind "port") on a bounded sample of the same workload.
+HIP events on the launch stream, in a side pass after the timed region; FC-only workloads: the whole step against the
+HBM roof; NeuralNDCG workloads add `roofline_loss_kernels` against the fp32 vector peak); `cpu_baseline` is the reference step
+restated with the torch CPU operators the reference itself calls (oracle/torch_port.py, kind "port", pinned to the numpy oracle;
+losses it does not cover: the numpy oracle) on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -466,6 +468,27 @@ def main():
             roof = dict(kernel=name, bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
                         frac=round(ach / PEAK_HBM_GBPS, 4), traffic=None, avg_launch_us=round(k["sec"] * 1e6, 1),
                         algorithmic_bytes_per_launch=by)
+        if not w["N"]:
+            # FCModel-only workloads (BASELINE configs[1]): 53 kFLOP per item against 552 B -- the step is HBM / launch bound, not MFMA
+            # bound, so the roofline is quoted for the whole step: SURVEY 8(d)'s algorithmic bytes per item (features once, label, score
+            # and gradient round trip) x items per step / the timed step
+            by = float(4 * w["n_features"] + 8) * B * L
+            ach = by / (dt / args.steps) / 1e9
+            roof = dict(kernel="whole step (FC GEMMs + score head + ListNet + Adam: ~15 launches, profiles/r03_bench_fc_listnet_kernel_stats.md)",
+                        bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(ach / PEAK_HBM_GBPS, 4), traffic=None,
+                        algorithmic_bytes_per_launch=by, avg_launch_us=round(dt / args.steps * 1e6, 1),
+                        note="launch / latency bound at this size: 0.2 ms per step of ~15 kernels of 5-50 us")
+        loss_roof = None
+        if w["loss"].startswith("neuralNDCG"):
+            # the Sinkhorn kernels are VALU bound (no contraction): algorithmic flops = n^2 x (4 per forward step + 6 per backward step)
+            # x max_iter + ~10 n^2 for NeuralSort / softmax and its backward, against the fp32 vector peak
+            it_ = int(w.get("loss_args", {}).get("max_iter", 50))
+            fl = float(B) * L * L * (10.0 * it_ + 10.0)
+            sec = kern["loss_fwd_bwd"]["sec"]
+            loss_roof = dict(kernel="ltrx_neural_forward_blk_kernel + ltrx_neural_backward_blk_kernel (whole plugin call)", bound="valu",
+                             achieved=round(fl / sec / 1e12, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                             frac=round(fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), algorithmic_flops_per_launch=fl,
+                             avg_launch_us=round(sec * 1e6, 1))
         out = {
             "metric": "slate-items/sec training (WEB30K synth, slate 240)", "value": round(value, 1),
             "unit": "slate-items/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -485,6 +508,7 @@ def main():
             "last_loss": last_loss,
             "valid_items_per_s": (round(value * float((y != -1).float().mean().item()), 1) if args.ragged else None),
             "roofline": roof,
+            "roofline_loss_kernels": loss_roof,
             "kernel_times_us": {n: round(v["sec"] * 1e6, 1) for n, v in kern.items()},
         }
         if world == 1 and B != 64 and args.engine == "fused" and not args.no_side_pass:

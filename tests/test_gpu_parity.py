@@ -616,12 +616,15 @@ def test_sharded_step_equals_single_rank_step():
     assert "EQUIV_OK" in out.stdout, out.stdout[-2000:]
 
 
-def test_neuralndcg_register_path_equals_general_path():
-    """the register-resident fast path (L <= 240) and the general L2-streaming kernels agree with each other and the oracle."""
+def test_neuralndcg_block_resident_path_equals_general_path():
+    """the block-resident kernels (L <= 240: 2 x 2 / 4 x 4 / 6 x 6 tiles on 16 waves, 15 x 5 tiles on 12 waves) and the general
+    L2-streaming kernels agree with each other and the oracle; L = 250 runs the general kernels on both paths; the 3-item slates
+    converge below tol before max_iter (batch-global early exit: the rewind of the backward kernel runs)."""
     from allrank_amd import losses as E, _lib as LB
     from tests.golden.make_inputs import make_inputs
     lib = LB.lib()
-    for (B, L, seed) in [(16, 240, 21), (9, 100, 22), (5, 64, 23), (4, 130, 24)]:
+    for (B, L, seed) in [(16, 240, 21), (9, 100, 22), (5, 64, 23), (4, 130, 24), (3, 190, 25), (6, 33, 26), (2, 250, 27), (4, 3, 28), (7, 1, 29),
+                         (3, 200, 30)]:
         s, y = make_inputs(B, L, seed)
         out = {}
         for force in (0, 1):
