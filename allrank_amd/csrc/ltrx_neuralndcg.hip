@@ -407,6 +407,10 @@ __global__ void __launch_bounds__(1024) ltrx_neural_backward_kernel(
 // Same arithmetic per element as the kernels above (x * (1/c), clamp at 1e-10, softmax as exp(z - max) / sum); only the order of
 // the partial sums inside a row / column differs.  Workspace: cn has max_iter + 1 rows per slate on this path.
 // ---------------------------------------------------------------------------------------------------------
+// (1 / c is an IEEE division, ~10 instructions: the hardware reciprocal v_rcp_f32 halves the VALU count of a forward iteration
+//  (700 -> 360 per wave) but only buys 5 % of the call -- the loop is bound by barrier / DPP / LDS latency, not by VALU issue --
+//  and costs another ulp per normalisation; measured and not adopted, profiles/NOTES.md round 3)
+#define LTRX_NEURAL_RCP(x) (1.0f / (x))
 template <int LCN>
 __device__ __forceinline__ float sum_lc(float v) {       // all-reduce over the LCN consecutive lanes that share lr
   v += LTRX_DPP_F(0.f, v, 0xB1, 0xF, true);               // quad_perm [1,0,3,2]
@@ -542,7 +546,7 @@ __global__ void __launch_bounds__(256 * NWC) ltrx_neural_forward_blk_kernel(cons
     if (it == max_iter) break;
 #pragma unroll
     for (int j = 0; j < TBC; ++j) {
-      const float rc = 1.0f / fmaxf(LTRX_PART4(part_c, g.c0 + j), kSinkEps);
+      const float rc = LTRX_NEURAL_RCP(fmaxf(LTRX_PART4(part_c, g.c0 + j), kSinkEps));
 #pragma unroll
       for (int i = 0; i < TBR; ++i) m[i][j] *= rc;
     }
@@ -558,7 +562,7 @@ __global__ void __launch_bounds__(256 * NWC) ltrx_neural_forward_blk_kernel(cons
     if (tid >= 256 && tid - 256 < n) rn[(size_t)it * L + tid - 256] = fmaxf(part_rows<NWC, W>(part_r, tid - 256), kSinkEps);
 #pragma unroll
     for (int i = 0; i < TBR; ++i) {
-      const float rr = 1.0f / fmaxf(part_rows<NWC, W>(part_r, g.r0 + i), kSinkEps);
+      const float rr = LTRX_NEURAL_RCP(fmaxf(part_rows<NWC, W>(part_r, g.r0 + i), kSinkEps));
 #pragma unroll
       for (int j = 0; j < TBC; ++j) m[i][j] *= rr;
     }
@@ -876,7 +880,7 @@ extern "C" int ltrx_neuralndcg_fwd_bwd(const float* y_pred, const float* y_true,
     if (L <= 64) LTRX_NEURAL_FWD_BLK(8, 2, 2, 4);
     else if (L <= 128) LTRX_NEURAL_FWD_BLK(8, 4, 4, 4);
     else if (L <= 192) LTRX_NEURAL_FWD_BLK(8, 6, 6, 4);
-    else LTRX_NEURAL_FWD_BLK(4, 15, 5, 3);
+    else LTRX_NEURAL_FWD_BLK(4, 15, 5, 3);         // (8 waves of 15 x 8 tiles: 2 % slower, profiles/NOTES.md round 3)
     LTRX_LAUNCH_CHECK();
     hipLaunchKernelGGL(ltrx_neural_residual_kernel, dim3(B), dim3(256), 0, s, y_true, L, pad_value, max_iter, w.cn, w.rn, w.res);
   } else {

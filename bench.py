@@ -450,7 +450,7 @@ def main():
                         frac=round(alg / PEAK_BF16_MFMA_TFLOPS, 4), traffic=traffic,
                         traffic_detail=traffic_detail,
                         algorithmic_bytes_per_launch=4.0 * (B * L * w["fc_sizes"][-1] + w["d_ff"] * w["fc_sizes"][-1] + B * L * w["d_ff"]),
-                        traffic_source="live: measure_hbm_traffic() (rocprofv3 --pmc child passes); committed copy of the same passes: profiles/r02_pmc_gemm256.md",
+                        traffic_source="live: measure_hbm_traffic() (rocprofv3 --pmc child passes); committed copy of the same passes: profiles/r03_pmc_gemm256.md",
                         avg_launch_us=round(k["sec"] * 1e6, 1),
                         timing="HIP events around the %d FFN-1 launches of 5 eager training steps after the timed region" % (5 * w["N"]),
                         back_to_back_launch_us=round(k.get("sec_back_to_back", k["sec"]) * 1e6, 1),
