@@ -252,7 +252,11 @@ struct SmemNT {
   __bf16 b[NT][256 * 32];
 };
 
-template <bool TAIL, int BM, int NT>
+// BIMG: B points at a pre-split IMAGE of the operand instead of fp32 values -- per 4 consecutive k the 16 bytes {hi0..hi3, lo0..lo3}
+// (bf16) in place of the 4 floats, same addressing (ltrx_split_image; the weights and their transposes, refreshed once per optimizer
+// step).  The staging of B is then a plain copy: half of the kernel's split work (VALU, and the power it draws) is gone, the bits
+// that reach LDS -- and the results -- are identical.
+template <bool TAIL, int BM, int NT, bool BIMG>
 __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                               int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
                                                               const float* __restrict__ bias, int act,
@@ -298,9 +302,14 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
         *reinterpret_cast<bf16x4*>(&d.a[0][o]) = h;
         if (NT == 2) *reinterpret_cast<bf16x4*>(&d.a[L1][o]) = l;
       }
-      split4<2>(rb[p], h, l, l2);
-      *reinterpret_cast<bf16x4*>(&d.b[0][o]) = h;
-      if (NT == 2) *reinterpret_cast<bf16x4*>(&d.b[L1][o]) = l;
+      if constexpr (BIMG) {
+        *reinterpret_cast<float2*>(&d.b[0][o]) = make_float2(rb[p].x, rb[p].y);
+        if (NT == 2) *reinterpret_cast<float2*>(&d.b[L1][o]) = make_float2(rb[p].z, rb[p].w);
+      } else {
+        split4<2>(rb[p], h, l, l2);
+        *reinterpret_cast<bf16x4*>(&d.b[0][o]) = h;
+        if (NT == 2) *reinterpret_cast<bf16x4*>(&d.b[L1][o]) = l;
+      }
     }
   };
   f32x16 acc[RI][2];
@@ -702,6 +711,30 @@ static void launch_slab_reduce(const float* slabs, int splits, size_t n, float* 
                      (int)blocks, bslabs, bsplits, nb, bias_out);
 }
 
+// pre-split operand image: every 4 consecutive floats of src become the 16 bytes {hi0..hi3, lo0..lo3} (bf16) of dst -- the same
+// split4 the kernels apply while staging, so a GEMM fed from the image is bit-identical to one fed from the fp32 values
+__global__ void __launch_bounds__(256) ltrx_split_image_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    bf16x4 h, l, l2;
+    split4<2>(src[i], h, l, l2);
+    float4 o;
+    *reinterpret_cast<bf16x4*>(&o.x) = h;
+    *reinterpret_cast<bf16x4*>(&o.z) = l;
+    dst[i] = o;
+  }
+}
+
+extern "C" int ltrx_split_image(const float* src, void* dst, size_t n, ltrx_stream_t stream) {
+  if (!src || !dst || (n & 3) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return LTRX_EINVAL;
+  if (n == 0) return LTRX_OK;
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ltrx_split_image_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n / 4);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
@@ -721,7 +754,7 @@ static void launch_nt(const float* A, int lda, const float* B, int ldb, float* C
                      ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step);
 }
 
-extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, const void* B_image, float* C, int ldc, int M, int N, int K,
                             const float* bias, int act, const float* aux, int ldaux, float drop_p, uint32_t drop_seed,
                             const uint32_t* drop_step, int strict, int tile, ltrx_stream_t stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2 || tile < 0) return LTRX_EINVAL;
@@ -752,9 +785,9 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
       // generated in the epilogue -- its hash is indexed by the row of THIS launch.
       const int m1 = (256 / (N / 256)) * 256;
       const int prec = plain ? 2 : strict;
-      int rc = ltrx_gemm_nt(A, lda, B, ldb, C, ldc, m1, N, K, bias, act, aux, ldaux, drop_p, drop_seed, drop_step, prec, 0, stream);
+      int rc = ltrx_gemm_nt(A, lda, B, ldb, B_image, C, ldc, m1, N, K, bias, act, aux, ldaux, drop_p, drop_seed, drop_step, prec, 0, stream);
       if (rc != LTRX_OK) return rc;
-      return ltrx_gemm_nt(A + (size_t)m1 * lda, lda, B, ldb, C + (size_t)m1 * ldc, ldc, M - m1, N, K, bias, act,
+      return ltrx_gemm_nt(A + (size_t)m1 * lda, lda, B, ldb, B_image, C + (size_t)m1 * ldc, ldc, M - m1, N, K, bias, act,
                           aux ? aux + (size_t)m1 * ldaux : nullptr, ldaux, drop_p, drop_seed, drop_step, prec, 0, stream);
     }
     if (t >= 360 || (t >= 168 && t <= 256)) v = 6;
@@ -770,7 +803,9 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
     static std::atomic<uint64_t> attr_done{0};
     const int arc = ltrx_once_per_device(attr_done, []() {
 #define LTRX_NT256_ATTR(TAIL_, BM_, NT_)                                                                                     \
-  (hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<TAIL_, BM_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+  (hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<TAIL_, BM_, NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                       (int)(2 * sizeof(SmemNT<BM_, NT_>))) != hipSuccess ||                                               \
+   hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<TAIL_, BM_, NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                        (int)(2 * sizeof(SmemNT<BM_, NT_>))) != hipSuccess)
       if (LTRX_NT256_ATTR(false, 256, 2) || LTRX_NT256_ATTR(true, 256, 2) || LTRX_NT256_ATTR(false, 128, 2) ||
           LTRX_NT256_ATTR(true, 128, 2) || LTRX_NT256_ATTR(false, 256, 1) || LTRX_NT256_ATTR(true, 256, 1) ||
@@ -783,12 +818,19 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, fl
     const int tiles_n = N / 256;
     const int bm = (v == 6) ? 256 : 128;
     const dim3 grid(((M + bm - 1) / bm) * tiles_n);
-#define LTRX_NT256_(TAIL_, BM_, NT_)                                                                                         \
-  hipLaunchKernelGGL((ltrx_gemm_nt256_kernel<TAIL_, BM_, NT_>), grid, dim3(512), 2 * sizeof(SmemNT<BM_, NT_>), s, A, lda, B, ldb, C, \
-                     ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step)
+    // the pre-split image of B (same addressing as B, 16-byte aligned) replaces the fp32 operand in this kernel family only
+    const bool bimg = B_image != nullptr && (((uintptr_t)B_image) & 15) == 0;
+    const float* Bk = bimg ? reinterpret_cast<const float*>(B_image) : B;
+#define LTRX_NT256_(TAIL_, BM_, NT_, IMG_)                                                                                   \
+  hipLaunchKernelGGL((ltrx_gemm_nt256_kernel<TAIL_, BM_, NT_, IMG_>), grid, dim3(512), 2 * sizeof(SmemNT<BM_, NT_>), s, A, lda, Bk, \
+                     ldb, C, ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step)
 #define LTRX_NT256(TAIL_, BM_)                                                                                               \
   do {                                                                                                                       \
-    if (plain) LTRX_NT256_(TAIL_, BM_, 1); else LTRX_NT256_(TAIL_, BM_, 2);                                                  \
+    if (plain) {                                                                                                             \
+      if (bimg) LTRX_NT256_(TAIL_, BM_, 1, true); else LTRX_NT256_(TAIL_, BM_, 1, false);                                    \
+    } else {                                                                                                                 \
+      if (bimg) LTRX_NT256_(TAIL_, BM_, 2, true); else LTRX_NT256_(TAIL_, BM_, 2, false);                                    \
+    }                                                                                                                        \
   } while (0)
     if (v == 6) {
       if (M % 256) LTRX_NT256(true, 256); else LTRX_NT256(false, 256);

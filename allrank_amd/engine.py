@@ -7,6 +7,8 @@ Differences from the reference driver (all outside the arithmetic): no ``loss.it
 the device; call ``.item()`` when you want it), gradients live in one flat buffer (allrank_amd.parallel), and under
 ``world_size > 1`` the loss is normalised by the global batch and gradients are summed over RCCL.
 """
+import ctypes
+
 import torch
 from torch.nn.utils import clip_grad_norm_
 
@@ -80,7 +82,8 @@ class FusedTrainer(object):
     """
 
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
-                 use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None, compact=False):
+                 use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None, compact=False,
+                 weight_images=True):
         """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
         products), "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs), or "bf16" -- the THROUGHPUT mode: one bf16
         product per contraction in the dense projections AND in attention (fp32 storage, accumulation, LayerNorm, softmax,
@@ -92,7 +95,9 @@ class FusedTrainer(object):
         consecutive rows, every row-wise kernel runs over the packed rows only, attention reads per-slate extents from
         cu_seqlens, and scores / d loss/d scores move between the packed rows and the padded [B, L] grid the loss kernels
         work on.  Same loss and gradients as the padded step (padded rows carry no gradient and are masked as keys); the
-        row count changes per batch, so this mode runs eagerly (no hipGraph)."""
+        row count changes per batch, so this mode runs eagerly (no hipGraph).
+        weight_images=False: the GEMMs split the weight operand on the fly in every tile instead of reading the per-step pre-split
+        images (same results bit for bit; kept for A/B measurements)."""
         import torch.nn as nn
         from . import _lib as LB
         from .losses import FusedLoss
@@ -102,6 +107,7 @@ class FusedTrainer(object):
         if gemm not in ("split_bf16", "split_bf16_strict", "hipblaslt", "bf16"):
             raise ValueError("gemm must be split_bf16, split_bf16_strict, hipblaslt or bf16")
         self.gemm = gemm
+        self.weight_images = bool(weight_images)
         self._prec = {"split_bf16_strict": 1, "bf16": 2}.get(gemm, 0)        # precision code of ltrx_gemm_nt / ltrx_gemm_tn
         # attention arithmetic of THIS trainer, passed with every ltrx_mha_fwd / ltrx_mha_bwd call (the library keeps no mode):
         # 1 = three bf16 products (fp32-class, parity), 2 = one product (the "bf16" throughput mode)
@@ -340,6 +346,10 @@ class FusedTrainer(object):
             self._tdesc = torch.tensor(desc if desc else [0, 0, 0, 0], dtype=torch.int64, device=dev)
             self._tstart = torch.tensor(tstart, dtype=torch.int32, device=dev)
             self._tn, self._ttiles = len(srcs), tstart[-1]
+            # pre-split bf16 hi / lo IMAGES of the weights and of their transposes (same offsets as flat_p / flat_t): what the
+            # large-tile NT GEMMs stage as operand B without splitting it again in every tile (ltrx_split_image, include/ltrx.h)
+            self.flat_pi = torch.empty_like(self.flat_p)
+            self.flat_ti = torch.empty_like(self.flat_t)
             self._refresh_transposes()
         self.loss = FusedLoss(loss_name, B, L, dev, **(loss_args or {}))
         if (self.n_out > 1) != (loss_name == "ordinal") or (loss_name == "ordinal" and int(loss_args["n"]) != self.n_out):
@@ -417,10 +427,23 @@ class FusedTrainer(object):
             self.woutT_pad[:, :self.n_out].copy_(self.W(self.model.output_layer.w_1.weight).t())
         if self.gemm == "hipblaslt":
             return
+        P = self.LB.ptr
         if self._tn:
-            P = self.LB.ptr
             self.LB.check(self.lib.ltrx_transpose_batch(P(self.flat_p), P(self.flat_t), P(self._tdesc), P(self._tstart), self._tn,
                                                         self._ttiles, self._st()), "transpose_batch")
+            self.LB.check(self.lib.ltrx_split_image(P(self.flat_t), P(self.flat_ti), self.flat_t.numel(), self._st()), "split_image(W^T)")
+        self.LB.check(self.lib.ltrx_split_image(P(self.flat_p), P(self.flat_pi), self.nflat, self._st()), "split_image(W)")
+
+    def _img(self, w):
+        """address of the pre-split image of a weight view (inside flat_p) or of a transposed copy (inside flat_t); None otherwise"""
+        if w is None or self.gemm == "hipblaslt" or not self.weight_images:
+            return None
+        a = w.data_ptr()
+        for base, img in ((self.flat_p, self.flat_pi), (self.flat_t, self.flat_ti)):
+            lo = base.data_ptr()
+            if lo <= a < lo + 4 * base.numel():
+                return ctypes.c_void_p(img.data_ptr() + (a - lo))
+        return None
 
     def _bucket_done(self, k):
         """gradient bucket k is final: start its all-reduce(SUM) now, behind the rest of the backward (the collective runs
@@ -459,7 +482,7 @@ class FusedTrainer(object):
                 self._drop_apply(out, out, p, seed)
             return
         P = self.LB.ptr
-        self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), P(out), out.stride(0), self.rows, w.shape[0],
+        self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), self._img(w), P(out), out.stride(0), self.rows, w.shape[0],
                                             x.shape[1], P(b), act, None, 0, float(p), seed, P(self.drop_step),
                                             self._prec, 0, self._st()), "gemm_nt(fwd)")
 
@@ -475,7 +498,7 @@ class FusedTrainer(object):
                 self._drop_apply(out, out, p, seed)
             return
         P = self.LB.ptr
-        self.LB.check(self.lib.ltrx_gemm_nt(P(dy), dy.stride(0), P(wT), wT.stride(0), P(out), out.stride(0), self.rows,
+        self.LB.check(self.lib.ltrx_gemm_nt(P(dy), dy.stride(0), P(wT), wT.stride(0), self._img(wT), P(out), out.stride(0), self.rows,
                                             wT.shape[0], dy.shape[1], None, 2 if relu_of is not None else 0, P(relu_of),
                                             relu_of.stride(0) if relu_of is not None else 0, float(p), seed, P(self.drop_step),
                                             self._prec, 0, self._st()), "gemm_nt(dgrad)")

@@ -240,7 +240,7 @@ class _LinearFn(torch.autograd.Function):
         b = L.f32c(b) if b is not None else None
         M = x2.shape[0]
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        L.check(L.lib().ltrx_gemm_nt(L.ptr(x2), K, L.ptr(w), K, L.ptr(y), N, M, N, K, L.ptr(b), int(act), None, 0, 0.0, 0, None, 0,
+        L.check(L.lib().ltrx_gemm_nt(L.ptr(x2), K, L.ptr(w), K, None, L.ptr(y), N, M, N, K, L.ptr(b), int(act), None, 0, 0.0, 0, None, 0,
                                      0, L.stream_of(x2)), "gemm_nt(linear fwd)")
         ctx.save_for_backward(x2, w, y if act else None)
         ctx.has_bias, ctx.act, ctx.xshape = b is not None, int(act), x.shape
@@ -260,7 +260,7 @@ class _LinearFn(torch.autograd.Function):
             if N % 4 == 0:
                 wT = w.t().contiguous()                          # [K, N]: the NT kernel wants both operands contraction-contiguous
                 dx = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
-                L.check(lib.ltrx_gemm_nt(L.ptr(dy2), N, L.ptr(wT), N, L.ptr(dx), K, M, K, N, None, 0, None, 0, 0.0, 0, None, 0,
+                L.check(lib.ltrx_gemm_nt(L.ptr(dy2), N, L.ptr(wT), N, None, L.ptr(dx), K, M, K, N, None, 0, None, 0, 0.0, 0, None, 0,
                                          0, L.stream_of(dy2)), "gemm_nt(linear dgrad)")
             else:
                 dx = dy2 @ w
@@ -299,9 +299,9 @@ class _FFNFn(torch.autograd.Function):
         lib, st = L.lib(), L.stream_of(x2)
         r = torch.empty((M, F_), dtype=torch.float32, device=x.device)
         y = torch.empty((M, N), dtype=torch.float32, device=x.device)
-        L.check(lib.ltrx_gemm_nt(L.ptr(x2), K, L.ptr(w1), K, L.ptr(r), F_, M, F_, K, L.ptr(b1), 1, None, 0, float(p), int(seed), None, 0, 0, st),
+        L.check(lib.ltrx_gemm_nt(L.ptr(x2), K, L.ptr(w1), K, None, L.ptr(r), F_, M, F_, K, L.ptr(b1), 1, None, 0, float(p), int(seed), None, 0, 0, st),
                 "gemm_nt(ffn w_1)")
-        L.check(lib.ltrx_gemm_nt(L.ptr(r), F_, L.ptr(w2), F_, L.ptr(y), N, M, N, F_, L.ptr(b2), 0, None, 0, 0.0, 0, None, 0, 0, st),
+        L.check(lib.ltrx_gemm_nt(L.ptr(r), F_, L.ptr(w2), F_, None, L.ptr(y), N, M, N, F_, L.ptr(b2), 0, None, 0, 0.0, 0, None, 0, 0, st),
                 "gemm_nt(ffn w_2)")
         ctx.save_for_backward(x2, w1, w2, r)
         ctx.p, ctx.xshape = float(p), x.shape
@@ -327,14 +327,14 @@ class _FFNFn(torch.autograd.Function):
         w2T = w2.t().contiguous()                                # [F, N]
         dr = torch.empty((M, F_), dtype=torch.float32, device=dev)
         # d r = (dy w_2) * [r > 0] / (1 - p): r is the post-ReLU, post-dropout activation, so its sign pattern IS the combined mask
-        L.check(lib.ltrx_gemm_nt(L.ptr(dy2), N, L.ptr(w2T), N, L.ptr(dr), F_, M, F_, N, None, 2, L.ptr(r), F_, ctx.p, 0, None, 0, 0, st),
+        L.check(lib.ltrx_gemm_nt(L.ptr(dy2), N, L.ptr(w2T), N, None, L.ptr(dr), F_, M, F_, N, None, 2, L.ptr(r), F_, ctx.p, 0, None, 0, 0, st),
                 "gemm_nt(ffn dgrad w_2)")
         dw1, db1 = wgrad(dr, x2, F_, K)
         dx = None
         if ctx.needs_input_grad[0]:
             w1T = w1.t().contiguous()                            # [K, F]
             dx = torch.empty((M, K), dtype=torch.float32, device=dev)
-            L.check(lib.ltrx_gemm_nt(L.ptr(dr), F_, L.ptr(w1T), F_, L.ptr(dx), K, M, K, F_, None, 0, None, 0, 0.0, 0, None, 0, 0, st),
+            L.check(lib.ltrx_gemm_nt(L.ptr(dr), F_, L.ptr(w1T), F_, None, L.ptr(dx), K, M, K, F_, None, 0, None, 0, 0.0, 0, None, 0, 0, st),
                     "gemm_nt(ffn dgrad w_1)")
             dx = dx.view(ctx.xshape)
         return dx, dw1, db1, dw2, db2, None, None

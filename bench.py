@@ -117,7 +117,7 @@ def time_kernels(w, B, L, device):
         b_ = torch.randn(Nn, device=device)
         C_ = torch.empty(Mrows, Nn, device=device)
         st = LB.stream_of(A_)
-        t_g = ev(lambda: LB.check(lib.ltrx_gemm_nt(LB.ptr(A_), Kk, LB.ptr(W_), Kk, LB.ptr(C_), Nn, Mrows, Nn, Kk, LB.ptr(b_), 1,
+        t_g = ev(lambda: LB.check(lib.ltrx_gemm_nt(LB.ptr(A_), Kk, LB.ptr(W_), Kk, None, LB.ptr(C_), Nn, Mrows, Nn, Kk, LB.ptr(b_), 1,
                                                    None, 0, 0.0, 0, None, 0, 0, st), "gemm_nt"))
         n_nt = 1 + 8 * w["N"] - 1          # fwd: fc + 4/layer; dgrad: 4/layer  (head GEMV is a separate kernel)
         _t256 = ((Mrows + 255) // 256) * (Nn // 256)
@@ -297,7 +297,7 @@ def gemm_error_vs_fp64(w, B, L, device, gemm):
     if gemm == "hipblaslt":
         torch.addmm(b_, A_, W_.t(), out=C_)
     else:
-        LB.check(lib.ltrx_gemm_nt(LB.ptr(A_), Kk, LB.ptr(W_), Kk, LB.ptr(C_), Nn, Mrows, Nn, Kk, LB.ptr(b_), 0, None, 0, 0.0, 0, None,
+        LB.check(lib.ltrx_gemm_nt(LB.ptr(A_), Kk, LB.ptr(W_), Kk, None, LB.ptr(C_), Nn, Mrows, Nn, Kk, LB.ptr(b_), 0, None, 0, 0.0, 0, None,
                                   {"split_bf16_strict": 1, "bf16": 2}.get(gemm, 0), 0, LB.stream_of(A_)), "gemm_nt")
     rows = torch.linspace(0, Mrows - 1, min(4096, Mrows), device=device).long()
     ref = A_[rows].double() @ W_.double().t() + b_.double()
@@ -324,6 +324,8 @@ def main():
     ap.add_argument("--gemm", default="split_bf16", choices=["split_bf16", "split_bf16_strict", "hipblaslt", "bf16"],
                     help="dense projections: libltrx fp32-accurate split-bf16 MFMA GEMMs (default), hipBLASLt fp32, or bf16 = the "
                          "one-product throughput mode (GEMMs and attention; outside the 1e-5 parity contract)")
+    ap.add_argument("--no-weight-images", action="store_true",
+                    help="A/B: split the weight operand of the GEMMs on the fly in every tile instead of once per optimizer step")
     ap.add_argument("--engine", default="fused", choices=["fused", "autograd"],
                     help="fused: explicit hipGraph-captured step (engine.FusedTrainer); autograd: nn.Module + torch autograd/Adam")
     args = ap.parse_args()
@@ -363,7 +365,7 @@ def main():
         args.ragged = True
     if args.engine == "fused":
         trainer = FusedTrainer(model, w["loss"], w.get("loss_args", {}), B, L, lr=1e-3, world_size=world, use_graph=True, gemm=args.gemm,
-                               compact=args.compact)   # Adam 1e-3: approxndcg.json:28-33
+                               compact=args.compact, weight_images=not args.no_weight_images)   # Adam 1e-3: approxndcg.json:28-33
     else:
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         _lf, _la = getattr(E, w["loss"]), w.get("loss_args", {})

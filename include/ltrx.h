@@ -289,9 +289,15 @@ int ltrx_score_head_bwd(const float* dscores, const float* x, const float* w, in
  *                 (act 0/1: counter-based mask over the [M,N] output; act 2: the mask is carried by aux, only 1/(1-p)).
  *   ltrx_gemm_tn: C[NP,KP] (dense) = A[M,NP]^T * B[M,KP]  -- weight gradient dW = dY^T X (split over M, deterministic);
  *                 bias_out[NP] (optional) = column sums of A = the bias gradient, produced in the same pass. */
-int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,
+int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, const void* B_image, float* C, int ldc, int M, int N, int K, const float* bias,
                  int act, const float* aux, int ldaux, float drop_p, uint32_t drop_seed, const uint32_t* drop_step, int strict,
                  int tile, ltrx_stream_t stream);
+/* B_image (optional, NULL = none): the operand B pre-split by ltrx_split_image -- every 4 consecutive floats of B replaced, at the
+ * same address offset, by the 16 bytes {hi0..hi3, lo0..lo3} of their bf16 hi / lo split.  The large-tile kernels then copy B into LDS
+ * instead of splitting it on the fly (identical bits, identical results, less VALU work); other kernels ignore it and read B.  What it
+ * is for: nn.Linear weights (model.py:35-44, transformer.py:193-227) change once per optimizer step but are staged by every tile of
+ * every GEMM of the step.  ltrx_split_image: n floats (multiple of 4), src and dst 16-byte aligned. */
+int ltrx_split_image(const float* src, void* dst, size_t n, ltrx_stream_t stream);
 /* `tile` (both GEMMs) is a per-call tuning argument: 0 = automatic choice per shape (what every product call passes);
  * ltrx_gemm_nt: 1 128x128x32, 2 128x128x64, 3 256x128x32, 4 256x128x64, 6 256x256x32, 7 128x256x32 (the large-tile forms
  * need N % 256 == 0, K % 32 == 0); ltrx_gemm_tn: 1 = the 128x128 kernel even where the 256x256 one applies.  Results do not

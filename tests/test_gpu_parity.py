@@ -529,10 +529,10 @@ def test_split_bf16_gemm_matches_fp64(strict):
         bias = rng.standard_normal(N).astype(np.float32)
         At, Bt, bt = _t(A), _t(Bw), _t(bias)
         C = torch.empty((Mm, N), device=DEV)
-        LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, LB.ptr(C), N, Mm, N, K, LB.ptr(bt), 1, None, 0, 0.0, 0, None, strict, 0, None), "gemm_nt")
+        LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, None, LB.ptr(C), N, Mm, N, K, LB.ptr(bt), 1, None, 0, 0.0, 0, None, strict, 0, None), "gemm_nt")
         aux = rng.standard_normal((Mm, N)).astype(np.float32)
         C2 = torch.empty((Mm, N), device=DEV)
-        LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, LB.ptr(C2), N, Mm, N, K, None, 2, LB.ptr(_t(aux)), N, 0.0, 0, None, strict, 0, None), "gemm_nt(mask)")
+        LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, None, LB.ptr(C2), N, Mm, N, K, None, 2, LB.ptr(_t(aux)), N, 0.0, 0, None, strict, 0, None), "gemm_nt(mask)")
         ref2 = (A.astype(np.float64) @ Bw.astype(np.float64).T) * (aux > 0)
         assert float(np.abs(C2.cpu().numpy() - ref2).max()) < 1e-4
         ref = np.maximum(A.astype(np.float64) @ Bw.astype(np.float64).T + bias, 0)
@@ -764,8 +764,8 @@ def test_dropout_sites_share_one_counter_based_mask():
     A, Bw, bias = _t(rng.standard_normal((Mm, K)).astype(np.float32)), _t(rng.standard_normal((N, K)).astype(np.float32)), _t(rng.standard_normal(N).astype(np.float32))
     step = torch.tensor([7], dtype=torch.int32, device=DEV)
     C0, C1, Mk = (torch.empty((Mm, N), device=DEV) for _ in range(3))
-    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, LB.ptr(C0), N, Mm, N, K, LB.ptr(bias), 1, None, 0, 0.0, 0, None, 0, 0, None), "nt")
-    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, LB.ptr(C1), N, Mm, N, K, LB.ptr(bias), 1, None, 0, p, seed, LB.ptr(step), 0, 0, None), "nt")
+    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, None, LB.ptr(C0), N, Mm, N, K, LB.ptr(bias), 1, None, 0, 0.0, 0, None, 0, 0, None), "nt")
+    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, None, LB.ptr(C1), N, Mm, N, K, LB.ptr(bias), 1, None, 0, p, seed, LB.ptr(step), 0, 0, None), "nt")
     ones = torch.ones((Mm, N), device=DEV)
     LB.check(lib.ltrx_dropout_apply(LB.ptr(ones), LB.ptr(Mk), ones.numel(), p, seed, LB.ptr(step), None), "apply")
     torch.cuda.synchronize()
@@ -776,9 +776,9 @@ def test_dropout_sites_share_one_counter_based_mask():
     assert torch.equal(C1, C0 * Mk)
     # act == 2 (ReLU+dropout backward): mask carried by aux, scale 1/(1-p)
     G2 = torch.empty((Mm, N), device=DEV)
-    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, LB.ptr(G2), N, Mm, N, K, None, 2, LB.ptr(C1), N, p, 0, None, 0, 0, None), "nt")
+    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, None, LB.ptr(G2), N, Mm, N, K, None, 2, LB.ptr(C1), N, p, 0, None, 0, 0, None), "nt")
     G0 = torch.empty((Mm, N), device=DEV)
-    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, LB.ptr(G0), N, Mm, N, K, None, 0, None, 0, 0.0, 0, None, 0, 0, None), "nt")
+    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, None, LB.ptr(G0), N, Mm, N, K, None, 0, None, 0, 0.0, 0, None, 0, 0, None), "nt")
     torch.cuda.synchronize()
     assert torch.equal(G2, torch.where(C1 > 0, G0 * np.float32(1 / (1 - p)), torch.zeros_like(G0)))
     # a different step word -> a different, equally dense mask; NULL step word == step word 0
@@ -1080,7 +1080,7 @@ def test_large_tile_gemm_matches_fp64_and_the_small_tile_kernel():
                 res = []
                 for (b_, act, ax, p) in ((bt, 1, None, 0.0), (None, 0, None, 0.0), (None, 2, auxt, 0.25), (bt, 1, None, 0.3), (bt, 0, None, 0.3)):
                     C = torch.empty((Mm, N), device=DEV)
-                    LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, LB.ptr(C), N, Mm, N, K, LB.ptr(b_), act, LB.ptr(ax),
+                    LB.check(lib.ltrx_gemm_nt(LB.ptr(At), K, LB.ptr(Bt), K, None, LB.ptr(C), N, Mm, N, K, LB.ptr(b_), act, LB.ptr(ax),
                                               N if ax is not None else 0, p, 77, LB.ptr(step), 0, variant, None), "gemm_nt")
                     res.append(C)
                 outs[variant] = res
@@ -1094,6 +1094,36 @@ def test_large_tile_gemm_matches_fp64_and_the_small_tile_kernel():
                 assert torch.equal(a == 0, b == 0)                  # identical ReLU / dropout masks
     finally:
         pass
+
+
+def test_gemm_nt_with_presplit_weight_image_is_bit_identical():
+    """ltrx_split_image + the B_image argument of ltrx_gemm_nt (the weights of the explicit step are split once per optimizer step
+    instead of in every tile): same bits as the fp32-operand call, every epilogue, both tile forms, ragged last row tile, one- and
+    three-product arithmetic; shapes that run the small-tile kernel ignore the image."""
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    rng = np.random.default_rng(31)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for (Mm, N, K) in [(6144, 4096, 64), (700, 512, 96), (24000, 1536, 64), (15360, 512, 64), (40000, 512, 64), (300, 256, 136), (64, 96, 20)]:
+        A = _t(rng.standard_normal((Mm, K)).astype(np.float32))
+        Bw = _t((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+        bias = _t(rng.standard_normal(N).astype(np.float32))
+        aux = _t(rng.standard_normal((Mm, N)).astype(np.float32))
+        img = torch.empty_like(Bw)
+        LB.check(lib.ltrx_split_image(LB.ptr(Bw), LB.ptr(img), Bw.numel(), None), "split_image")
+        # the image really is {hi0..3, lo0..3} per 4 floats
+        hl = img.view(torch.bfloat16).view(N, K // 4, 2, 4).float()
+        ref_hi = Bw.view(N, K // 4, 4).to(torch.bfloat16).float()
+        assert torch.equal(hl[:, :, 0], ref_hi) and torch.equal(hl[:, :, 1], (Bw.view(N, K // 4, 4) - ref_hi).to(torch.bfloat16).float())
+        for prec in (0, 2):
+            for (b_, act, ax, p) in ((bias, 1, None, 0.0), (None, 0, None, 0.0), (None, 2, aux, 0.25), (bias, 1, None, 0.3)):
+                outs = []
+                for image in (None, img):
+                    C = torch.empty((Mm, N), device=DEV)
+                    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, LB.ptr(image), LB.ptr(C), N, Mm, N, K, LB.ptr(b_), act, LB.ptr(ax),
+                                              N if ax is not None else 0, p, 77, LB.ptr(step), prec, 0, None), "gemm_nt")
+                    outs.append(C)
+                assert torch.equal(outs[0], outs[1]), (Mm, N, K, prec, act)
 
 
 def test_large_tile_wgrad_gemm_matches_fp64_and_the_small_tile_kernel():

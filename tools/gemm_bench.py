@@ -23,7 +23,7 @@ for (m, n, k) in shapes:
     fl = 2.0 * m * n * k
     row = dict(shape=(m, n, k))
     for v in (1, 2, 3, 5):
-        us = ev(lambda: LB.check(lib.ltrx_gemm_nt(LB.ptr(A), k, LB.ptr(B), k, LB.ptr(C), n, m, n, k, LB.ptr(bias), 0, None, 0, 0.0, 0, None, 0, v, None), "nt"))
+        us = ev(lambda: LB.check(lib.ltrx_gemm_nt(LB.ptr(A), k, LB.ptr(B), k, None, LB.ptr(C), n, m, n, k, LB.ptr(bias), 0, None, 0, 0.0, 0, None, 0, v, None), "nt"))
         row["nt_v%d" % v] = "%.1fus %.0fTF" % (us, fl / us / 1e6)
     us = ev(lambda: torch.addmm(bias, A, B.t(), out=C))
     row["hipblaslt_fp32"] = "%.1fus %.0fTF" % (us, fl / us / 1e6)

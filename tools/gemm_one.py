@@ -10,7 +10,7 @@ if os.environ.get("GZERO"):           # DVFS probe: all-zero operands draw less 
 GV = int(os.environ.get("GV", "0"))          # tile argument of the calls (0 = auto)
 PREC = int(os.environ.get("GPREC", "0"))       # 0 three products, 1 strict, 2 plain bf16
 for _ in range(5):
-    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), k, LB.ptr(B), k, LB.ptr(C), n, m, n, k, LB.ptr(bias), 0, None, 0, 0.0, 0, None, PREC, GV, None), "nt")
+    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), k, LB.ptr(B), k, None, LB.ptr(C), n, m, n, k, LB.ptr(bias), 0, None, 0, 0.0, 0, None, PREC, GV, None), "nt")
 if os.environ.get("GONLY") == "nt":
     torch.cuda.synchronize()
     sys.exit(0)

@@ -12,7 +12,7 @@ VARS = [int(v) for v in os.environ.get("GVARS", "6,8,9").split(",")]
 
 def run(v, A, W, C, bias, act, aux):
     n, k = W.shape
-    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), k, LB.ptr(W), k, LB.ptr(C), n, A.shape[0], n, k, LB.ptr(bias), act, LB.ptr(aux), n if aux is not None else 0,
+    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), k, LB.ptr(W), k, None, LB.ptr(C), n, A.shape[0], n, k, LB.ptr(bias), act, LB.ptr(aux), n if aux is not None else 0,
                               0.0, 0, None, 0, v, None), "nt v%d" % v)
 
 

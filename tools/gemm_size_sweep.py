@@ -25,7 +25,7 @@ for (N, K) in ((2048, 512), (1536, 512), (512, 2048), (512, 512)):
     for M in Ms:
         A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
         C = torch.empty(M, N, device="cuda")
-        t = ev(lambda: LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(W), K, LB.ptr(C), N, M, N, K, LB.ptr(b), 0, None, 0, 0.0, 0, None, 0, 0, None), "nt"))
+        t = ev(lambda: LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(W), K, None, LB.ptr(C), N, M, N, K, LB.ptr(b), 0, None, 0, 0.0, 0, None, 0, 0, None), "nt"))
         row.append("%d:%.0f(%.0fTF)" % (M // 1024, t, 2.0 * M * N * K / t / 1e6))
         del A, W, C
     print("NT N%d K%d  " % (N, K) + "  ".join(row))

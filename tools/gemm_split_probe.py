@@ -10,7 +10,7 @@ N = 512
 
 def call(A, W, C, b, m0, m1):
     K = A.shape[1]
-    LB.check(lib.ltrx_gemm_nt(A.data_ptr() + 4 * K * m0, K, LB.ptr(W), K, C.data_ptr() + 4 * N * m0, N, m1 - m0, N, K, LB.ptr(b), 0, None, 0,
+    LB.check(lib.ltrx_gemm_nt(A.data_ptr() + 4 * K * m0, K, LB.ptr(W), K, None, C.data_ptr() + 4 * N * m0, N, m1 - m0, N, K, LB.ptr(b), 0, None, 0,
                               0.0, 0, None, 0, 0, None), "nt")
 
 
