@@ -19,9 +19,12 @@ __global__ void ltrx_bump_step_kernel(float* __restrict__ step) { step[0] += 1.0
 
 __global__ void __launch_bounds__(256) ltrx_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, size_t n,
-                                                        float lr, float b1, float b2, float eps,
+                                                        float lr, float b1, float b2, float eps, float wd, int decoupled,
                                                         const float* __restrict__ step, float grad_scale,
                                                         const float* __restrict__ grad_scale_dev) {
+  // wd: torch.optim.Adam(weight_decay=wd) adds wd * p to the gradient; decoupled != 0: torch.optim.AdamW multiplies p by
+  // (1 - lr * wd) before the update instead
+  const float l2 = decoupled ? 0.f : wd, shrink = decoupled ? 1.0f - lr * wd : 1.0f;
   if (grad_scale_dev) grad_scale *= grad_scale_dev[0];
   const float t = step[0];
   const float bc1 = 1.0f - powf(b1, t);
@@ -36,10 +39,10 @@ __global__ void __launch_bounds__(256) ltrx_adam_kernel(float* __restrict__ p, c
     float4 vv = reinterpret_cast<float4*>(v)[i];
 #define LTRX_ADAM1(c)                                                   \
   {                                                                     \
-    const float gr = gg.c * grad_scale;                                 \
+    const float gr = gg.c * grad_scale + l2 * pp.c;                     \
     mm.c = b1 * mm.c + (1.0f - b1) * gr;                                \
     vv.c = b2 * vv.c + (1.0f - b2) * gr * gr;                           \
-    pp.c -= step_size * (mm.c / (sqrtf(vv.c) / bc2s + eps));            \
+    pp.c = pp.c * shrink - step_size * (mm.c / (sqrtf(vv.c) / bc2s + eps)); \
   }
     LTRX_ADAM1(x) LTRX_ADAM1(y) LTRX_ADAM1(z) LTRX_ADAM1(w)
     reinterpret_cast<float4*>(p)[i] = pp;
@@ -48,19 +51,47 @@ __global__ void __launch_bounds__(256) ltrx_adam_kernel(float* __restrict__ p, c
   }
   // tail (n % 4 elements)
   for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float gr = g[i] * grad_scale;
+    const float gr = g[i] * grad_scale + l2 * p[i];
     const float mi = b1 * m[i] + (1.0f - b1) * gr;
     const float vi = b2 * v[i] + (1.0f - b2) * gr * gr;
     m[i] = mi;
     v[i] = vi;
-    p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    p[i] = p[i] * shrink - step_size * (mi / (sqrtf(vi) / bc2s + eps));
   }
 #undef LTRX_ADAM1
 }
 
+// torch.optim.SGD (dampening 0): g' = g (+ wd p); buf = momentum buf + g'; p -= lr (nesterov ? g' + momentum buf : buf)
+__global__ void __launch_bounds__(256) ltrx_sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                       size_t n, float lr, float momentum, int nesterov, float wd, float grad_scale,
+                                                       const float* __restrict__ grad_scale_dev) {
+  if (grad_scale_dev) grad_scale *= grad_scale_dev[0];
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float gr = g[i] * grad_scale + wd * p[i];
+    if (momentum != 0.f) {
+      const float b = momentum * buf[i] + gr;
+      buf[i] = b;
+      gr = nesterov ? gr + momentum * b : b;
+    }
+    p[i] -= lr * gr;
+  }
+}
+
+extern "C" int ltrx_sgd_step(float* params, const float* grads, float* momentum_buf, size_t n, float lr, float momentum,
+                             int nesterov, float weight_decay, float grad_scale, const float* grad_scale_dev, ltrx_stream_t stream) {
+  if (!params || !grads || n == 0 || (momentum != 0.f && !momentum_buf) || (nesterov && !(momentum > 0.f))) return LTRX_EINVAL;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ltrx_sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf, n, lr,
+                     momentum, nesterov, weight_decay, grad_scale, grad_scale_dev);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
 extern "C" int ltrx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
-                              float beta1, float beta2, float eps, float* step_count, float grad_scale,
-                              const float* grad_scale_dev, ltrx_stream_t stream) {
+                              float beta1, float beta2, float eps, float weight_decay, int decoupled, float* step_count,
+                              float grad_scale, const float* grad_scale_dev, ltrx_stream_t stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !step_count || n == 0) return LTRX_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(ltrx_bump_step_kernel, dim3(1), dim3(1), 0, s, step_count);
@@ -69,7 +100,7 @@ extern "C" int ltrx_adam_step(float* params, const float* grads, float* exp_avg,
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(ltrx_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n, lr,
-                     beta1, beta2, eps, step_count, grad_scale, grad_scale_dev);
+                     beta1, beta2, eps, weight_decay, decoupled, step_count, grad_scale, grad_scale_dev);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }

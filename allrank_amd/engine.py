@@ -82,6 +82,7 @@ class FusedTrainer(object):
     """
 
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
+                 optimizer="Adam", weight_decay=0.0, momentum=0.0, nesterov=False,
                  use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None, compact=False,
                  weight_images=True):
         """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
@@ -96,6 +97,8 @@ class FusedTrainer(object):
         cu_seqlens, and scores / d loss/d scores move between the packed rows and the padded [B, L] grid the loss kernels
         work on.  Same loss and gradients as the padded step (padded rows carry no gradient and are masked as keys); the
         row count changes per batch, so this mode runs eagerly (no hipGraph).
+        optimizer: "Adam" (betas, eps, weight_decay = L2 term), "AdamW" (decoupled weight decay) or "SGD" (momentum, nesterov,
+        weight_decay; dampening 0) -- torch.optim's update rules (main.py:82) in one flat-buffer kernel.
         weight_images=False: the GEMMs split the weight operand on the fly in every tile instead of reading the per-step pre-split
         images (same results bit for bit; kept for A/B measurements)."""
         import torch.nn as nn
@@ -116,6 +119,10 @@ class FusedTrainer(object):
         self.model = model
         self.B, self.L, self.M = B, L, B * L
         self.lr, self.betas, self.eps = lr, betas, eps
+        if optimizer not in ("Adam", "AdamW", "SGD"):
+            raise NotImplementedError("FusedTrainer: optimizer %r (Adam, AdamW and SGD are fused)" % (optimizer,))
+        self.optimizer, self.weight_decay = optimizer, float(weight_decay)
+        self.momentum, self.nesterov = float(momentum), bool(nesterov)
         self.world, self.group = world_size, group
         if not isinstance(model, LTRModel) or not isinstance(model.input_layer, FCModel):
             raise NotImplementedError("FusedTrainer needs an allrank_amd LTRModel with an FCModel input block")
@@ -696,9 +703,16 @@ class FusedTrainer(object):
         if self.clip:
             self.LB.check(self.lib.ltrx_clip_grad_norm_scale(P(self.flat_g), self.nflat, self.clip, P(self.clip_scale),
                                                              P(self.grad_norm), P(self.ws_clip), self._st()), "clip_grad_norm")
+        gsc = P(self.clip_scale) if self.clip else None
+        if self.optimizer == "SGD":
+            self.LB.check(self.lib.ltrx_sgd_step(P(self.flat_p), P(self.flat_g), P(self.flat_m) if self.momentum else None, self.nflat,
+                                                 float(self.lr), self.momentum, 1 if self.nesterov else 0, self.weight_decay, 1.0, gsc,
+                                                 self._st()), "sgd_step")
+            return
         self.LB.check(self.lib.ltrx_adam_step(P(self.flat_p), P(self.flat_g), P(self.flat_m), P(self.flat_v), self.nflat,
                                               float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                              P(self.step_count), 1.0, P(self.clip_scale) if self.clip else None, self._st()),
+                                              self.weight_decay, 1 if self.optimizer == "AdamW" else 0,
+                                              P(self.step_count), 1.0, gsc, self._st()),
                       "adam_step")
 
     def _full(self):

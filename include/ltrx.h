@@ -224,12 +224,18 @@ int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* 
  * GEMMs that the explicit, graph-capturable step of allrank_amd/engine.py needs.
  * ------------------------------------------------------------------------------------------- */
 
-/* torch.optim.Adam.step (allrank/main.py:82, Adam in every shipped config) over one flat fp32 buffer of n elements;
- * step_count[1] (device, float) is incremented first and used for the bias corrections; grads are multiplied by
- * grad_scale (1.0 normally) and, when given, by grad_scale_dev[0] (device; the clipping coefficient) on the fly. */
+/* The optimizers `getattr(torch.optim, config.optimizer.name)` (allrank/main.py:82) resolves to in practice, over one flat fp32
+ * buffer of n elements.  ltrx_adam_step = torch.optim.Adam.step (Adam in every shipped config; weight_decay = the L2 term added to
+ * the gradient) or, with decoupled != 0, torch.optim.AdamW.step (p *= 1 - lr * weight_decay first): step_count[1] (device, float) is
+ * incremented first and used for the bias corrections.  ltrx_sgd_step = torch.optim.SGD.step with dampening 0 (momentum_buf may be
+ * NULL when momentum == 0).  Gradients are multiplied by grad_scale (1.0 normally) and, when given, by grad_scale_dev[0] (device; the
+ * clipping coefficient) on the fly.  (amsgrad / maximize / foreach variants: not implemented -- the Python layer keeps those jobs
+ * on torch's optimizer.) */
 int ltrx_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
-                   float beta2, float eps, float* step_count, float grad_scale, const float* grad_scale_dev,
-                   ltrx_stream_t stream);
+                   float beta2, float eps, float weight_decay, int decoupled, float* step_count, float grad_scale,
+                   const float* grad_scale_dev, ltrx_stream_t stream);
+int ltrx_sgd_step(float* params, const float* grads, float* momentum_buf, size_t n, float lr, float momentum, int nesterov,
+                  float weight_decay, float grad_scale, const float* grad_scale_dev, ltrx_stream_t stream);
 
 /* torch.nn.utils.clip_grad_norm_ (allrank/training/train_utils.py:24-25) over the flat gradient buffer:
  * scale_out[0] = min(1, max_norm / (||grads||_2 + 1e-6)), norm_out[0] (optional) = the norm; deterministic two-stage sum. */

@@ -128,14 +128,45 @@ def test_fused_step_short_last_batch_is_normalised_by_its_real_slate_count():
         assert ft.graph is not None          # the full batches did get their graph
 
 
+@pytest.mark.parametrize("name,kw", [("Adam", dict(lr=2e-3, betas=(0.8, 0.95), eps=1e-6, weight_decay=0.01)),
+                                     ("AdamW", dict(lr=2e-3, weight_decay=0.05)),
+                                     ("SGD", dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-3)),
+                                     ("SGD", dict(lr=0.05))])
+def test_fused_optimizers_equal_torch_optim(name, kw):
+    """`getattr(torch.optim, config.optimizer.name)(**args)` (main.py:82): Adam with non-default betas / eps / L2 weight decay, AdamW and
+    SGD (momentum, Nesterov, weight decay) run on the explicit step -- the flat-buffer update kernels against torch's own optimizer
+    driven by the same gradients, five steps; and fit() picks the fused engine for them."""
+    import copy
+    from functools import partial
+    from allrank_amd import losses as E, fit as EF
+    from allrank_amd.engine import FusedTrainer
+    L, F, bs = 30, 20, 16
+    x, y, _ = (t.to(DEV) for t in _data(16, L, F, 9))
+    m_f = _model(F)
+    m_t = copy.deepcopy(m_f)
+    opt_t = getattr(torch.optim, name)(m_t.parameters(), **kw)
+    spec, reason = EF._fused_spec(m_f, partial(E.listNet), getattr(torch.optim, name)(m_f.parameters(), **kw))
+    assert spec is not None and reason == "", reason
+    ft = FusedTrainer(m_f, spec[0], spec[1], bs, L, lr=spec[2], use_graph=True, **spec[3])
+    for step in range(5):
+        ft.step(x, y, None)
+        # torch's optimizer on the torch copy, fed the ENGINE's gradients of this step (the update rule is what is under test)
+        for pt, pf in zip(m_t.parameters(), m_f.parameters()):
+            pt.grad = pf.grad.detach().clone()
+        opt_t.step()
+        for (n, pt), (_, pf) in zip(m_t.named_parameters(), m_f.named_parameters()):
+            assert float((pt - pf).abs().max()) <= 2e-6 * max(1.0, float(pt.abs().max())), (name, step, n)
+        m_t.load_state_dict(m_f.state_dict())             # (keep the two weight sets bit-identical: only the optimizer state runs free)
+
+
 def test_fit_falls_back_to_the_autograd_trainer(tmp_path):
     from allrank_amd import losses as E, fit as EF
     cfg = types.SimpleNamespace(metrics={"ndcg": [5]}, val_metric="ndcg_5")
     train_dl, val_dl = _loaders()
     model = _model(20)
-    opt = torch.optim.SGD(model.parameters(), lr=0.01)
+    opt = torch.optim.RMSprop(model.parameters(), lr=0.001)              # (Adam / AdamW / SGD are fused; anything else keeps torch's optimizer)
     res = EF.fit(2, model, partial(E.listNet), opt, None, train_dl, val_dl, cfg, None, 5, torch.device(DEV), str(tmp_path), None)
-    assert EF.last_run["engine"] == "autograd" and "Adam" in EF.last_run["reason"] and res["epochs"] == 1
+    assert EF.last_run["engine"] == "autograd" and "RMSprop" in EF.last_run["reason"] and res["epochs"] == 1
 
 
 def test_evaluate_equals_compute_metrics_of_the_oracle():

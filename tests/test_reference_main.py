@@ -89,7 +89,8 @@ def test_unmodified_main_reaches_the_explicit_step_with_a_fusable_job(tmp_path, 
         allrank_amd.uninstall()
     assert "allrank.training.train_utils.fit" in done
     assert isinstance(seen["model"], LTRModel) and seen["reason"] == ""
-    assert seen["spec"] == ("listNet", {}, 0.001)         # what FusedTrainer(model, loss_name, loss_args, ..., lr) is built from
+    # what FusedTrainer(model, loss_name, loss_args, ..., lr=, **optimizer kwargs) is built from
+    assert seen["spec"] == ("listNet", {}, 0.001, dict(optimizer="Adam", betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0))
     assert seen["epochs"] == 3 and seen["n_batches"] == 4 and seen["ext"] == {}
     assert seen["xb"] == (32, 24, 20) and seen["yb"] == (32, 24) and seen["idx"] == (32, 24) and seen["idx_dtype"] == torch.int64
     assert seen["batch_shape"] == (32, 24)                # the shapes the static step is built for, without consuming a batch
