@@ -282,6 +282,8 @@ static int ln_grid(int rows) {
   return g > 1024 ? 1024 : (g < 1 ? 1 : g);
 }
 // the backward keeps per-block column partials: fewer, fatter blocks (each wave walks many rows)
+// (320: measured again in round 3 -- 1024 workgroups run the kernel itself 20 % faster standalone (120 -> 96 us) but triple the partial
+//  rows the reduce kernel sums (8 -> 22 us), and the training step does not move: 9.31 vs 9.31 ms; profiles/NOTES.md)
 static int ln_bwd_grid(int rows) {
   int g = (rows + 15) / 16;
   return g > 320 ? 320 : (g < 1 ? 1 : g);

@@ -75,7 +75,8 @@ class FusedTrainer(object):
       (site seed ^ per-step device word, element index), generated inside the producing kernel's epilogue (GEMM bias+
       ReLU+dropout, the residual add of the LayerNorm kernel, the attention probabilities) and REGENERATED in the backward
       -- no mask tensors, and a replayed hipGraph draws fresh masks because the step word lives in device memory.
-    Supported model family: FCModel (optional input_norm = nn.LayerNorm, activation None/ReLU) -> optional encoder with
+    Supported model family: FCModel (optional input_norm = nn.LayerNorm, activation None / ReLU, or Sigmoid / Tanh without FC
+    dropout) -> optional encoder with
     optional fixed / learned positional encoding (positional.py:15-77) -> OutputLayer(any d_output, activation None / Sigmoid /
     Tanh; d_output > 1 feeds the ``ordinal`` loss, ``scores`` is then the sum over the output units, model.py:119-128).
     Other FC / output activations raise NotImplementedError (use ``Trainer``).
@@ -136,8 +137,12 @@ class FusedTrainer(object):
             self.fc_act = 0
         elif isinstance(fc.activation, nn.ReLU):
             self.fc_act = 1
+        elif isinstance(fc.activation, (nn.Sigmoid, nn.Tanh)) and self.p_fc == 0.0:
+            # (model.py:28-29 resolves any torch.nn name; Sigmoid / Tanh run as an elementwise pass after the GEMM whose derivative is
+            #  taken from the stored output -- with dropout after them the stored output no longer determines it: autograd Trainer)
+            self.fc_act = 3 if isinstance(fc.activation, nn.Sigmoid) else 4
         else:
-            raise NotImplementedError("FusedTrainer: FC activation %r" % (fc.activation,))
+            raise NotImplementedError("FusedTrainer: FC activation %r%s" % (fc.activation, " with dropout" if self.p_fc else ""))
         enc = model.encoder if isinstance(model.encoder, Encoder) else None
         self.pos = enc.position if (enc is not None and enc.position is not None) else None
         self.pos_learned = isinstance(self.pos, LearnedPositionalEncoding)
@@ -538,7 +543,12 @@ class FusedTrainer(object):
                                                        self._st()), "layernorm_torch_fwd")
             h = self.x_norm
         for i, lyr in enumerate(fc.layers):
-            self._lin_fwd(h, W(lyr.weight), W(lyr.bias), self.fc_out[i], self.fc_act, dp(self.p_fc), self._site(1000 + i))
+            if self.fc_act >= 3:                                   # Sigmoid / Tanh: GEMM + bias, then the activation in place
+                self._lin_fwd(h, W(lyr.weight), W(lyr.bias), self.fc_out[i])
+                self.LB.check(lib.ltrx_out_act_fwd(P(self.fc_out[i]), M * self.fc_out[i].shape[1], self.fc_act - 2, P(self.fc_out[i]),
+                                                   self._st()), "fc_act_fwd")
+            else:
+                self._lin_fwd(h, W(lyr.weight), W(lyr.bias), self.fc_out[i], self.fc_act, dp(self.p_fc), self._site(1000 + i))
             h = self.fc_out[i]
         if self.pos is not None:                                  # transformer.py:51-52: x = sqrt(d) x + pe[rank]
             self.LB.check(lib.ltrx_posenc_fwd(P(h), P(self._pos_table()), P(self.idx_rows), P(kpm), M, d, self.pos_pad, float(d) ** 0.5,
@@ -673,7 +683,10 @@ class FusedTrainer(object):
         for i in range(self.nfc - 1, -1, -1):
             lyr = fc.layers[i]
             if i == self.nfc - 1:                                # the last FC activation(+dropout) feeds the encoder / head
-                if self.fc_act == 1:
+                if self.fc_act >= 3:
+                    self.LB.check(lib.ltrx_out_act_bwd(P(ds), P(self.fc_out[i]), M * ds.shape[1], self.fc_act - 2, P(ds), self._st()),
+                                  "fc_act_bwd")
+                elif self.fc_act == 1:
                     self._relu_bwd(ds, self.fc_out[i], self.p_fc)
                 elif self.p_fc:
                     self._drop_apply(ds, ds, self.p_fc, self._site(1000 + i))
@@ -692,6 +705,9 @@ class FusedTrainer(object):
                                 relu_of=self.fc_out[i - 1] if self.fc_act == 1 else None, p=self.p_fc,
                                 seed=self._site(1000 + i - 1))
                 ds = self.fc_dgrad[i - 1]
+                if self.fc_act >= 3:
+                    self.LB.check(lib.ltrx_out_act_bwd(P(ds), P(self.fc_out[i - 1]), M * ds.shape[1], self.fc_act - 2, P(ds), self._st()),
+                                  "fc_act_bwd")
         self._bucket_done(len(self._buckets) - 1)
         return loss
 

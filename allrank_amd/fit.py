@@ -90,6 +90,73 @@ def _fused_spec(model, loss_func, optimizer):
     return (loss_func.func.__name__, dict(loss_func.keywords or {}), float(g["lr"]), opt), ""
 
 
+def _pad_batch(xb, yb, idx, B):
+    n = B - xb.shape[0]
+    if n <= 0:
+        return xb, yb, idx
+    return (torch.cat([xb, xb.new_zeros((n,) + tuple(xb.shape[1:]))]),
+            torch.cat([yb, yb.new_full((n, yb.shape[1]), float(PADDED_Y_VALUE))]),
+            torch.cat([idx, idx.new_full((n, idx.shape[1]), -1)]))
+
+
+class _Prefetcher(object):
+    """Host batches -> device batches with one batch of look-ahead.  The reference copies every batch on the compute stream in
+    front of the step (``xb.to(device)``, train_utils.py:95).  Here batch t+1 is copied on a SEPARATE stream into one of two
+    persistent device sets while the GPU runs step t (as soon as the step that last read that set has finished), and the compute
+    stream waits for the copy's event before step t+1.  Measured at config 3 (tools/fit_h2d_timing.py, 34 MB per batch): batch
+    resident in HBM 9.9 ms per step, ``.to(device)`` per step 10.8 ms, this class 10.65-10.7 ms -- the host-to-device copy executes as
+    a blit kernel that shares the CUs with the step, so most of its 0.8 ms stays; an extra hop through pinned staging buffers
+    costs 5+ ms of host time per batch on this platform (15-17 ms per step) and is not used.  Keeping the training set in HBM
+    (allrank_amd.data.DeviceSlates) is what removes the copy.  Batches that are already on the device pass through."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.stage = [None, None]          # per set: (device tensors, event "copy done")
+        self.free = [None, None]           # per set: event on the compute stream "the step that read this device set has finished"
+        self.turn = 0
+
+    def _send(self, batch):
+        if all((not torch.is_tensor(t)) or t.is_cuda for t in batch):
+            return batch, None, None
+        k = self.turn & 1
+        self.turn += 1
+        slot = self.stage[k]
+        if slot is None or any(d.shape[1:] != t.shape[1:] or d.shape[0] < t.shape[0] or d.dtype != t.dtype for d, t in zip(slot[0], batch)):
+            torch.cuda.current_stream(self.device).synchronize()      # (re)allocation: nothing of the old set may still be in use
+            slot = self.stage[k] = ([torch.empty(t.shape, dtype=t.dtype, device=self.device) for t in batch], torch.cuda.Event())
+            self.free[k] = None
+        dev, ev = slot
+        n = batch[0].shape[0]
+        if self.free[k] is not None:
+            self.stream.wait_event(self.free[k])
+        with torch.cuda.stream(self.stream):
+            for t, d in zip(batch, dev):
+                d[:n].copy_(t, non_blocking=True)
+            ev.record(self.stream)
+        return [d[:n] for d in dev], ev, k
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._send(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur, ev, k = nxt
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+            yield cur
+            if k is not None:                             # the consumer has enqueued its work on the compute stream
+                e = torch.cuda.Event()
+                e.record(torch.cuda.current_stream(self.device))
+                self.free[k] = e
+            try:
+                nxt = self._send(next(it))
+            except StopIteration:
+                nxt = None
+
+
 def make_result(epoch, train_metrics, val_metrics, num_params):
     """the dict main.py:90 receives, with the VALUE TYPES the reference's fit returns: main.py:104 hands it to
     dump_experiment_result (utils/experiments.py:20-24), which calls ``.item()`` on every metric and on num_params -- numpy scalars in

@@ -155,7 +155,7 @@ def test_fused_optimizers_equal_torch_optim(name, kw):
             pt.grad = pf.grad.detach().clone()
         opt_t.step()
         for (n, pt), (_, pf) in zip(m_t.named_parameters(), m_f.named_parameters()):
-            assert float((pt - pf).abs().max()) <= 2e-6 * max(1.0, float(pt.abs().max())), (name, step, n)
+            assert float((pt - pf).detach().abs().max()) <= 2e-6 * max(1.0, float(pt.detach().abs().max())), (name, step, n)
         m_t.load_state_dict(m_f.state_dict())             # (keep the two weight sets bit-identical: only the optimizer state runs free)
 
 

@@ -515,6 +515,33 @@ def test_fused_trainer_fc_only_relu():
         assert abs(lf - lo) <= (1e-5 if step == 0 else 1e-3) * (1 + abs(lo)), (step, lf, lo)
 
 
+@pytest.mark.parametrize("act", ["Tanh", "Sigmoid"])
+def test_fused_trainer_fc_sigmoid_tanh(act):
+    """FCModel activations other than ReLU (model.py:28-29 resolves any torch.nn name) on the explicit step: a two-layer FC stack with
+    Tanh / Sigmoid in front of a one-layer encoder -- loss, scores and every parameter gradient against the oracle"""
+    from allrank_amd.engine import FusedTrainer
+    cfg = dict(n_features=20, fc_sizes=[24, 16], fc_activation=act, fc_input_norm=False, N=1, d_ff=32, h=2, output_activation=None)
+    params = M.init_params(cfg, seed=13)
+    m1 = _make_engine_model(cfg, params)
+    rng = np.random.default_rng(14)
+    B, L = 8, 24
+    x = rng.standard_normal((B, L, 20)).astype(np.float32)
+    y = rng.integers(0, 5, (B, L)).astype(np.float32)
+    y[2, 15:] = -1
+    x[2, 15:] = 0
+    mask = y == -1
+    ft = FusedTrainer(m1, "listNet", {}, B, L, lr=1e-3, use_graph=False, gemm="split_bf16")
+    so, cache = M.forward(params, cfg, x, mask)
+    lo, gs, _ = O.listnet(so, y)
+    grads = M.backward(params, cfg, cache, gs)
+    lf = float(ft.step(_t(x), _t(y)).item())
+    assert abs(lf - float(lo)) <= 1e-5 * (1 + abs(float(lo))), (lf, lo)
+    assert float(np.abs(ft.scores.cpu().numpy() - so)[~mask].max()) < 2e-5 * max(1.0, float(np.abs(so).max()))
+    scale = max(float(np.abs(v).max()) for v in grads.values())
+    for n, p_ in m1.named_parameters():
+        assert float(np.abs(p_.grad.cpu().numpy() - grads[n]).max()) <= 2e-4 * scale, (act, n)
+
+
 @pytest.mark.parametrize("strict", [0, 1])
 def test_split_bf16_gemm_matches_fp64(strict):
     """fp32-accurate GEMMs on the bf16 MFMA: error relative to sum_k |a||b| must be fp32-class
