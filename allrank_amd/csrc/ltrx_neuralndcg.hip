@@ -468,6 +468,22 @@ __device__ __forceinline__ float part_rows_max(const float (*part)[W], int idx) 
   return a;
 }
 
+#ifdef LTRX_NEURAL_STAMP     // lab builds only (tools/lab/lib_variant.sh): cycle stamps of one workgroup of the forward kernel
+__device__ unsigned long long g_neural_stamps[12][8][8];
+#define NSTAMP(it, ph)                                                                 \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    if (blockIdx.x == LTRX_NEURAL_STAMP && (threadIdx.x & 63) == 0 && (it) >= 20 && (it) < 28)    \
+      g_neural_stamps[threadIdx.x >> 6][(it) - 20][ph] = __builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+extern "C" int ltrx_debug_neural_stamps(unsigned long long* host_dst) {
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_neural_stamps), sizeof(unsigned long long) * 12 * 8 * 8) == hipSuccess ? 0 : 1;
+}
+#else
+#define NSTAMP(it, ph)
+#endif
+
 template <int LRN, int TBR, int TBC, int NWC>
 __global__ void __launch_bounds__(256 * NWC) ltrx_neural_forward_blk_kernel(const float* __restrict__ y_pred,
                                                                        const float* __restrict__ y_true, int L, float pad,
@@ -479,6 +495,7 @@ __global__ void __launch_bounds__(256 * NWC) ltrx_neural_forward_blk_kernel(cons
   __shared__ int redi[LTRX_MAX_WAVES];
   __shared__ __attribute__((aligned(16))) float part_r[NWC][W];    // row partials: one per wave column
   __shared__ __attribute__((aligned(16))) float part_c[4][W];      // column partials: one per wave row (also the softmax sums)
+  __shared__ float dump[256 * NWC];                                // where the lanes that do not publish a partial sum write
   const SlateLds t = carve_lds(lds, L);
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n = load_slate(t, y_pred + (size_t)b * L, y_true + (size_t)b * L, L, pad, 0, 0, redi);
@@ -487,6 +504,12 @@ __global__ void __launch_bounds__(256 * NWC) ltrx_neural_forward_blk_kernel(cons
   float* cn = cnws + (size_t)b * (max_iter + 1) * L;
   float* rn = rnws + (size_t)b * max_iter * L;
   const G g;
+  // partial sums are published by the lanes lc == 0 (rows) / lr == 0 (columns); the others store to `dump`: a store whose ADDRESS
+  // is selected keeps the loop free of exec-mask changes, so the 15 (5) independent reduction chains of a phase interleave
+  // (cycle stamps, profiles/NOTES.md round 3: the row phase of the youngest wave of a SIMD 3100 -> see there)
+  float* const rdst = (g.lc == 0) ? &part_r[g.wc][g.r0] : &dump[tid];
+  float* const cdst = (g.lr == 0) ? &part_c[g.wr][g.c0] : &dump[tid];
+  const int rstep = (g.lc == 0) ? 1 : 0, cstep = (g.lr == 0) ? 1 : 0;
   float m[TBR][TBC];
   // ---- P0 = row softmax of (scaling_i s_j - Bsum_j) / tau, two passes over the same expression (clamped table indices +
   //      selects: no branches around the reads) ----
@@ -533,15 +556,17 @@ __global__ void __launch_bounds__(256 * NWC) ltrx_neural_forward_blk_kernel(cons
   }
   // ---- Sinkhorn ----
   for (int it = 0; it <= max_iter; ++it) {
+    NSTAMP(it, 0);
 #pragma unroll
     for (int j = 0; j < TBC; ++j) {
       float a = m[0][j];
 #pragma unroll
       for (int i = 1; i < TBR; ++i) a += m[i][j];
-      a = sum_lr<LCN>(a);
-      if (g.lr == 0) part_c[g.wr][g.c0 + j] = a;
+      cdst[j * cstep] = sum_lr<LCN>(a);
     }
+    NSTAMP(it, 1);
     __syncthreads();
+    NSTAMP(it, 2);
     if (tid < n) cn[(size_t)it * L + tid] = LTRX_PART4(part_c, tid);      // BEFORE the clamp: normaliser trace + residual trace
     if (it == max_iter) break;
 #pragma unroll
@@ -550,15 +575,17 @@ __global__ void __launch_bounds__(256 * NWC) ltrx_neural_forward_blk_kernel(cons
 #pragma unroll
       for (int i = 0; i < TBR; ++i) m[i][j] *= rc;
     }
+    NSTAMP(it, 3);
 #pragma unroll
     for (int i = 0; i < TBR; ++i) {
       float a = m[i][0];
 #pragma unroll
       for (int j = 1; j < TBC; ++j) a += m[i][j];
-      a = sum_lc<LCN>(a);
-      if (g.lc == 0) part_r[g.wc][g.r0 + i] = a;
+      rdst[i * rstep] = sum_lc<LCN>(a);
     }
+    NSTAMP(it, 4);
     __syncthreads();
+    NSTAMP(it, 5);
     if (tid >= 256 && tid - 256 < n) rn[(size_t)it * L + tid - 256] = fmaxf(part_rows<NWC, W>(part_r, tid - 256), kSinkEps);
 #pragma unroll
     for (int i = 0; i < TBR; ++i) {
@@ -566,6 +593,7 @@ __global__ void __launch_bounds__(256 * NWC) ltrx_neural_forward_blk_kernel(cons
 #pragma unroll
       for (int j = 0; j < TBC; ++j) m[i][j] *= rr;
     }
+    NSTAMP(it, 6);
   }
   // ---- publish the final state for the backward kernel ----
 #pragma unroll
