@@ -43,7 +43,7 @@ SIGNATURES = {
     "ltrx_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_mha_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _f, ctypes.c_uint32, _vp, _vp, _vp, _i, _vp]),
-    "ltrx_mha_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ltrx_mha_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ltrx_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _f, _vp, _vp]),
     "ltrx_sgd_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _i, _f, _f, _vp, _vp]),
     "ltrx_clip_workspace_bytes": (_sz, [_sz]),

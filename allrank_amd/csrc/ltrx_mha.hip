@@ -523,8 +523,10 @@ int ltrx_mha_fwd_res_launch(const float* q, const float* k, const float* v, cons
                             const int* order, bool plain, hipStream_t s);
 int ltrx_mha_bwd_res_launch(const float* q, const float* k, const float* v, const uint8_t* kpm, const float* o, const float* dout,
                             const float* lse, int B, int L, int h, int dk, int rs, int ors, float* dq, float* dkk, float* dv, int drs,
-                            float* delta, float p_drop, uint32_t seed, const uint32_t* seed_step, const int* cu, const int* order,
+                            void* ws, float p_drop, uint32_t seed, const uint32_t* seed_step, const int* cu, const int* order,
                             bool plain, hipStream_t s);
+bool ltrx_mha_res_bwd_fits(int L, int dk);
+size_t ltrx_mha_res_bwd_ws_bytes(int B, int L, int h);
 
 static int mha_check(int B, int L, int h, int dk, int rs, int ors) {
   if (B <= 0 || L <= 0 || h <= 0 || dk <= 0) return LTRX_EINVAL;
@@ -571,8 +573,9 @@ extern "C" int ltrx_mha_fwd(const float* q, const float* k, const float* v, cons
   return LTRX_OK;
 }
 
-extern "C" size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h) {
-  if (B <= 0 || L <= 0 || h <= 0) return 0;
+extern "C" size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h, int d_k, int mode) {
+  if (B <= 0 || L <= 0 || h <= 0 || d_k <= 0) return 0;
+  if (mode != 0 && ltrx_mha_res_bwd_fits(L, d_k)) return ltrx_mha_res_bwd_ws_bytes(B, L, h);     // the dS exchange
   return (size_t)B * L * h * sizeof(float);
 }
 
@@ -589,9 +592,9 @@ extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, cons
   if (d_row_stride % 4 != 0 || d_row_stride < h * d_k) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* delta = (float*)ws;
-  if (mode != 0 && ltrx_mha_res_fits(L, d_k))
+  if (mode != 0 && ltrx_mha_res_bwd_fits(L, d_k))
     return ltrx_mha_bwd_res_launch(q, k, v, key_pad_mask, o, dout, lse, B, L, h, d_k, row_stride, o_row_stride, dq, dk, dv, d_row_stride,
-                                   delta, p_drop, seed, seed_step, cu_seqlens, slate_order, mode == 2, s);
+                                   ws, p_drop, seed, seed_step, cu_seqlens, slate_order, mode == 2, s);
   const DropCfg drop = make_drop(p_drop, seed);
   const dim3 grid(B * h, (L + 127) / 128);
   const float scale = 1.0f / sqrtf((float)d_k);

@@ -18,6 +18,10 @@
 //   * image layout: [row][64] bf16 per plane, 16-byte chunk c of row r at position c ^ s(r), s(r) = bit2(r) | bit3(r) << 1 |
 //     bit1(r) << 2: conflict-free for the 16-lane groups of the row-wise ds_read_b128 AND for the four rows x two column
 //     blocks of a transposed read (row bit 1 moves the 32-byte region, row bit 0 the 128-byte half of the bank row).
+//   * the backward computes S, P, dP and delta ONCE (round 3; five tile products instead of seven): the dK/dV kernel, which needs
+//     dS with the queries inside a lane, also writes it to an HBM workspace, and dQ = dS K -- which needs the keys inside a lane --
+//     is a second, memory-bound kernel that reads it back: the transposition happens in memory, deterministically (no atomics,
+//     no cross-wave reduction; everything in one kernel does not fit the LDS: Q, dO, K, V images alone are 256 KB).
 // Softmax in the log2 domain, natural-log LSE saved, dropout on P regenerated from (seed, query row, key) -- identical
 // conventions to ltrx_mha.hip, so forward / backward kernels of the two paths are interchangeable.  Variable-length
 // (cu_seqlens) batches: slate b is rows cu[b] .. cu[b+1]-1; waves beyond the slate's length exit after the staging barrier.
@@ -26,6 +30,7 @@
 using namespace ltrx;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef bf16x4 __attribute__((address_space(3))) * lds_bf16x4_ptr;
@@ -36,6 +41,8 @@ constexpr int RMAX = 256;                 // rows (items of a slate) held in LDS
 constexpr int DK = 64;                    // padded head dimension
 constexpr int PLANE = RMAX * DK * 2;      // bytes of one bf16 plane
 constexpr size_t RES_STATS = 4 * (size_t)PLANE + 3 * RMAX * sizeof(float);   // LDS bytes of the four planes + per-row statistics
+constexpr int XROW = 64;                  // keys per step of the dQ kernel (floats per row of a wave's dS staging area)
+constexpr size_t DQ_SMEM = 2 * (size_t)PLANE + 8 * 32 * XROW * sizeof(float);
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
@@ -284,7 +291,7 @@ __device__ __forceinline__ Slate which_slate(int L, int h, const int* __restrict
 // Q rows and first K / V tile during its LAST tile -- any earlier and the next streamed tile's vmcnt wait, which is in-order, waits
 // for these requests too (measured +14 %); as LDS-DMA into a scratch area the release fence of the LDS barrier waits for them
 // (same +14 %) -- into registers that stay reserved until the end of the kernel, and the successor's prologue finds the lines in
-// (or on their way into) this XCD's L2: forward 198 -> 190 us at config 3 (prologue 10.1 k -> 4.9 k cycles).  The two backward
+// (or on their way into) this XCD's L2: forward 198 -> 190 us at config 3 (prologue 10.1 k -> 4.9 k cycles).  The backward
 // kernels measured no gain from the same trick and do not use it.
 struct Touch {
   float t[2];
@@ -347,6 +354,8 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
   STAMP(32, 0);
   tile_gload(tr, src, 0, len, dk, rs);
   if ((int)(blockIdx.y * RMAX) >= len) return;        // whole workgroup beyond this slate (uniform: before any barrier)
+  uint8_t km_n = 0;                                   // threads 0-31: padding-mask byte of key 32 kt + threadIdx.x of the tile being staged
+  if (threadIdx.x < 32 && kpm && (int)threadIdx.x < len) km_n = kpm[sl.row0 + threadIdx.x];
   const int q0 = blockIdx.y * RMAX + wave * 32;
   const bool active = q0 < len;                 // (inactive waves still help staging and take every barrier)
   bf16x8 qh[4], ql[4];
@@ -360,11 +369,13 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
   for (int kt = 0; kt < nkt; ++kt) {
     STAMP(kt, 0);
     tile_sstore<PL>(dst, kt, tr);
-    if (threadIdx.x < 32) {
-      const int key = kt * 32 + threadIdx.x;
-      kbias[(kt & 7) * 32 + threadIdx.x] = (key >= len || (kpm && kpm[sl.row0 + key])) ? -INFINITY : 0.f;
+    if (threadIdx.x < 32) kbias[(kt & 7) * 32 + threadIdx.x] = (kt * 32 + (int)threadIdx.x >= len || km_n) ? -INFINITY : 0.f;
+    if (kt + 1 < nkt) {
+      tile_gload(tr, src, kt + 1, len, dk, rs);       // in flight during this tile's MFMAs
+      // the mask bytes of the next tile travel with it (loaded at the top of their own tile, the round trip sat between wave 0 and
+      // the barrier every other wave was already waiting at)
+      if (threadIdx.x < 32 && kpm && (kt + 1) * 32 + (int)threadIdx.x < len) km_n = kpm[sl.row0 + (kt + 1) * 32 + threadIdx.x];
     }
-    if (kt + 1 < nkt) tile_gload(tr, src, kt + 1, len, dk, rs);       // in flight during this tile's MFMAs
     if (LTRX_MHA_TOUCH && kt == nkt - 1 && blockIdx.y == 0) {     // (after the last wait on a streamed tile: nothing waits for these)
       Slate nx;
       if (next_slate(L, h, cu, order, nx)) {
@@ -426,89 +437,117 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// backward dQ (+ delta): K and V resident; wave owns 32 queries (Q and dO fragments in registers)
+// backward, second kernel: dQ = dS K.  dS comes from the dK/dV kernel's workspace (row-major [query][key] per (slate, head),
+// row stride LK) -- S, P and dP are computed ONCE per backward, in the kernel below.  A wave owns 32 queries and turns its
+// [32 queries][64 keys] fp32 block of dS (one "step") into the MFMA's D layout (lane = query, registers = keys) through a
+// wave-private LDS area: coalesced 256-byte rows in, one row per lane out (16-byte chunk c of row r at position c ^ (r & 15):
+// conflict-free both ways; no barrier is involved in that exchange).  K lives in LDS in chunks of 8 tiles (256 keys, the ring of the
+// other kernels), staged by the 512 threads between two barriers per chunk.
+// What bounds this kernel is memory latency, not the 24 MFMAs of a step (0.3 us): the dS blocks of D steps are in flight in
+// registers at any time (D = 3 when the slate is one chunk -- 4 would be the whole slate but spills; D = 2 and the next chunk of K
+// prefetched otherwise).
 // ------------------------------------------------------------------------------------------------------------------
-template <bool DROP, bool PL>
-__global__ void __launch_bounds__(512) ltrx_mha_bwd_dq_res_kernel(
-    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const uint8_t* __restrict__ kpm,
-    const float* __restrict__ o, const float* __restrict__ dout, const float* __restrict__ lse, float* __restrict__ delta, int L, int h,
-    int dk, int rs, int ors, float* __restrict__ dq, int drs, float scale, DropCfg drop, const uint32_t* __restrict__ drop_step,
-    const int* __restrict__ cu, const int* __restrict__ order) {
+struct DsRegs {
+  f32x4 x[8];
+};
+__device__ __forceinline__ void ds_gload(DsRegs& d, const float* __restrict__ rows, int step, int LK) {
+  const int lane = threadIdx.x & 63;
+  const float* p = rows + (size_t)(lane >> 4) * LK + step * XROW + (lane & 15) * 4;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d.x[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)(4 * j) * LK));
+}
+template <bool PL, int D, bool KPF>
+__global__ void __launch_bounds__(512) ltrx_mha_bwd_dq_res_kernel(const float* __restrict__ k, const float* __restrict__ dsw, int LK, int L,
+                                                                  int h, int dk, int rs, float* __restrict__ dq, int drs,
+                                                                  const int* __restrict__ cu, const int* __restrict__ order) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* kimg = smem;
-  unsigned char* vimg = smem + 2 * PLANE;
-  float* kbias = reinterpret_cast<float*>(smem + 4 * PLANE);
-  if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   const Slate sl = which_slate(L, h, cu, order);
-  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31;
+  f32x4* xs = reinterpret_cast<f32x4*>(smem + 2 * PLANE) + wave * (32 * XROW / 4);
   const int len = sl.len;
-  const float* src = (threadIdx.x < 256 ? k : v) + sl.row0 * rs + (size_t)sl.head * dk;
-  unsigned char* dst = threadIdx.x < 256 ? kimg : vimg;
-  TileRegs tr;
-  tile_gload(tr, src, 0, len, dk, rs);
   if ((int)(blockIdx.y * RMAX) >= len) return;
+  const float* src = k + sl.row0 * rs + (size_t)sl.head * dk;
+  const int sub = threadIdx.x >> 8;                    // threads 0-255 stage the even tiles of a chunk, 256-511 the odd ones
   const int q0 = blockIdx.y * RMAX + wave * 32;
   const bool active = q0 < len;
-  const int qrow = q0 + (lane & 31);
-  const size_t stat = ((size_t)sl.b * h + sl.head) * sl.Lmax + qrow;
-  // delta_q = <dO_q, O_q> in fp32 (each half-wave covers half of the head dimension); published for the dK/dV kernel
-  float del_q = 0.f;
-  if (qrow < len) {
-    const float* op = o + (sl.row0 + qrow) * ors + (size_t)sl.head * dk;
-    const float* dp = dout + (sl.row0 + qrow) * ors + (size_t)sl.head * dk;
-    const int cm = (dk / 2) & ~3;
-    const int c0 = half ? cm : 0, c1 = half ? dk : cm;
-    for (int c = c0; c < c1; c += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(op + c);
-      const float4 g = *reinterpret_cast<const float4*>(dp + c);
-      del_q += a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
-    }
+  const float* rows = dsw + ((size_t)sl.b * h + sl.head) * LK * LK + (size_t)q0 * LK;
+  const int nkt = (len + 31) / 32, nstep = (nkt + 1) / 2, nchunk = KPF ? (nkt + 7) / 8 : 1;      // (!KPF: launched for L <= 256 only)
+  static_assert(KPF ? (4 % D == 0) : true, "the register slot of step 4 c + s must not depend on c");
+  TileRegs tr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) tile_gload(tr[j], src, 2 * j + sub, len, dk, rs);       // (tiles beyond the slate are zeros)
+  DsRegs dr[D];
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+      if (s < nstep) ds_gload(dr[s], rows, s, LK);
   }
-  del_q += __shfl_xor(del_q, 32, 64);
-  if (half == 0 && qrow < len) delta[stat] = del_q;
-  const float lse_q = (qrow < len) ? lse[stat] * kLog2e : 0.f;
-  bf16x8 qh[4], ql[4], doh[4], dol[4];
-  load_fixed(qh, ql, q + sl.row0 * rs + (size_t)sl.head * dk, q0, len, dk, rs);
-  load_fixed(doh, dol, dout + sl.row0 * ors + (size_t)sl.head * dk, q0, len, dk, ors);
-  const uint32_t drow = DROP ? drop_row_seed(drop, sl.bh, sl.Lmax, qrow) : 0u;
-  const float sl2 = scale * kLog2e;
   f32x16 dqacc[2];
   zero2(dqacc);
-  const int nkt = (len + 31) / 32;
-  for (int kt = 0; kt < nkt; ++kt) {
-    tile_sstore<PL>(dst, kt, tr);
-    if (threadIdx.x < 32) {
-      const int key = kt * 32 + threadIdx.x;
-      kbias[(kt & 7) * 32 + threadIdx.x] = (key >= len || (kpm && kpm[sl.row0 + key])) ? -INFINITY : 0.f;
+  for (int c = 0; c < nchunk; ++c) {
+    if (c > 0) lds_only_barrier();                     // every wave is done with the previous chunk of K
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile_sstore<PL>(kimg, 2 * j + sub, tr[j]);
+    if (KPF && c + 1 < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile_gload(tr[j], src, 8 * (c + 1) + 2 * j + sub, len, dk, rs);
     }
-    if (kt + 1 < nkt) tile_gload(tr, src, kt + 1, len, dk, rs);
     lds_only_barrier();
     if (!active) continue;
-    const int slot = (kt & 7) * 32;
-    const f32x16 s = rows_x_fixed<2, PL>(kimg, slot, qh, ql);       // S^T[key][query]
-    const f32x16 dp = rows_x_fixed<2, PL>(vimg, slot, doh, dol);    // dP^T[key][query] = V dO^T
-    f32x16 ds;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kt * 32 + rowmap(r, half);
-      const float p = fast_exp2(s[r] * sl2 + kbias[slot + rowmap(r, half)] - lse_q);
-      const float dm = DROP ? drop_scale_rk(drop, drow, key) : 1.0f;
-      ds[r] = p * (dp[r] * dm - del_q) * scale;
+    for (int s = 0; s < 4; ++s) {
+      const int i = 4 * c + s;
+      if (i >= nstep) break;
+      DsRegs& cur = dr[s % D];                         // = (4 c + s) % D
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = (lane >> 4) + 4 * j;
+        xs[r * (XROW / 4) + ((lane & 15) ^ (r & 15))] = cur.x[j];
+      }
+      if (i + D < nstep) ds_gload(cur, rows, i + D, LK);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (2 * i + t >= nkt) break;                           // (uniform) the odd tile of the last step
+        f32x16 ds;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 x = xs[l31 * (XROW / 4) + ((8 * t + 2 * g + half) ^ (l31 & 15))];     // keys 32 t + 8 g + 4 half + 0..3
+          ds[4 * g + 0] = x.x;
+          ds[4 * g + 1] = x.y;
+          ds[4 * g + 2] = x.z;
+          ds[4 * g + 3] = x.w;
+        }
+        cols_x_p<PL>(kimg, (2 * s + t) * 32, ds, dqacc);      // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+      }
     }
-    cols_x_p<PL>(kimg, slot, ds, dqacc);                                   // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
   }
   if (!active) return;
   store_rows(dq + sl.row0 * drs + (size_t)sl.head * dk, q0, len, dk, drs, dqacc, 1.0f);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// backward dK, dV: Q and dO resident; wave owns 32 keys (K and V fragments in registers)
+// backward, first kernel: dK, dV, delta, and dS for the dQ kernel above.  Q and dO resident; wave owns 32 keys (K and V fragments
+// in registers).  delta_q = <dO_q, O_q> in fp32 is computed by the threads that stage the dO tiles: the matching O values travel
+// with every dO tile (8 floats per thread, 8 threads per row), so delta costs no extra pass, no extra kernel and -- unlike a
+// prologue that reads all of O and dO up front, measured +60 us -- adds nothing to the burst of compulsory loads every workgroup
+// starts with.  The dS tile a wave has in its registers after the softmax backward -- [query = rowmap(r, half)][key = l31] -- is
+// written to the workspace row-major (one 128-byte segment per half-wave and register, nontemporal: it is read once, by another
+// kernel, after 0.5 GB of other traffic).
 // ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tile_delta(const TileRegs& g, const TileRegs& a) {       // this thread's 8 columns, then the row's 8 threads
+  float d = g.a.x * a.a.x + g.a.y * a.a.y + g.a.z * a.a.z + g.a.w * a.a.w;
+  d += g.b.x * a.b.x + g.b.y * a.b.y + g.b.z * a.b.z + g.b.w * a.b.w;
+  d += __shfl_xor(d, 4, 64);
+  d += __shfl_xor(d, 2, 64);
+  d += __shfl_xor(d, 1, 64);
+  return d;
+}
 template <bool DROP, bool PL>
 __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const uint8_t* __restrict__ kpm,
-    const float* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta, int L, int h, int dk, int rs,
-    int ors, float* __restrict__ dkout, float* __restrict__ dvout, int drs, float scale, DropCfg drop,
+    const float* __restrict__ o, const float* __restrict__ dout, const float* __restrict__ lse, int L, int h, int dk, int rs, int ors,
+    float* __restrict__ dkout, float* __restrict__ dvout, int drs, float* __restrict__ dsw, int LK, float scale, DropCfg drop,
     const uint32_t* __restrict__ drop_step, const int* __restrict__ cu, const int* __restrict__ order) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* qimg = smem;
@@ -518,15 +557,21 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
   uint32_t* drow_t = reinterpret_cast<uint32_t*>(del_t + RMAX);
   if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   const Slate sl = which_slate(L, h, cu, order);
-  const int lane = threadIdx.x & 63, half = lane >> 5, wave = threadIdx.x >> 6;
+  // (wave index in a scalar register: `active` below must be a SCALAR branch -- as a divergent one both sides run under exec
+  //  masks and the tile loads of the inactive side make the active side wait vmcnt(0) before its own)
+  const int lane = threadIdx.x & 63, half = lane >> 5, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int len = sl.len;
-  const bool first = threadIdx.x < 256;
+  const bool first = wave < 4;                         // waves 0-3 stage Q, waves 4-7 stage dO (+ O for delta)
   const float* src = first ? q + sl.row0 * rs + (size_t)sl.head * dk : dout + sl.row0 * ors + (size_t)sl.head * dk;
+  const float* osrc = o + sl.row0 * ors + (size_t)sl.head * dk;
   const size_t srs = first ? (size_t)rs : (size_t)ors;
   unsigned char* dst = first ? qimg : doimg;
-  TileRegs tr;
+  TileRegs tr, to;
   tile_gload(tr, src, 0, len, dk, srs);
+  if (!first) tile_gload(to, osrc, 0, len, dk, ors);
   const size_t statb = ((size_t)sl.b * h + sl.head) * sl.Lmax;
+  float lse_n = 0.f;                                   // threads 0-31: LSE of query 32 qt + threadIdx.x of the tile being staged
+  if (threadIdx.x < 32 && (int)threadIdx.x < len) lse_n = lse[statb + threadIdx.x];
   if ((int)(blockIdx.y * RMAX) >= len) return;
   const int k0 = blockIdx.y * RMAX + wave * 32;
   bf16x8 kh[4], kl[4], vh[4], vl[4];
@@ -541,17 +586,29 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
   zero2(dkacc);
   zero2(dvacc);
   const int nqt = (len + 31) / 32;
+  // dS tile addressing: a wave-uniform base (scalar registers) + ONE 32-bit per-lane offset, so that the 16 stores of a tile cost
+  // no vector registers beyond the data (the kernel sits at the 256-register limit)
+  float* const dsp = dsw + ((size_t)sl.b * h + sl.head) * LK * LK + (blockIdx.y * RMAX + wave * 32);
+  const int dso = (4 * half * LK + (lane & 31)) * 4;      // bytes
   for (int qt = 0; qt < nqt; ++qt) {
+    if (!first) {                                                // (rows beyond the slate were loaded as zeros: delta 0)
+      const float d = tile_delta(tr, to);
+      if ((threadIdx.x & 7) == 0) del_t[(qt & 7) * 32 + ((threadIdx.x & 255) >> 3)] = d;
+    }
     tile_sstore<PL>(dst, qt, tr);
     if (threadIdx.x < 32) {                                      // per-query statistics of this tile (ring slot)
       const int qr = qt * 32 + threadIdx.x, sl_ = (qt & 7) * 32 + threadIdx.x;
-      lse_t[sl_] = (qr < len) ? lse[statb + qr] * kLog2e : INFINITY;       // +inf -> P = exp2(-inf) = 0 for rows >= len
-      del_t[sl_] = (qr < len) ? delta[statb + qr] : 0.f;
+      lse_t[sl_] = (qr < len) ? lse_n * kLog2e : INFINITY;       // +inf -> P = exp2(-inf) = 0 for rows >= len
       if (DROP) drow_t[sl_] = drop_row_seed(drop, sl.bh, sl.Lmax, qr);
     }
-    if (qt + 1 < nqt) tile_gload(tr, src, qt + 1, len, dk, srs);
     lds_only_barrier();
-    if (!active) continue;
+    if (!active) {
+      if (qt + 1 < nqt) {
+        tile_gload(tr, src, qt + 1, len, dk, srs);
+        if (!first) tile_gload(to, osrc, qt + 1, len, dk, ors);
+      }
+      continue;
+    }
     const int slot = (qt & 7) * 32;
     // (order chosen for register pressure: both 16-register products first, then the two accumulations; the fences keep the
     //  scheduler from hoisting the second accumulation's transposed reads above the first)
@@ -564,6 +621,23 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
       const float dm = DROP ? drop_scale_rk(drop, drow_t[qr], key) : 1.0f;
       ds[r] = pr * (ds[r] * dm - del_t[qr]) * scale;             // dS
       p[r] = pr * dm;                                            // P M
+    }
+    {
+      const float* const t = dsp + (size_t)(qt * 32) * LK;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)         // (asm: hipcc otherwise keeps 16 loop-invariant 64-bit vector addresses = 32 registers)
+        asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(dso), "v"(ds[r]), "s"(t + (size_t)((r & 3) + 8 * (r >> 2)) * LK));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next tile's loads go out AFTER the dS stores: the wait that precedes the next tile_sstore is vmcnt(0) and the memory
+    // counter retires in order -- issued before the stores (at the barrier, as in the other kernels) every tile waited for the write
+    // acknowledgements of its 16 stores; now those hide behind the loads' own latency and the two products below
+    if (qt + 1 < nqt) {
+      tile_gload(tr, src, qt + 1, len, dk, srs);
+      if (!first) tile_gload(to, osrc, qt + 1, len, dk, ors);
+      // (wave 0 is always active.)  The statistics of the NEXT tile travel with its operands: loaded at the top of the tile that
+      // uses them, the round trip sat between every workgroup-wide barrier and wave 0's arrival at it
+      if (threadIdx.x < 32 && (qt + 1) * 32 + (int)threadIdx.x < len) lse_n = lse[statb + (qt + 1) * 32 + threadIdx.x];
     }
     __builtin_amdgcn_sched_barrier(0);
     cols_x_p<PL>(doimg, slot, p, dvacc);                             // dV^T[d][key] += dO^T[d][query] (P M)[query][key]
@@ -582,10 +656,18 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
 static constexpr size_t RES_SMEM = RES_STATS;
 
 bool ltrx_mha_res_fits(int L, int dk) { return L > 0 && (L + RMAX - 1) / RMAX <= 65535 && dk > 32 && dk <= DK; }
+// (the dS exchange is B h LK^2 floats: bounded by the longest slate the losses take, LTRX_MAX_SLATE_LEN)
+bool ltrx_mha_res_bwd_fits(int L, int dk) { return ltrx_mha_res_fits(L, dk) && L <= LTRX_MAX_SLATE_LEN; }
+static int ds_stride(int L) { return (L + XROW - 1) / XROW * XROW; }
+// workspace of the backward: dS[B, h, LK, LK], LK = L rounded up to 64
+size_t ltrx_mha_res_bwd_ws_bytes(int B, int L, int h) {
+  const size_t lk = (size_t)ds_stride(L);
+  return (size_t)B * h * lk * lk * sizeof(float);
+}
 
 template <typename K>
-static int res_attr(K kernel) {
-  return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_SMEM) == hipSuccess ? LTRX_OK : LTRX_EHIP;
+static int res_attr(K kernel, size_t bytes) {
+  return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? LTRX_OK : LTRX_EHIP;
 }
 
 int ltrx_mha_fwd_res_launch(const float* q, const float* k, const float* v, const uint8_t* kpm, int B, int L, int h, int dk, int rs,
@@ -593,8 +675,8 @@ int ltrx_mha_fwd_res_launch(const float* q, const float* k, const float* v, cons
                             const int* order, bool plain, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
   const int arc = ltrx_once_per_device(attr_done, []() {
-    if (res_attr(ltrx_mha_fwd_res_kernel<false, false>) != LTRX_OK || res_attr(ltrx_mha_fwd_res_kernel<true, false>) != LTRX_OK ||
-        res_attr(ltrx_mha_fwd_res_kernel<false, true>) != LTRX_OK || res_attr(ltrx_mha_fwd_res_kernel<true, true>) != LTRX_OK)
+    if (res_attr(ltrx_mha_fwd_res_kernel<false, false>, RES_SMEM) != LTRX_OK || res_attr(ltrx_mha_fwd_res_kernel<true, false>, RES_SMEM) != LTRX_OK ||
+        res_attr(ltrx_mha_fwd_res_kernel<false, true>, RES_SMEM) != LTRX_OK || res_attr(ltrx_mha_fwd_res_kernel<true, true>, RES_SMEM) != LTRX_OK)
       return LTRX_EHIP;
     return LTRX_OK;
   });
@@ -617,14 +699,16 @@ int ltrx_mha_fwd_res_launch(const float* q, const float* k, const float* v, cons
 
 int ltrx_mha_bwd_res_launch(const float* q, const float* k, const float* v, const uint8_t* kpm, const float* o, const float* dout,
                             const float* lse, int B, int L, int h, int dk, int rs, int ors, float* dq, float* dkk, float* dv, int drs,
-                            float* delta, float p_drop, uint32_t seed, const uint32_t* seed_step, const int* cu, const int* order,
+                            void* ws, float p_drop, uint32_t seed, const uint32_t* seed_step, const int* cu, const int* order,
                             bool plain, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
   const int arc = ltrx_once_per_device(attr_done, []() {
-    if (res_attr(ltrx_mha_bwd_dq_res_kernel<false, false>) != LTRX_OK || res_attr(ltrx_mha_bwd_dq_res_kernel<true, false>) != LTRX_OK ||
-        res_attr(ltrx_mha_bwd_dkdv_res_kernel<false, false>) != LTRX_OK || res_attr(ltrx_mha_bwd_dkdv_res_kernel<true, false>) != LTRX_OK ||
-        res_attr(ltrx_mha_bwd_dq_res_kernel<false, true>) != LTRX_OK || res_attr(ltrx_mha_bwd_dq_res_kernel<true, true>) != LTRX_OK ||
-        res_attr(ltrx_mha_bwd_dkdv_res_kernel<false, true>) != LTRX_OK || res_attr(ltrx_mha_bwd_dkdv_res_kernel<true, true>) != LTRX_OK)
+    if (res_attr(ltrx_mha_bwd_dq_res_kernel<false, 3, false>, DQ_SMEM) != LTRX_OK || res_attr(ltrx_mha_bwd_dq_res_kernel<true, 3, false>, DQ_SMEM) != LTRX_OK ||
+        res_attr(ltrx_mha_bwd_dq_res_kernel<false, 2, true>, DQ_SMEM) != LTRX_OK || res_attr(ltrx_mha_bwd_dq_res_kernel<true, 2, true>, DQ_SMEM) != LTRX_OK ||
+        res_attr(ltrx_mha_bwd_dkdv_res_kernel<false, false>, RES_SMEM) != LTRX_OK ||
+        res_attr(ltrx_mha_bwd_dkdv_res_kernel<true, false>, RES_SMEM) != LTRX_OK ||
+        res_attr(ltrx_mha_bwd_dkdv_res_kernel<false, true>, RES_SMEM) != LTRX_OK ||
+        res_attr(ltrx_mha_bwd_dkdv_res_kernel<true, true>, RES_SMEM) != LTRX_OK)
       return LTRX_EHIP;
     return LTRX_OK;
   });
@@ -632,25 +716,26 @@ int ltrx_mha_bwd_res_launch(const float* q, const float* k, const float* v, cons
   const DropCfg drop = ltrx_make_drop(p_drop, seed);
   const float scale = 1.0f / sqrtf((float)dk);
   const dim3 grid(B * h, (L + RMAX - 1) / RMAX);
-#define LTRX_DQ(D_, P_)                                                                                                            \
-  hipLaunchKernelGGL((ltrx_mha_bwd_dq_res_kernel<D_, P_>), grid, dim3(512), RES_SMEM, s, q, k, v, kpm, o, dout, lse, delta, L, h, dk, rs, \
-                     ors, dq, drs, scale, drop, seed_step, cu, order)
+  const int LK = ds_stride(L);
+  float* dsw = (float*)ws;
 #define LTRX_DKDV(D_, P_)                                                                                                          \
-  hipLaunchKernelGGL((ltrx_mha_bwd_dkdv_res_kernel<D_, P_>), grid, dim3(512), RES_SMEM, s, q, k, v, kpm, dout, lse, delta, L, h, dk, rs,  \
-                     ors, dkk, dv, drs, scale, drop, seed_step, cu, order)
-  if (drop.thresh != 0u) {
-    if (plain) LTRX_DQ(true, true); else LTRX_DQ(true, false);
-  } else {
-    if (plain) LTRX_DQ(false, true); else LTRX_DQ(false, false);
-  }
-  LTRX_LAUNCH_CHECK();
+  hipLaunchKernelGGL((ltrx_mha_bwd_dkdv_res_kernel<D_, P_>), grid, dim3(512), RES_SMEM, s, q, k, v, kpm, o, dout, lse, L, h, dk,  \
+                     rs, ors, dkk, dv, drs, dsw, LK, scale, drop, seed_step, cu, order)
   if (drop.thresh != 0u) {
     if (plain) LTRX_DKDV(true, true); else LTRX_DKDV(true, false);
   } else {
     if (plain) LTRX_DKDV(false, true); else LTRX_DKDV(false, false);
   }
-#undef LTRX_DQ
 #undef LTRX_DKDV
+  LTRX_LAUNCH_CHECK();
+#define LTRX_DQ(P_, D_, K_)                                                                                                       \
+  hipLaunchKernelGGL((ltrx_mha_bwd_dq_res_kernel<P_, D_, K_>), grid, dim3(512), DQ_SMEM, s, k, dsw, LK, L, h, dk, rs, dq, drs, cu, order)
+  if (grid.y == 1) {
+    if (plain) LTRX_DQ(true, 3, false); else LTRX_DQ(false, 3, false);
+  } else {
+    if (plain) LTRX_DQ(true, 2, true); else LTRX_DQ(false, 2, true);
+  }
+#undef LTRX_DQ
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }

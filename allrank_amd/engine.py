@@ -304,7 +304,7 @@ class FusedTrainer(object):
             self.tmp_d = torch.zeros((M, d), **f32)
             self.d_br = torch.zeros((M, d), **f32)            # gradient of a dropped residual branch (ds * keep)
             self.ws_ln = torch.empty(max(self.lib.ltrx_layernorm_bwd_workspace_bytes(M, d), 64), dtype=torch.uint8, device=dev)
-            self.ws_mha = torch.empty(max(self.lib.ltrx_mha_bwd_workspace_bytes(B, L, self.h), 64), dtype=torch.uint8, device=dev)
+            self.ws_mha = torch.empty(max(self.lib.ltrx_mha_bwd_workspace_bytes(B, L, self.h, self.d // self.h, self._mha_mode), 64), dtype=torch.uint8, device=dev)
         no = self.n_out
         self.scores_raw = torch.zeros((B, L) if no == 1 else (B, L, no), **f32)      # what the loss sees (model.forward)
         self.scores = self.scores_raw if no == 1 else torch.zeros((B, L), **f32)      # model.score (sum over the output units)

@@ -154,7 +154,7 @@ class _AttentionFn(torch.autograd.Function):
         dqkv = torch.empty((B, SL, 3 * d), dtype=torch.float32, device=o.device)
         dq, dkk, dv = dqkv[:, :, 0:d], dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:3 * d]
         lib = L.lib()
-        ws = L.workspace(lib.ltrx_mha_bwd_workspace_bytes(B, SL, h), o)
+        ws = L.workspace(lib.ltrx_mha_bwd_workspace_bytes(B, SL, h, dk_, ctx.mode), o)
         L.check(lib.ltrx_mha_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(mask), L.ptr(o), L.ptr(do), L.ptr(lse), B, SL, h, dk_,
                                  q.stride(1), d, L.ptr(dq), L.ptr(dkk), L.ptr(dv), 3 * d, ctx.p_drop, ctx.seed, None, None, None, ctx.mode, L.ptr(ws),
                                  L.stream_of(o)), "mha_bwd")
@@ -190,7 +190,7 @@ class _AttentionPackedFn(torch.autograd.Function):
         do = L.f32c(do)
         dqkv = torch.empty((B, SL, 3 * d), dtype=torch.float32, device=o.device)
         lib = L.lib()
-        ws = L.workspace(lib.ltrx_mha_bwd_workspace_bytes(B, SL, h), o)
+        ws = L.workspace(lib.ltrx_mha_bwd_workspace_bytes(B, SL, h, d // h, ctx.mode), o)
         L.check(lib.ltrx_mha_bwd(L.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, L.ptr(mask), L.ptr(o), L.ptr(do), L.ptr(lse),
                                  B, SL, h, d // h, 3 * d, d, L.ptr(dqkv), dqkv.data_ptr() + 4 * d, dqkv.data_ptr() + 8 * d, 3 * d,
                                  ctx.p_drop, ctx.seed, None, None, None, ctx.mode, L.ptr(ws), L.stream_of(o)), "mha_bwd")

@@ -140,7 +140,7 @@ def time_kernels(w, B, L, device):
         lse_ = torch.empty(B, h, L, device=device)
         dqkv = torch.empty(B, L, 3 * d, device=device)
         m8 = mask.to(torch.uint8)
-        ws_ = torch.empty(max(lib.ltrx_mha_bwd_workspace_bytes(B, L, h), 64), dtype=torch.uint8, device=device)
+        ws_ = torch.empty(max(lib.ltrx_mha_bwd_workspace_bytes(B, L, h, dk, 1), 64), dtype=torch.uint8, device=device)
         st2 = LB.stream_of(qkv)
         t_f = ev(lambda: LB.check(lib.ltrx_mha_fwd(LB.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, LB.ptr(m8), B, L, h, dk,
                                                    3 * d, LB.ptr(o_), d, LB.ptr(lse_), 0.0, 0, None, None, None, 1, st2), "mha_fwd"))

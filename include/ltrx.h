@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTRX_VERSION 110 /* 0.1.1: mode / tile / path are call arguments (round 3) */
+#define LTRX_VERSION 111 /* 0.1.1: mode / tile / path are call arguments; attention backward workspace depends on (d_k, mode) (round 3) */
 
 #define LTRX_OK 0
 #define LTRX_EINVAL (-1)
@@ -211,8 +211,12 @@ int ltrx_mha_fwd(const float* q, const float* k, const float* v, const uint8_t* 
                  int d_k, int row_stride, float* o, int o_row_stride, float* lse_out, float p_drop, uint32_t seed,
                  const uint32_t* seed_step, const int32_t* cu_seqlens, const int32_t* slate_order, int mode,
                  ltrx_stream_t stream);
-/* backward: dq,dk,dv from do; delta_ws[B,h,L] scratch (rowsum(do*o)). */
-size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h);
+/* backward: dq,dk,dv from do.  `ws` holds delta[B,h,L] (rowsum(do*o)) for the exact kernels, or -- in modes 1 / 2 where the
+ * LDS-resident kernels run (32 < d_k <= 64, L <= LTRX_MAX_SLATE_LEN) -- the dS exchange between the two backward kernels,
+ * B*h*LK*LK floats with LK = L rounded up to 64: S, P, dP and delta are computed once, by the dK/dV kernel, which hands dS to a
+ * dQ = dS K kernel through HBM (deterministic, no atomics).  Size it with ltrx_mha_bwd_workspace_bytes for the SAME (d_k, mode)
+ * the call will use. */
+size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h, int d_k, int mode);
 int ltrx_mha_bwd(const float* q, const float* k, const float* v, const uint8_t* key_pad_mask, const float* o,
                  const float* dout, const float* lse, int B, int L, int h, int d_k, int row_stride, int o_row_stride,
                  float* dq, float* dk, float* dv, int d_row_stride, float p_drop, uint32_t seed,

@@ -29,13 +29,13 @@ def test_header_symbols_are_exported(libpath):
     for n in names:
         assert hasattr(h, n), "libltrx.so does not export %s declared in include/ltrx.h" % n
     h.ltrx_version.restype = ctypes.c_int
-    assert h.ltrx_version() == 110
+    assert h.ltrx_version() == 111
 
 
 def test_binding_table_matches_header(libpath):
     from allrank_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
-    assert _lib.lib().ltrx_version() == 110
+    assert _lib.lib().ltrx_version() == 111
 
 
 def test_slate_length_limits_are_stated_once_and_reported(libpath):
@@ -59,7 +59,10 @@ def test_workspace_queries_and_argument_validation_run_without_a_gpu(libpath):
     lib = _lib.lib()
     assert lib.ltrx_listnet_workspace_bytes(64, 240) >= 64 * 4
     assert lib.ltrx_neuralndcg_workspace_bytes(64, 240, 50) >= 2 * 64 * 240 * 240 * 4
-    assert lib.ltrx_mha_bwd_workspace_bytes(64, 240, 8) == 64 * 240 * 8 * 4
+    assert lib.ltrx_mha_bwd_workspace_bytes(64, 240, 8, 64, 0) == 64 * 240 * 8 * 4
+    # modes 1 / 2, LDS-resident backward: the dS exchange, B*h*256*256 floats
+    assert lib.ltrx_mha_bwd_workspace_bytes(64, 240, 8, 64, 1) == 64 * 8 * 256 * 256 * 4
+    assert lib.ltrx_mha_bwd_workspace_bytes(64, 240, 8, 128, 1) == 64 * 240 * 8 * 4
     # NULL pointers / bad shapes are rejected before any HIP call
     assert lib.ltrx_listnet_fwd_bwd(None, None, 1, 1, 1e-10, -1.0, 1.0, None, None, None, None, None) == -1
     assert lib.ltrx_mha_fwd(None, None, None, None, 1, 1, 1, 64, 64, None, 64, None, 0.0, 0, None, None, None, 1, None) == -1

@@ -148,6 +148,14 @@ def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=
                    score_err=serr, score_scale=float(np.abs(so[~mask]).max()), grads={},
                    relu_units=units, relu_units_on_other_branch=flips, max_abs_preact_of_those=zmax)
         row.update(_ndcg5_row(sc_t, so, y, mask, serr))
+        # d loss / d scores: the loss kernel against the oracle AT THE ENGINE'S OWN SCORES (the kernel's error), and how far the
+        # oracle's own gradient moves between the engine's scores and the oracle's (the conditioning of the loss at this point:
+        # what ANY forward with this score error does to every parameter gradient downstream)
+        gs_at_engine = np.asarray(oracle_loss(sc, y)[1], dtype=np.float64)
+        gk = ft.loss.grad.detach().cpu().numpy().astype(np.float64).reshape(gs_at_engine.shape)
+        gsc = float(np.abs(gs).max())
+        row["lossgrad_kernel_err"] = float(np.abs(gk - gs_at_engine).max()) / gsc
+        row["lossgrad_shift_from_score_err"] = float(np.abs(gs_at_engine - gs).max()) / gsc
         gmax = max(float(np.abs(g_or[k]).max()) for k in keys)
         for k in keys:
             own = float(np.abs(g_or[k]).max())
@@ -199,10 +207,18 @@ def _check(rows, name, grad_tol=GRAD_TOL, ndcg=True):
             (name, s, r["relu_units_on_other_branch"], r["relu_units"], r["max_abs_preact_of_those"])
         # every parameter gradient, relative to the largest entry of its own tensor (tensors whose true gradient is
         # identically 0 -- key bias, output bias under a shift-invariant loss -- are bounded relative to the model's largest)
+        # The loss kernel itself, at the engine's own scores: <= 1e-4 of the largest d loss / d score (measured <= 2e-5).  What the
+        # forward's score error does to the loss gradient IN EXACT ARITHMETIC (the oracle's gradient at the engine's scores vs at
+        # its own) is the conditioning of the loss at this point, and every parameter gradient inherits it: NeuralNDCG at the
+        # third step of config 4 moves by 2e-3 for a score error of 9e-5 (its kernel error there: 2e-5) -- the bars above are
+        # widened to twice that shift where it exceeds them, and the shift is in the logged table.
+        shift = r["lossgrad_shift_from_score_err"]
+        assert r["lossgrad_kernel_err"] <= max(1e-4, grad_tol / 10), (name, s, r["lossgrad_kernel_err"])
+        tol, tol_model, tol_rms = max(grad_tol, 2 * shift), max(GRAD_TOL_MODEL, 2 * shift), max(GRAD_RMS_TOL, shift)
         bad = {k: v for k, v in r["grads"].items()
-               if (v["own_max"] > 1e-6 * r["grad_model_scale"] and (v["rel"] > grad_tol or v["rms_err"] > GRAD_RMS_TOL * v["own_max"]))
-               or v["rel_model"] > GRAD_TOL_MODEL}
-        assert not bad, (name, s, bad)
+               if (v["own_max"] > 1e-6 * r["grad_model_scale"] and (v["rel"] > tol or v["rms_err"] > tol_rms * v["own_max"]))
+               or v["rel_model"] > tol_model}
+        assert not bad, (name, s, shift, bad)
         # Adam: every entry of every tensor to fp32 round-off of the update (|w| <= ~2, update <= lr)
         assert r["adam_err"] <= 3e-7, (name, s, r["adam_err"])
         assert 0.5 * LR <= r["adam_move"] <= 1.01 * LR * 10, (name, s, r["adam_move"])

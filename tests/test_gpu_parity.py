@@ -1323,7 +1323,7 @@ def test_attention_varlen_matches_padded(B, L, h, dk, lens, p_drop):
     n = int(cu[-1])
     cu = cu.cuda()
     st = LB.stream_of(qkv)
-    ws = torch.empty(max(lib.ltrx_mha_bwd_workspace_bytes(B, L, h), 64), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(max(lib.ltrx_mha_bwd_workspace_bytes(B, L, h, dk, 1), 64), dtype=torch.uint8, device="cuda")
 
     def run(qkv_, do_, kpm, cu_, rows, order_=None):
         o = torch.zeros((rows, d), device="cuda")

@@ -12,9 +12,9 @@ o = torch.empty(B * L, d, device=dev)
 lse = torch.empty(B, h, L, device=dev)
 dqkv = torch.empty(B * L, 3 * d, device=dev)
 mask = torch.zeros(B, L, dtype=torch.uint8, device=dev)
-ws = torch.empty(max(lib.ltrx_mha_bwd_workspace_bytes(B, L, h), 64), dtype=torch.uint8, device=dev)
 P = LB.ptr
 MODE = int(os.environ.get('MMODE', '1'))     # attention arithmetic of the calls: 0 exact fp32, 1 split-bf16, 2 plain bf16
+ws = torch.empty(max(lib.ltrx_mha_bwd_workspace_bytes(B, L, h, d // h, MODE), 64), dtype=torch.uint8, device=dev)
 for _ in range(5):
     LB.check(lib.ltrx_mha_fwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(mask), B, L, h, dk, 3 * d, P(o), d, P(lse), 0.0, 0,
                               None, None, None, MODE, None), "fwd")

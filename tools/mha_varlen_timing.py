@@ -16,7 +16,7 @@ for ln in (16, 32, 64, 96, 112, 128, 160, 192, 240):
     lse = torch.empty(B, h, Lmax, device=dev)
     dqkv = torch.empty(n, 3 * d, device=dev)
     cu = (torch.arange(B + 1, dtype=torch.int32) * ln).to(dev)
-    ws = torch.empty(max(lib.ltrx_mha_bwd_workspace_bytes(B, Lmax, h), 64), dtype=torch.uint8, device=dev)
+    ws = torch.empty(max(lib.ltrx_mha_bwd_workspace_bytes(B, Lmax, h, dk, 1), 64), dtype=torch.uint8, device=dev)
     st = LB.stream_of(qkv)
 
     def fwd():
