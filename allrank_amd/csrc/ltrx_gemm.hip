@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(BM_ * 2) __attribute__((amdgpu_waves_per_eu(2,
           if (act == 1) v = fmaxf(v, 0.f);
           if (act == 2) v = (aux[(size_t)row * ldaux + col] > 0.f) ? v * drop.inv_keep : 0.f;   // ReLU(+dropout) backward
           else if (drop.thresh != 0u) v *= ltrx::drop_keep_scale(dsp, (uint64_t)row * (uint64_t)N + (uint64_t)col);
+          if (act == 3) v += aux[(size_t)row * ldaux + col];                                    // residual stream + drop(branch)
           C[(size_t)row * ldc + col] = v;
         }
       }
@@ -380,7 +381,7 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
       f32x4 ax[4];
-      if (act == 2) {
+      if (act == 2 || act == 3) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int row = m0 + wr * (BM / 2) + i * 32 + 8 * g + 4 * half + q;
@@ -416,6 +417,9 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
           v.y *= ltrx::drop_keep_scale(dsp, e + 1);
           v.z *= ltrx::drop_keep_scale(dsp, e + 2);
           v.w *= ltrx::drop_keep_scale(dsp, e + 3);
+        }
+        if (act == 3) {      // SublayerConnection: x + dropout(sublayer(norm(x))) (transformer.py:98-106), the stream read here
+          v.x += ax[g].x; v.y += ax[g].y; v.z += ax[g].z; v.w += ax[g].w;
         }
         __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(C + (size_t)row * ldc + col));
       }
@@ -757,10 +761,10 @@ static void launch_nt(const float* A, int lda, const float* B, int ldb, float* C
 extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, const void* B_image, float* C, int ldc, int M, int N, int K,
                             const float* bias, int act, const float* aux, int ldaux, float drop_p, uint32_t drop_seed,
                             const uint32_t* drop_step, int strict, int tile, ltrx_stream_t stream) {
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2 || tile < 0) return LTRX_EINVAL;
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 3 || tile < 0) return LTRX_EINVAL;
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return LTRX_EINVAL;
   const ltrx::DropSpec drop = ltrx_make_drop(drop_p, drop_seed);
-  if (act == 2 && (!aux || ldaux < N)) return LTRX_EINVAL;
+  if ((act == 2 || act == 3) && (!aux || ldaux < N)) return LTRX_EINVAL;
   if ((K & 3) || (lda & 3) || (ldb & 3) || lda < K || ldb < K || ldc < N) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   int v = tile;

@@ -293,7 +293,6 @@ class FusedTrainer(object):
                 s_att=self._site(4 * i), s_ff=self._site(4 * i + 1), s_s0=self._site(4 * i + 2), s_s1=self._site(4 * i + 3))
             self.layers.append(st)
         if self.N:
-            self.branch = torch.zeros((M, d), **f32)          # attention-proj / FFN output before the residual add
             self.xsum_f = torch.zeros((M, d), **f32)
             self.xf = torch.zeros((M, d), **f32)
             self.mean_f = torch.zeros(M, **f32)
@@ -483,8 +482,10 @@ class FusedTrainer(object):
         else:
             wait()
 
-    def _lin_fwd(self, x, w, b, out, act=0, p=0.0, seed=0):
-        """out = drop_p(act(x w^T + b))   (nn.Linear forward, act 1 = ReLU; dropout in the epilogue)"""
+    def _lin_fwd(self, x, w, b, out, act=0, p=0.0, seed=0, res=None):
+        """out = drop_p(act(x w^T + b)) [+ res]   (nn.Linear forward, act 1 = ReLU; dropout in the epilogue; ``res`` = the
+        residual stream of the SublayerConnection this projection closes, transformer.py:98-106: added in the epilogue, so the
+        sum is written once by the GEMM instead of being re-read and re-written by the LayerNorm that follows)"""
         if self.gemm == "hipblaslt":
             n = self.rows
             torch.addmm(b, x[:n], w.t(), out=out[:n])
@@ -492,11 +493,13 @@ class FusedTrainer(object):
                 torch.relu_(out[:n])
             if p:
                 self._drop_apply(out, out, p, seed)
+            if res is not None:
+                out[:n].add_(res[:n])
             return
         P = self.LB.ptr
         self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), self._img(w), P(out), out.stride(0), self.rows, w.shape[0],
-                                            x.shape[1], P(b), act, None, 0, float(p), seed, P(self.drop_step),
-                                            self._prec, 0, self._st()), "gemm_nt(fwd)")
+                                            x.shape[1], P(b), 3 if res is not None else act, P(res), res.stride(0) if res is not None else 0,
+                                            float(p), seed, P(self.drop_step), self._prec, 0, self._st()), "gemm_nt(fwd)")
 
     def _lin_dgrad(self, dy, w, wT, out, relu_of=None, p=0.0, seed=0):
         """out = dy w   (input gradient of nn.Linear); wT = w^T contiguous.  With ``relu_of`` (the saved post-ReLU,
@@ -555,16 +558,10 @@ class FusedTrainer(object):
                                               P(self.x_pe), self._st()), "posenc_fwd")
             h = self.x_pe
         x = h                                                     # residual stream
-        p_prev, s_prev = 0.0, 0                                   # dropout of the pending FFN branch (sublayer[1] of layer i-1)
         for i, st in enumerate(self.layers):
             lay = st["mod"]
             n0, n1 = lay.sublayer[0].norm, lay.sublayer[1].norm
-            if i == 0:
-                self._ln_fwd(x, None, W(n0.a_2), W(n0.b_2), None, st["xn0"], st["mean0"], st["rstd0"])
-            else:                                                 # x = x1_prev + ffn_prev, fused with this layer's first norm
-                self._ln_fwd(x, self.branch, W(n0.a_2), W(n0.b_2), st["xsum0"], st["xn0"], st["mean0"], st["rstd0"],
-                             dp(p_prev), s_prev)
-                x = st["xsum0"]
+            self._ln_fwd(x, None, W(n0.a_2), W(n0.b_2), None, st["xn0"], st["mean0"], st["rstd0"])
             st["xin"] = x
             self._lin_fwd(st["xn0"], st["wqkv"], st["bqkv"], st["qkv"])
             qkv = st["qkv"]
@@ -572,9 +569,9 @@ class FusedTrainer(object):
                                            d // self.h, 3 * d, P(st["o"]), d, P(st["lse"]), dp(st["p_att"]), st["s_att"],
                                            P(self.drop_step), P(self.cu), P(self.order), self._mha_mode, self._st()), "mha_fwd")
             lo = lay.self_attn.linears[3]
-            self._lin_fwd(st["o"], W(lo.weight), W(lo.bias), self.branch)
-            self._ln_fwd(x, self.branch, W(n1.a_2), W(n1.b_2), st["x1"], st["xn1"], st["mean1"], st["rstd1"],
-                         dp(st["p_s0"]), st["s_s0"])
+            # x1 = x + dropout(attention branch): the residual sum is the out-projection's epilogue (act 3)
+            self._lin_fwd(st["o"], W(lo.weight), W(lo.bias), st["x1"], 0, dp(st["p_s0"]), st["s_s0"], res=x)
+            self._ln_fwd(st["x1"], None, W(n1.a_2), W(n1.b_2), None, st["xn1"], st["mean1"], st["rstd1"])
             ff = lay.feed_forward
             if self.probe is not None and train:                  # bench.py: HIP events around the roofline kernel, in the step
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -583,13 +580,14 @@ class FusedTrainer(object):
             if self.probe is not None and train:
                 ev1.record()
                 self.probe.append((ev0, ev1))
-            self._lin_fwd(st["r"], W(ff.w_2.weight), W(ff.w_2.bias), self.branch)
-            x = st["x1"]
-            p_prev, s_prev = st["p_s1"], st["s_s1"]
+            # x(next layer) = x1 + dropout(feed-forward branch), again in the epilogue of the projection that closes the sublayer
+            nxt = self.layers[i + 1]["xsum0"] if i + 1 < len(self.layers) else self.xsum_f
+            self._lin_fwd(st["r"], W(ff.w_2.weight), W(ff.w_2.bias), nxt, 0, dp(st["p_s1"]), st["s_s1"], res=st["x1"])
+            x = nxt
         out = self.model.output_layer
         if self.N:
             nf = self.enc.norm
-            self._ln_fwd(x, self.branch, W(nf.a_2), W(nf.b_2), self.xsum_f, self.xf, self.mean_f, self.rstd_f, dp(p_prev), s_prev)
+            self._ln_fwd(x, None, W(nf.a_2), W(nf.b_2), None, self.xf, self.mean_f, self.rstd_f)
             feat = self.xf
         else:
             feat = x

@@ -294,7 +294,9 @@ int ltrx_score_head_bwd(const float* dscores, const float* x, const float* w, in
  *   ltrx_gemm_nt: C[M,N] (ld ldc) = epi( A[M,K] (ld lda) * B[N,K]^T (ld ldb) + bias[N] )
  *                 -- forward (B = weight) and input gradient (B = weight^T);  K, lda, ldb multiples of 4.
  *                 epilogue `act`: 0 none, 1 ReLU (transformer.py:227 fused), 2 multiply by (aux[m,n] > 0): the ReLU
- *                 backward fused into the input-gradient GEMM (aux = the saved post-activation tensor, ld ldaux).
+ *                 backward fused into the input-gradient GEMM (aux = the saved post-activation tensor, ld ldaux);
+ *                 3 add aux[m,n] AFTER the dropout: C = aux + drop_p(A B^T + bias), the residual connection of
+ *                 SublayerConnection (transformer.py:98-106) written by the projection that closes the sublayer.
  *                 drop_p > 0: nn.Dropout after the activation (model.py:43, transformer.py:227) fused in the epilogue
  *                 (act 0/1: counter-based mask over the [M,N] output; act 2: the mask is carried by aux, only 1/(1-p)).
  *   ltrx_gemm_tn: C[NP,KP] (dense) = A[M,NP]^T * B[M,KP]  -- weight gradient dW = dY^T X (split over M, deterministic);

@@ -1153,6 +1153,43 @@ def test_gemm_nt_with_presplit_weight_image_is_bit_identical():
                 assert torch.equal(outs[0], outs[1]), (Mm, N, K, prec, act)
 
 
+def test_gemm_nt_residual_epilogue_equals_gemm_then_add_bit_for_bit():
+    """act 3 of ltrx_gemm_nt: C = aux + dropout_p(A B^T + bias), the SublayerConnection sum (transformer.py:98-106) written by
+    the projection that closes the sublayer.  Same bits as the GEMM with the same dropout site followed by a separate fp32 add
+    -- the composition the engine used before (the add lived in ltrx_layernorm_fwd) -- for both tile forms, a ragged last row
+    tile, with and without dropout / weight image; an in-place residual (C == aux) is allowed."""
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    rng = np.random.default_rng(41)
+    step = torch.full((1,), 3, dtype=torch.int32, device=DEV)
+    for (Mm, N, K) in [(24000, 512, 512), (6144, 512, 2048), (700, 512, 96), (300, 256, 136), (64, 96, 20)]:
+        A = _t(rng.standard_normal((Mm, K)).astype(np.float32))
+        Bw = _t((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+        bias = _t(rng.standard_normal(N).astype(np.float32))
+        res = _t(rng.standard_normal((Mm, N)).astype(np.float32))
+        img = None
+        if K % 4 == 0:
+            img = torch.empty_like(Bw)
+            LB.check(lib.ltrx_split_image(LB.ptr(Bw), LB.ptr(img), Bw.numel(), None), "split_image")
+        for p in (0.0, 0.2):
+            for image in ((None, img) if img is not None else (None,)):
+                two = torch.empty((Mm, N), device=DEV)
+                LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, LB.ptr(image), LB.ptr(two), N, Mm, N, K, LB.ptr(bias), 0, None, 0, p, 91,
+                                          LB.ptr(step), 0, 0, None), "gemm_nt")
+                two = two + res
+                one = torch.empty((Mm, N), device=DEV)
+                LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, LB.ptr(image), LB.ptr(one), N, Mm, N, K, LB.ptr(bias), 3, LB.ptr(res), N, p, 91,
+                                          LB.ptr(step), 0, 0, None), "gemm_nt(act 3)")
+                assert torch.equal(one, two), (Mm, N, K, p)
+                inplace = res.clone()
+                LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, LB.ptr(image), LB.ptr(inplace), N, Mm, N, K, LB.ptr(bias), 3, LB.ptr(inplace), N,
+                                          p, 91, LB.ptr(step), 0, 0, None), "gemm_nt(act 3, in place)")
+                assert torch.equal(inplace, two), (Mm, N, K, p)
+    C = torch.empty((64, 96), device=DEV)
+    assert lib.ltrx_gemm_nt(LB.ptr(A), 20, LB.ptr(Bw), 20, None, LB.ptr(C), 96, 64, 96, 20, None, 3, None, 0, 0.0, 0, None, 0, 0, None) != 0   # act 3 needs aux
+    assert lib.ltrx_gemm_nt(LB.ptr(A), 20, LB.ptr(Bw), 20, None, LB.ptr(C), 96, 64, 96, 20, None, 4, None, 0, 0.0, 0, None, 0, 0, None) != 0
+
+
 def test_large_tile_wgrad_gemm_matches_fp64_and_the_small_tile_kernel():
     """the 256 x 256 split-K weight-gradient kernel (auto for NP, KP multiples of 256) vs fp64 and vs the 128 x 128 kernel."""
     from allrank_amd import _lib as LB
