@@ -181,15 +181,15 @@ __global__ void __launch_bounds__(256) ltrx_layernorm_fwd_vec_kernel(const float
   }
 }
 
-template <int NV>
-__global__ void __launch_bounds__(256) ltrx_layernorm_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ xsum,
+template <int NV, int WPB>
+__global__ void __launch_bounds__(64 * WPB) ltrx_layernorm_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ xsum,
                                                                      const float* __restrict__ a, const float* __restrict__ mean_in,
                                                                      const float* __restrict__ rstd_in, const float* __restrict__ dres,
                                                                      int rows, float eps, float* __restrict__ dx,
                                                                      float* __restrict__ partial) {
   constexpr int D = 256 * NV;
-  __shared__ __attribute__((aligned(16))) float lds[4 * 2 * D];
-  const int lane = lane_id(), w = wave_id(), wpb = blockDim.x >> 6;
+  __shared__ __attribute__((aligned(16))) float lds[WPB * 2 * D];
+  const int lane = lane_id(), w = wave_id(), wpb = WPB;
   float4 av[NV], da[NV], db[NV];
 #pragma unroll
   for (int t = 0; t < NV; ++t) {
@@ -282,12 +282,19 @@ static int ln_grid(int rows) {
   return g > 1024 ? 1024 : (g < 1 ? 1 : g);
 }
 // the backward keeps per-block column partials: fewer, fatter blocks (each wave walks many rows)
-// (320: measured again in round 3 -- 1024 workgroups run the kernel itself 20 % faster standalone (120 -> 96 us) but triple the partial
-//  rows the reduce kernel sums (8 -> 22 us), and the training step does not move: 9.31 vs 9.31 ms; profiles/NOTES.md)
+// (round 3: 1024 four-wave workgroups run the kernel 20 % faster than 320 (120 -> 96 us at 61440 x 512: 16 instead of 5 waves per CU
+//  in flight) but triple the partial rows of the reduce kernel (8 -> 22 us); 256 sixteen-wave workgroups -- ln_bwd_wide below -- keep the
+//  waves in flight AND cut the partial rows: 118 + 8.5 -> 94 + 6.9 us, same-box A/B gpurun_out/r3_ln_wide_ab.txt, profiles/NOTES.md)
 static int ln_bwd_grid(int rows) {
   int g = (rows + 15) / 16;
   return g > 320 ? 320 : (g < 1 ? 1 : g);
 }
+// D <= 512 and enough rows: 16-wave workgroups, one per CU -- the same 16 waves per CU in flight as 1024 four-wave workgroups
+// (which stream 20 % faster than 320 of them) but 256 partial rows for the reduce kernel instead of 1024
+#ifndef LTRX_LN_BWD_G16
+#define LTRX_LN_BWD_G16 256
+#endif
+static bool ln_bwd_wide(int rows, int D) { return D <= 512 && rows >= 16 * 4 * LTRX_LN_BWD_G16; }
 static int ln_fwd_vec_grid(int rows) {
   int g = (rows + 7) / 8;
   return g > 1024 ? 1024 : (g < 1 ? 1 : g);
@@ -324,7 +331,7 @@ extern "C" int ltrx_layernorm_fwd(const float* x, const float* res, const float*
 
 extern "C" size_t ltrx_layernorm_bwd_workspace_bytes(int rows, int D) {
   if (rows <= 0 || D <= 0) return 0;
-  return (size_t)ln_bwd_grid(rows) * 2 * D * sizeof(float);
+  return (size_t)(LTRX_LN_BWD_G16 > 320 ? LTRX_LN_BWD_G16 : 320) * 2 * D * sizeof(float);
 }
 
 extern "C" int ltrx_layernorm_bwd(const float* dy, const float* xsum, const float* a, const float* mean,
@@ -333,14 +340,20 @@ extern "C" int ltrx_layernorm_bwd(const float* dy, const float* xsum, const floa
   if (!dy || !xsum || !a || !mean || !rstd || !dx_out || !da_out || !db_out || !ws || rows <= 0 || D < 2) return LTRX_EINVAL;
   if ((size_t)4 * 2 * D * sizeof(float) > 64 * 1024) return LTRX_EUNSUPPORTED;   // D <= 2048
   hipStream_t s = (hipStream_t)stream;
-  const int grid = ln_bwd_grid(rows);
+  int grid = ln_bwd_grid(rows);
   if (ln_vec_ok(D, dy, xsum, dx_out) && ln_vec_ok(D, a, dres_in, ws)) {
-#define LTRX_LN_BWD(NV) hipLaunchKernelGGL(ltrx_layernorm_bwd_vec_kernel<NV>, dim3(grid), dim3(256), 0, s, dy, xsum, a, mean, rstd, dres_in, rows, eps, dx_out, (float*)ws)
-    switch (D / 256) {
-      case 1: LTRX_LN_BWD(1); break;
-      case 2: LTRX_LN_BWD(2); break;
-      case 3: LTRX_LN_BWD(3); break;
-      default: LTRX_LN_BWD(4); break;
+#define LTRX_LN_BWD(NV, WPB) \
+  hipLaunchKernelGGL((ltrx_layernorm_bwd_vec_kernel<NV, WPB>), dim3(grid), dim3(64 * WPB), 0, s, dy, xsum, a, mean, rstd, dres_in, rows, eps, dx_out, (float*)ws)
+    if (ln_bwd_wide(rows, D)) {
+      grid = LTRX_LN_BWD_G16;
+      if (D / 256 == 1) LTRX_LN_BWD(1, 16); else LTRX_LN_BWD(2, 16);
+    } else {
+      switch (D / 256) {
+        case 1: LTRX_LN_BWD(1, 4); break;
+        case 2: LTRX_LN_BWD(2, 4); break;
+        case 3: LTRX_LN_BWD(3, 4); break;
+        default: LTRX_LN_BWD(4, 4); break;
+      }
     }
 #undef LTRX_LN_BWD
   } else {
