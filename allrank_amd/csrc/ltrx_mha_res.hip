@@ -132,15 +132,23 @@ __device__ __forceinline__ void lds_only_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 #ifdef LTRX_MHA_STAMP        // lab builds only (tools/lab/lib_variant.sh): cycle stamps of one workgroup of the forward kernel
-__device__ unsigned long long g_mha_stamps[8][40][6];
-#define STAMP(kt, ph)                                                                  \
+__device__ unsigned long long g_mha_stamps[8][40][8];       // (or of the dK/dV kernel with -DLTRX_MHA_STAMP_DKDV)
+#define STAMP_(kt, ph)                                                                 \
   do {                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                 \
     if (blockIdx.x == LTRX_MHA_STAMP && (threadIdx.x & 63) == 0) g_mha_stamps[threadIdx.x >> 6][kt][ph] = __builtin_readcyclecounter(); \
     __builtin_amdgcn_sched_barrier(0);                                                 \
   } while (0)
+#ifdef LTRX_MHA_STAMP_DKDV
+#define STAMP(kt, ph)
+#define DSTAMP(kt, ph) STAMP_(kt, ph)
+#else
+#define STAMP(kt, ph) STAMP_(kt, ph)
+#define DSTAMP(kt, ph)
+#endif
 #else
 #define STAMP(kt, ph)
+#define DSTAMP(kt, ph)
 #endif
 #ifndef LTRX_MHA_TOUCH
 #define LTRX_MHA_TOUCH 1
@@ -567,6 +575,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
   const size_t srs = first ? (size_t)rs : (size_t)ors;
   unsigned char* dst = first ? qimg : doimg;
   TileRegs tr, to;
+  DSTAMP(32, 0);
   tile_gload(tr, src, 0, len, dk, srs);
   if (!first) tile_gload(to, osrc, 0, len, dk, ors);
   const size_t statb = ((size_t)sl.b * h + sl.head) * sl.Lmax;
@@ -590,7 +599,9 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
   // no vector registers beyond the data (the kernel sits at the 256-register limit)
   float* const dsp = dsw + ((size_t)sl.b * h + sl.head) * LK * LK + (blockIdx.y * RMAX + wave * 32);
   const int dso = (4 * half * LK + (lane & 31)) * 4;      // bytes
+  DSTAMP(32, 1);
   for (int qt = 0; qt < nqt; ++qt) {
+    DSTAMP(qt, 0);
     if (!first) {                                                // (rows beyond the slate were loaded as zeros: delta 0)
       const float d = tile_delta(tr, to);
       if ((threadIdx.x & 7) == 0) del_t[(qt & 7) * 32 + ((threadIdx.x & 255) >> 3)] = d;
@@ -601,7 +612,9 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
       lse_t[sl_] = (qr < len) ? lse_n * kLog2e : INFINITY;       // +inf -> P = exp2(-inf) = 0 for rows >= len
       if (DROP) drow_t[sl_] = drop_row_seed(drop, sl.bh, sl.Lmax, qr);
     }
+    DSTAMP(qt, 1);
     lds_only_barrier();
+    DSTAMP(qt, 2);
     if (!active) {
       if (qt + 1 < nqt) {
         tile_gload(tr, src, qt + 1, len, dk, srs);
@@ -614,6 +627,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
     //  scheduler from hoisting the second accumulation's transposed reads above the first)
     f32x16 p = rows_x_fixed<2, PL>(qimg, slot, kh, kl);               // S[query = rowmap(r, half)][key = l31]
     f32x16 ds = rows_x_fixed<2, PL>(doimg, slot, vh, vl);            // dP[query][key] = dO V^T
+    DSTAMP(qt, 3);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qr = slot + rowmap(r, half);
@@ -622,6 +636,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
       ds[r] = pr * (ds[r] * dm - del_t[qr]) * scale;             // dS
       p[r] = pr * dm;                                            // P M
     }
+    DSTAMP(qt, 4);
     {
       const float* const t = dsp + (size_t)(qt * 32) * LK;
 #pragma unroll
@@ -639,15 +654,20 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
       // uses them, the round trip sat between every workgroup-wide barrier and wave 0's arrival at it
       if (threadIdx.x < 32 && (qt + 1) * 32 + (int)threadIdx.x < len) lse_n = lse[statb + (qt + 1) * 32 + threadIdx.x];
     }
+    DSTAMP(qt, 5);
     __builtin_amdgcn_sched_barrier(0);
     cols_x_p<PL>(doimg, slot, p, dvacc);                             // dV^T[d][key] += dO^T[d][query] (P M)[query][key]
+    DSTAMP(qt, 6);
     __builtin_amdgcn_sched_barrier(0);
     cols_x_p<PL>(qimg, slot, ds, dkacc);                             // dK^T[d][key] += Q^T[d][query] dS[query][key]
+    DSTAMP(qt, 7);
     __builtin_amdgcn_sched_barrier(0);
   }
+  DSTAMP(33, 0);
   if (!active) return;
   store_rows(dkout + sl.row0 * drs + (size_t)sl.head * dk, k0, len, dk, drs, dkacc, 1.0f);
   store_rows(dvout + sl.row0 * drs + (size_t)sl.head * dk, k0, len, dk, drs, dvacc, 1.0f);
+  DSTAMP(34, 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -742,6 +762,6 @@ int ltrx_mha_bwd_res_launch(const float* q, const float* k, const float* v, cons
 
 #ifdef LTRX_MHA_STAMP
 extern "C" int ltrx_debug_mha_stamps(unsigned long long* host_dst) {
-  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_mha_stamps), sizeof(unsigned long long) * 8 * 40 * 6) == hipSuccess ? 0 : 1;
+  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_mha_stamps), sizeof(unsigned long long) * 8 * 40 * 8) == hipSuccess ? 0 : 1;
 }
 #endif
