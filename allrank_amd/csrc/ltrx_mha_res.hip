@@ -41,8 +41,8 @@ constexpr int RMAX = 256;                 // rows (items of a slate) held in LDS
 constexpr int DK = 64;                    // padded head dimension
 constexpr int PLANE = RMAX * DK * 2;      // bytes of one bf16 plane
 constexpr size_t RES_STATS = 4 * (size_t)PLANE + 3 * RMAX * sizeof(float);   // LDS bytes of the four planes + per-row statistics
-constexpr int XROW = 64;                  // keys per step of the dQ kernel (floats per row of a wave's dS staging area)
-constexpr size_t DQ_SMEM = 2 * (size_t)PLANE + 8 * 32 * XROW * sizeof(float);
+constexpr int XROW = 64;                  // the dS workspace's row stride is a multiple of this (64 floats = 256 bytes)
+constexpr size_t dq_smem(int nw) { return 2 * (size_t)PLANE + (size_t)nw * 32 * 32 * sizeof(float); }     // dQ kernel: 80 KB with 4 waves (two workgroups per CU)
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
@@ -447,87 +447,86 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
 // ------------------------------------------------------------------------------------------------------------------
 // backward, second kernel: dQ = dS K.  dS comes from the dK/dV kernel's workspace (row-major [query][key] per (slate, head),
 // row stride LK) -- S, P and dP are computed ONCE per backward, in the kernel below.  A wave owns 32 queries and turns its
-// [32 queries][64 keys] fp32 block of dS (one "step") into the MFMA's D layout (lane = query, registers = keys) through a
-// wave-private LDS area: coalesced 256-byte rows in, one row per lane out (16-byte chunk c of row r at position c ^ (r & 15):
-// conflict-free both ways; no barrier is involved in that exchange).  K lives in LDS in chunks of 8 tiles (256 keys, the ring of the
-// other kernels), staged by the 512 threads between two barriers per chunk.
-// What bounds this kernel is memory latency, not the 24 MFMAs of a step (0.3 us): the dS blocks of D steps are in flight in
-// registers at any time (D = 3 when the slate is one chunk -- 4 would be the whole slate but spills; D = 2 and the next chunk of K
-// prefetched otherwise).
+// [32 queries][32 keys] fp32 tile of dS into the MFMA's D layout (lane = query, registers = keys) through a wave-private 4-KB
+// LDS area: coalesced 128-byte rows in, one row per lane out (16-byte chunk c of row r at position c ^ ((r >> 1) & 7):
+// conflict-free both ways; no barrier is involved in that exchange).  K lives in LDS in chunks of 8 tiles (256 keys, the ring of
+// the other kernels), staged by the workgroup between two barriers per chunk.
+// What bounds this kernel is memory latency and phase, not the 12 MFMAs of a tile.  Slates of one chunk (<= 256): FOUR-wave
+// workgroups (NW = 4, 128 queries) with 80 KB of LDS, so that two of them share a CU and one streams while the other is in its
+// prologue or stores its result (one eight-wave workgroup per CU: 171 -> 157 us at the bench shape), the dS tiles of D = 6 steps in
+// flight in registers.  Longer slates: eight-wave workgroups (every workgroup stages ALL the slate's keys, so fewer, larger ones:
+// 456 vs 500 us at 64 x 1024), D = 4 and the next chunk of K prefetched.
 // ------------------------------------------------------------------------------------------------------------------
 struct DsRegs {
-  f32x4 x[8];
+  f32x4 x[4];
 };
-__device__ __forceinline__ void ds_gload(DsRegs& d, const float* __restrict__ rows, int step, int LK) {
+__device__ __forceinline__ void ds_gload(DsRegs& d, const float* __restrict__ rows, int tile, int LK) {
   const int lane = threadIdx.x & 63;
-  const float* p = rows + (size_t)(lane >> 4) * LK + step * XROW + (lane & 15) * 4;
+  const float* p = rows + (size_t)(lane >> 3) * LK + tile * 32 + (lane & 7) * 4;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) d.x[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)(4 * j) * LK));
+  for (int j = 0; j < 4; ++j) d.x[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + (size_t)(8 * j) * LK));
 }
-template <bool PL, int D, bool KPF>
-__global__ void __launch_bounds__(512) ltrx_mha_bwd_dq_res_kernel(const float* __restrict__ k, const float* __restrict__ dsw, int LK, int L,
+template <bool PL, int NW, int D, bool KPF>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) ltrx_mha_bwd_dq_res_kernel(const float* __restrict__ k, const float* __restrict__ dsw, int LK, int L,
                                                                   int h, int dk, int rs, float* __restrict__ dq, int drs,
                                                                   const int* __restrict__ cu, const int* __restrict__ order) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* kimg = smem;
   const Slate sl = which_slate(L, h, cu, order);
   const int lane = threadIdx.x & 63, half = lane >> 5, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31;
-  f32x4* xs = reinterpret_cast<f32x4*>(smem + 2 * PLANE) + wave * (32 * XROW / 4);
+  f32x4* xs = reinterpret_cast<f32x4*>(smem + 2 * PLANE) + wave * (32 * 32 / 4);
   const int len = sl.len;
-  if ((int)(blockIdx.y * RMAX) >= len) return;
+  constexpr int TPT = 32 / NW;                         // tiles of a chunk staged per thread (2048 (row, 8-column) positions per chunk)
+  if ((int)(blockIdx.y * (32 * NW)) >= len) return;
   const float* src = k + sl.row0 * rs + (size_t)sl.head * dk;
-  const int sub = threadIdx.x >> 8;                    // threads 0-255 stage the even tiles of a chunk, 256-511 the odd ones
-  const int q0 = blockIdx.y * RMAX + wave * 32;
+  const int q0 = blockIdx.y * (32 * NW) + wave * 32;
+  const int sub = (NW == 8) ? (int)(threadIdx.x >> 8) : 0;     // NW = 8: threads 0-255 stage the even tiles, 256-511 the odd ones
   const bool active = q0 < len;
   const float* rows = dsw + ((size_t)sl.b * h + sl.head) * LK * LK + (size_t)q0 * LK;
-  const int nkt = (len + 31) / 32, nstep = (nkt + 1) / 2, nchunk = KPF ? (nkt + 7) / 8 : 1;      // (!KPF: launched for L <= 256 only)
-  static_assert(KPF ? (4 % D == 0) : true, "the register slot of step 4 c + s must not depend on c");
-  TileRegs tr[4];
+  const int nkt = (len + 31) / 32, nchunk = KPF ? (nkt + 7) / 8 : 1;      // (!KPF: launched for L <= 256 only)
+  static_assert(KPF ? (8 % D == 0) : true, "the register slot of tile 8 c + s must not depend on c");
+  TileRegs tr[TPT];                                    // thread = one (row, 8 columns) position of TPT of the chunk's 8 tiles
 #pragma unroll
-  for (int j = 0; j < 4; ++j) tile_gload(tr[j], src, 2 * j + sub, len, dk, rs);       // (tiles beyond the slate are zeros)
+  for (int j = 0; j < TPT; ++j) tile_gload(tr[j], src, (8 / TPT) * j + sub, len, dk, rs);       // (tiles beyond the slate are zeros)
   DsRegs dr[D];
   if (active) {
 #pragma unroll
     for (int s = 0; s < D; ++s)
-      if (s < nstep) ds_gload(dr[s], rows, s, LK);
+      if (s < nkt) ds_gload(dr[s], rows, s, LK);
   }
   f32x16 dqacc[2];
   zero2(dqacc);
   for (int c = 0; c < nchunk; ++c) {
     if (c > 0) lds_only_barrier();                     // every wave is done with the previous chunk of K
 #pragma unroll
-    for (int j = 0; j < 4; ++j) tile_sstore<PL>(kimg, 2 * j + sub, tr[j]);
+    for (int j = 0; j < TPT; ++j) tile_sstore<PL>(kimg, (8 / TPT) * j + sub, tr[j]);
     if (KPF && c + 1 < nchunk) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) tile_gload(tr[j], src, 8 * (c + 1) + 2 * j + sub, len, dk, rs);
+      for (int j = 0; j < TPT; ++j) tile_gload(tr[j], src, 8 * (c + 1) + (8 / TPT) * j + sub, len, dk, rs);
     }
     lds_only_barrier();
     if (!active) continue;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int i = 4 * c + s;
-      if (i >= nstep) break;
-      DsRegs& cur = dr[s % D];                         // = (4 c + s) % D
+    for (int s = 0; s < 8; ++s) {
+      const int i = 8 * c + s;
+      if (i >= nkt) break;
+      DsRegs& cur = dr[s % D];                         // = (8 c + s) % D
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int r = (lane >> 4) + 4 * j;
-        xs[r * (XROW / 4) + ((lane & 15) ^ (r & 15))] = cur.x[j];
+      for (int j = 0; j < 4; ++j) {
+        const int r = (lane >> 3) + 8 * j;
+        xs[r * 8 + ((lane & 7) ^ ((r >> 1) & 7))] = cur.x[j];
       }
-      if (i + D < nstep) ds_gload(cur, rows, i + D, LK);
+      if (i + D < nkt) ds_gload(cur, rows, i + D, LK);
+      f32x16 ds;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        if (2 * i + t >= nkt) break;                           // (uniform) the odd tile of the last step
-        f32x16 ds;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 x = xs[l31 * (XROW / 4) + ((8 * t + 2 * g + half) ^ (l31 & 15))];     // keys 32 t + 8 g + 4 half + 0..3
-          ds[4 * g + 0] = x.x;
-          ds[4 * g + 1] = x.y;
-          ds[4 * g + 2] = x.z;
-          ds[4 * g + 3] = x.w;
-        }
-        cols_x_p<PL>(kimg, (2 * s + t) * 32, ds, dqacc);      // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 x = xs[l31 * 8 + ((2 * g + half) ^ ((l31 >> 1) & 7))];     // keys 8 g + 4 half + 0..3 of the tile
+        ds[4 * g + 0] = x.x;
+        ds[4 * g + 1] = x.y;
+        ds[4 * g + 2] = x.z;
+        ds[4 * g + 3] = x.w;
       }
+      cols_x_p<PL>(kimg, s * 32, ds, dqacc);              // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
     }
   }
   if (!active) return;
@@ -723,8 +722,8 @@ int ltrx_mha_bwd_res_launch(const float* q, const float* k, const float* v, cons
                             bool plain, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
   const int arc = ltrx_once_per_device(attr_done, []() {
-    if (res_attr(ltrx_mha_bwd_dq_res_kernel<false, 3, false>, DQ_SMEM) != LTRX_OK || res_attr(ltrx_mha_bwd_dq_res_kernel<true, 3, false>, DQ_SMEM) != LTRX_OK ||
-        res_attr(ltrx_mha_bwd_dq_res_kernel<false, 2, true>, DQ_SMEM) != LTRX_OK || res_attr(ltrx_mha_bwd_dq_res_kernel<true, 2, true>, DQ_SMEM) != LTRX_OK ||
+    if (res_attr(ltrx_mha_bwd_dq_res_kernel<false, 4, 6, false>, dq_smem(4)) != LTRX_OK || res_attr(ltrx_mha_bwd_dq_res_kernel<true, 4, 6, false>, dq_smem(4)) != LTRX_OK ||
+        res_attr(ltrx_mha_bwd_dq_res_kernel<false, 8, 4, true>, dq_smem(8)) != LTRX_OK || res_attr(ltrx_mha_bwd_dq_res_kernel<true, 8, 4, true>, dq_smem(8)) != LTRX_OK ||
         res_attr(ltrx_mha_bwd_dkdv_res_kernel<false, false>, RES_SMEM) != LTRX_OK ||
         res_attr(ltrx_mha_bwd_dkdv_res_kernel<true, false>, RES_SMEM) != LTRX_OK ||
         res_attr(ltrx_mha_bwd_dkdv_res_kernel<false, true>, RES_SMEM) != LTRX_OK ||
@@ -748,12 +747,13 @@ int ltrx_mha_bwd_res_launch(const float* q, const float* k, const float* v, cons
   }
 #undef LTRX_DKDV
   LTRX_LAUNCH_CHECK();
-#define LTRX_DQ(P_, D_, K_)                                                                                                       \
-  hipLaunchKernelGGL((ltrx_mha_bwd_dq_res_kernel<P_, D_, K_>), grid, dim3(512), DQ_SMEM, s, k, dsw, LK, L, h, dk, rs, dq, drs, cu, order)
+#define LTRX_DQ(P_, NW_, D_, K_)                                                                                                   \
+  hipLaunchKernelGGL((ltrx_mha_bwd_dq_res_kernel<P_, NW_, D_, K_>), dim3(B * h, (L + 32 * NW_ - 1) / (32 * NW_)), dim3(64 * NW_),      \
+                     dq_smem(NW_), s, k, dsw, LK, L, h, dk, rs, dq, drs, cu, order)
   if (grid.y == 1) {
-    if (plain) LTRX_DQ(true, 3, false); else LTRX_DQ(false, 3, false);
+    if (plain) LTRX_DQ(true, 4, 6, false); else LTRX_DQ(false, 4, 6, false);
   } else {
-    if (plain) LTRX_DQ(true, 2, true); else LTRX_DQ(false, 2, true);
+    if (plain) LTRX_DQ(true, 8, 4, true); else LTRX_DQ(false, 8, 4, true);
   }
 #undef LTRX_DQ
   LTRX_LAUNCH_CHECK();
