@@ -123,6 +123,43 @@ __device__ __forceinline__ void load_fixed(bf16x8 (&fh)[4], bf16x8 (&fl)[4], con
   }
 }
 
+// the same fragments through a wave-private 8-KB LDS scratch: 16 lanes per row (4 rows x 256 contiguous bytes per instruction
+// instead of 64 different 128-byte lines) in, one row per lane out (16-byte chunk c of row r at position c ^ (r & 15)).  The
+// per-lane form above costs the texture-address unit one line lookup per LANE: 2 x 8 instructions x 64 lookups per wave and
+// tensor, all eight waves of a workgroup at once, before the first tile can start.
+struct FixedRegs {
+  f32x4 x[8];
+};
+__device__ __forceinline__ void fixed_gload(FixedRegs& f, const float* __restrict__ base, int row0, int nrows, int dk, size_t rs) {
+  const int lane = threadIdx.x & 63, c16 = lane & 15;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = (lane >> 4) + 4 * j;
+    const bool ok = (row0 + r < nrows) && (4 * c16 < dk);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)(ok ? row0 + r : 0) * rs + (ok ? 4 * c16 : 0));    // (row 0 exists)
+    f.x[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+__device__ __forceinline__ void fixed_finish(bf16x8 (&fh)[4], bf16x8 (&fl)[4], const FixedRegs& f, f32x4* scratch) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5, c16 = lane & 15;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = (lane >> 4) + 4 * j;
+    scratch[r * 16 + (c16 ^ (r & 15))] = f.x[j];
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const f32x4 a = scratch[l31 * 16 + ((4 * ks + 2 * half) ^ (l31 & 15))];
+    const f32x4 b = scratch[l31 * 16 + ((4 * ks + 2 * half + 1) ^ (l31 & 15))];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      fh[ks][e] = (__bf16)v[e];
+      fl[ks][e] = (__bf16)(v[e] - (float)fh[ks][e]);
+    }
+  }
+}
+
 #define LTRX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 // barrier that orders LDS only: __syncthreads() also drains vmcnt(0), i.e. it would wait at every tile for the global loads of
 // the NEXT tile that were issued just before it (and for the touch_line requests)
@@ -367,7 +404,11 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
   const int q0 = blockIdx.y * RMAX + wave * 32;
   const bool active = q0 < len;                 // (inactive waves still help staging and take every barrier)
   bf16x8 qh[4], ql[4];
-  load_fixed(qh, ql, qb, q0, len, dk, rs);
+  {   // (scratch: this wave's 8 KB of ring slots 4-7 of the image planes, first written by tile 4 -- four barriers from here)
+    FixedRegs fq;
+    fixed_gload(fq, qb, q0, len, dk, rs);
+    fixed_finish(qh, ql, fq, reinterpret_cast<f32x4*>(smem + (size_t)(wave >> 1) * PLANE + PLANE / 2 + (size_t)(wave & 1) * 8192));
+  }
   f32x16 oacc[2];
   zero2(oacc);
   float m = -INFINITY, l = 0.f;
@@ -583,11 +624,20 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
   if ((int)(blockIdx.y * RMAX) >= len) return;
   const int k0 = blockIdx.y * RMAX + wave * 32;
   bf16x8 kh[4], kl[4], vh[4], vl[4];
-  load_fixed(kh, kl, k + sl.row0 * rs + (size_t)sl.head * dk, k0, len, dk, rs);
-  load_fixed(vh, vl, v + sl.row0 * rs + (size_t)sl.head * dk, k0, len, dk, rs);
   const bool active = k0 < len;
   const int key = k0 + (lane & 31);
-  const bool key_masked = (key >= len) || (kpm && kpm[sl.row0 + (key < len ? key : 0)] != 0);
+  bool key_masked;
+  {   // every load of the prologue is issued before the first wait (K, V, the mask byte: one memory round trip, not three)
+    FixedRegs fk, fv;
+    fixed_gload(fk, k + sl.row0 * rs + (size_t)sl.head * dk, k0, len, dk, rs);
+    fixed_gload(fv, v + sl.row0 * rs + (size_t)sl.head * dk, k0, len, dk, rs);
+    const uint8_t km = kpm ? kpm[sl.row0 + (key < len ? key : 0)] : (uint8_t)0;
+    // scratch: this wave's 8 KB of ring slots 4-7 of the image planes (first written by tile 4, four barriers from here)
+    f32x4* scratch = reinterpret_cast<f32x4*>(smem + (size_t)(wave >> 1) * PLANE + PLANE / 2 + (size_t)(wave & 1) * 8192);
+    fixed_finish(kh, kl, fk, scratch);
+    fixed_finish(vh, vl, fv, scratch);
+    key_masked = (key >= len) || km != 0;
+  }
   const float kbias = key_masked ? -INFINITY : 0.f;
   const float sl2 = scale * kLog2e;
   f32x16 dkacc[2], dvacc[2];
