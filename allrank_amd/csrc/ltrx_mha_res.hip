@@ -103,30 +103,11 @@ __device__ __forceinline__ void tile_sstore(unsigned char* img, int tile, const 
   if (!PL) *reinterpret_cast<bf16x8*>(img + PLANE + o) = l;
 }
 
-// the wave's fixed operand FIXED[row0 + l31][16 ks + 8 half + (0..7)], pre-split (registers)
-__device__ __forceinline__ void load_fixed(bf16x8 (&fh)[4], bf16x8 (&fl)[4], const float* __restrict__ base, int row0, int nrows,
-                                           int dk, size_t rs) {
-  const int row = row0 + (threadIdx.x & 31);
-  const int half = (threadIdx.x & 63) >> 5;
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int c = 16 * ks + 8 * half;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (row < nrows && c < dk) a = *reinterpret_cast<const float4*>(base + (size_t)row * rs + c);
-    if (row < nrows && c + 4 < dk) b = *reinterpret_cast<const float4*>(base + (size_t)row * rs + c + 4);
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      fh[ks][e] = (__bf16)x[e];
-      fl[ks][e] = (__bf16)(x[e] - (float)fh[ks][e]);
-    }
-  }
-}
-
-// the same fragments through a wave-private 8-KB LDS scratch: 16 lanes per row (4 rows x 256 contiguous bytes per instruction
-// instead of 64 different 128-byte lines) in, one row per lane out (16-byte chunk c of row r at position c ^ (r & 15)).  The
-// per-lane form above costs the texture-address unit one line lookup per LANE: 2 x 8 instructions x 64 lookups per wave and
-// tensor, all eight waves of a workgroup at once, before the first tile can start.
+// the wave's fixed operand FIXED[row0 + l31][16 ks + 8 half + (0..7)], pre-split (registers).  Loaded 16 lanes per row (4 rows x
+// 256 contiguous bytes per instruction) and turned into one-row-per-lane fragments through a wave-private 8-KB LDS scratch
+// (16-byte chunk c of row r at position c ^ (r & 15)).  Read straight from memory in the fragment layout -- every lane its own row,
+// 2 x 4 sixteen-byte pieces -- each instruction costs the texture-address unit one line lookup per LANE, all eight waves of a
+// workgroup at once, before the first tile can start (round 3: forward 193 -> 185 us, dK/dV prologue 17.9 k -> 12.9 k cycles).
 struct FixedRegs {
   f32x4 x[8];
 };
