@@ -270,22 +270,33 @@ __device__ __forceinline__ void cols_x_p(const unsigned char* img, int tile_row0
   mma_cols<PL>(f, p, out);
 }
 
-// lane owns output row row0 + l31; register 4g + e of out[ct] is column 32 ct + 8 g + 4 half + e
+// lane owns output row row0 + l31; register 4g + e of out[ct] is column 32 ct + 8 g + 4 half + e.  Written through a wave-private
+// 4-KB LDS scratch, one [32 rows][32 columns] half at a time, so that a store instruction covers 8 rows x 128 contiguous bytes
+// instead of 64 lanes x 16 bytes in 32 different rows (the texture-address unit pays per line: 64 instead of 512 line writes per
+// wave and tensor; round 3).  Scratch layout = the dS exchange of the dQ kernel: chunk c of row r at c ^ ((r >> 1) & 7).
 __device__ __forceinline__ void store_rows(float* __restrict__ base, int row0, int nrows, int dk, size_t rs, const f32x16 (&out)[2],
-                                           float scale) {
-  const int lane = threadIdx.x & 63;
-  const int row = row0 + (lane & 31);
-  if (row >= nrows) return;
-  float* rp = base + (size_t)row * rs;
+                                           float scale, f32x4* scratch) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
+  for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int c = 32 * ct + 8 * g + 4 * (lane >> 5);
-      if (c < dk)
-        *reinterpret_cast<float4*>(rp + c) = make_float4(out[ct][4 * g + 0] * scale, out[ct][4 * g + 1] * scale,
-                                                         out[ct][4 * g + 2] * scale, out[ct][4 * g + 3] * scale);
+    for (int g = 0; g < 4; ++g)
+      scratch[l31 * 8 + ((2 * g + half) ^ ((l31 >> 1) & 7))] =
+          f32x4{out[ct][4 * g + 0] * scale, out[ct][4 * g + 1] * scale, out[ct][4 * g + 2] * scale, out[ct][4 * g + 3] * scale};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = (lane >> 3) + 8 * j, c = 32 * ct + 4 * (lane & 7);
+      const f32x4 v = scratch[r * 8 + ((lane & 7) ^ ((r >> 1) & 7))];
+      if (row0 + r < nrows && c < dk) *reinterpret_cast<f32x4*>(base + (size_t)(row0 + r) * rs + c) = v;
     }
+  }
+}
+// a wave-private 4-KB scratch inside the image planes once the wave has left its tile loop: only the LAST tile's ring slot can
+// still be read by a slower wave (every earlier tile lies behind a barrier this wave has passed), so the half of planes 0 / 1
+// (16 KB each = 8 waves x 4 KB) that does not hold that slot is free
+__device__ __forceinline__ f32x4* end_scratch(unsigned char* smem, int last_tile, int wave) {
+  const size_t half_off = (((last_tile & 7) >= 4) ? 0 : PLANE / 2);
+  return reinterpret_cast<f32x4*>(smem + (size_t)(wave >> 2) * PLANE + half_off + (size_t)(wave & 3) * 4096);
 }
 
 __device__ __forceinline__ void zero2(f32x16 (&o)[2]) {
@@ -459,7 +470,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
   }
   const float lt = l + __shfl_xor(l, 32, 64);
   const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
-  store_rows(o + sl.row0 * ors + (size_t)sl.head * dk, q0, len, dk, ors, oacc, inv);
+  store_rows(o + sl.row0 * ors + (size_t)sl.head * dk, q0, len, dk, ors, oacc, inv, end_scratch(smem, nkt - 1, wave));
   const int qrow = q0 + (lane & 31);
   if (half == 0 && qrow < len) lse[((size_t)sl.b * h + sl.head) * sl.Lmax + qrow] = (lt > 0.f) ? (m + log2f(lt)) * kLn2 : 0.f;
   STAMP(34, 0);
@@ -552,7 +563,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
     }
   }
   if (!active) return;
-  store_rows(dq + sl.row0 * drs + (size_t)sl.head * dk, q0, len, dk, drs, dqacc, 1.0f);
+  store_rows(dq + sl.row0 * drs + (size_t)sl.head * dk, q0, len, dk, drs, dqacc, 1.0f, xs);      // (xs: this wave's dS exchange area)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -695,8 +706,9 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
   }
   DSTAMP(33, 0);
   if (!active) return;
-  store_rows(dkout + sl.row0 * drs + (size_t)sl.head * dk, k0, len, dk, drs, dkacc, 1.0f);
-  store_rows(dvout + sl.row0 * drs + (size_t)sl.head * dk, k0, len, dk, drs, dvacc, 1.0f);
+  f32x4* const es = end_scratch(smem, nqt - 1, wave);
+  store_rows(dkout + sl.row0 * drs + (size_t)sl.head * dk, k0, len, dk, drs, dkacc, 1.0f, es);
+  store_rows(dvout + sl.row0 * drs + (size_t)sl.head * dk, k0, len, dk, drs, dvacc, 1.0f, es);
   DSTAMP(34, 0);
 }
 
