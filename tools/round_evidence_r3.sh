@@ -1,4 +1,4 @@
-# round-3 evidence run: full -m gpu suite, smoke, default bench line, kernel stats per BASELINE workload, PMC of GEMM / attention kernels, bench set
+# usage: gpurun -- "bash tools/round_evidence_r3.sh" -- round-3 evidence run: full -m gpu suite, smoke, default bench line, kernel stats per BASELINE workload, PMC of GEMM / attention kernels, bench set (profiles/r03_* come from its gpurun_out/ files)
 cd $GRAFT_REPO_ROOT
 rm -f gpurun_out/parity_benchdims_*.json
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/r3f_pytest.log 2>&1
