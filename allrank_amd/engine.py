@@ -58,7 +58,7 @@ class Trainer(object):
 class FusedTrainer(object):
     """One training step of train_utils.py:18-29 as a fixed launch sequence on persistent HBM buffers:
 
-        FC -> N x [LN -> QKV GEMM -> fused attention -> out GEMM -> (+res, LN) -> FFN GEMMs(+ReLU)] -> (+res, LN)
+        FC -> N x [LN -> QKV GEMM -> fused attention -> out GEMM(+res) -> LN -> FFN GEMMs(+ReLU, +res)] -> LN
            -> score head -> fused listwise loss (value + d/dscores) -> hand-written backward -> [RCCL all-reduce]
            -> fused Adam over ONE flat parameter buffer.
 
@@ -73,7 +73,8 @@ class FusedTrainer(object):
       ~100 launches of 10-300 us, so launch latency matters.
     * dropout (every shipped transformer config trains with 0.1-0.4) is counter-based: a mask element is a hash of
       (site seed ^ per-step device word, element index), generated inside the producing kernel's epilogue (GEMM bias+
-      ReLU+dropout, the residual add of the LayerNorm kernel, the attention probabilities) and REGENERATED in the backward
+      ReLU+dropout, the residual sum in the epilogue of the projection that closes a sublayer, the attention probabilities)
+      and REGENERATED in the backward
       -- no mask tensors, and a replayed hipGraph draws fresh masks because the step word lives in device memory.
     Supported model family: FCModel (optional input_norm = nn.LayerNorm, activation None / ReLU, or Sigmoid / Tanh without FC
     dropout) -> optional encoder with
