@@ -301,25 +301,28 @@ __global__ void __launch_bounds__(256) ltrx_score_head_bwd_vec_kernel(const floa
   for (int c = threadIdx.x; c <= D; c += blockDim.x) pa[c] = (lds[0][c] + lds[1][c]) + (lds[2][c] + lds[3][c]);
 }
 
-// dw[c] = sum_k partial[k][c] (c < D), db = column D; 64 columns x 4 row groups per workgroup, fixed combine order
-__global__ void __launch_bounds__(256) ltrx_score_head_reduce_kernel(const float* __restrict__ partial, int nblk, int D,
-                                                                     float* __restrict__ dw, float* __restrict__ db) {
-  __shared__ float sh[4][64];
+// dw[c] = sum_k partial[k][c] (c < D), db = column D; 64 columns x 16 row groups (waves) per workgroup, fixed combine order
+// (16 waves: with 4 the 512 partial rows were 128 dependent-latency iterations per wave, 21 us for 1 MB)
+__global__ void __launch_bounds__(1024) ltrx_score_head_reduce_kernel(const float* __restrict__ partial, int nblk, int D,
+                                                                      float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float sh[16][64];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   float a0 = 0.f, a1 = 0.f;
   if (c <= D) {
     int k = rg;
-    for (; k + 4 < nblk; k += 8) {
+    for (; k + 16 < nblk; k += 32) {
       a0 += partial[(size_t)k * (D + 1) + c];
-      a1 += partial[(size_t)(k + 4) * (D + 1) + c];
+      a1 += partial[(size_t)(k + 16) * (D + 1) + c];
     }
     if (k < nblk) a0 += partial[(size_t)k * (D + 1) + c];
   }
   sh[rg][cl] = a0 + a1;
   __syncthreads();
   if (rg == 0 && c <= D) {
-    const float a = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) a += sh[w][cl];
     if (c < D) dw[c] = a; else db[0] = a;
   }
 }
@@ -361,7 +364,7 @@ extern "C" int ltrx_score_head_bwd(const float* dscores, const float* x, const f
     hipLaunchKernelGGL(ltrx_score_head_bwd_kernel, dim3(g), dim3(256), (size_t)(4 * D + 4) * sizeof(float), s, dscores, x, w, M,
                        D, dx, (float*)ws);
   LTRX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ltrx_score_head_reduce_kernel, dim3((D + 1 + 63) / 64), dim3(256), 0, s, (const float*)ws, g, D, dw, db);
+  hipLaunchKernelGGL(ltrx_score_head_reduce_kernel, dim3((D + 1 + 63) / 64), dim3(1024), 0, s, (const float*)ws, g, D, dw, db);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }
