@@ -690,15 +690,49 @@ __global__ void __launch_bounds__(256) ltrx_gemm_slab_reduce_kernel(const float*
                                                                     const float* __restrict__ slabs2, int splits2, size_t n2,
                                                                     float* __restrict__ C2) {
   if ((int)blockIdx.x >= main_blocks) {
-    const size_t stride = (size_t)(gridDim.x - main_blocks) * blockDim.x;
-    for (size_t i = (size_t)(blockIdx.x - main_blocks) * blockDim.x + threadIdx.x; i < n2; i += stride) {
-      float a = 0.f;
-      for (int sidx = 0; sidx < splits2; ++sidx) a += slabs2[(size_t)sidx * n2 + i];
-      C2[i] = a;
+    // bias slabs: 64 columns per workgroup, its 4 waves take every 4th slab with 8 loads in flight, partials combined through LDS
+    // in a fixed order (one thread per column looping over all slabs was up to 128 dependent-latency iterations in a handful of
+    // workgroups: the critical path of this launch)
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const size_t c = (size_t)(blockIdx.x - main_blocks) * 64 + cl;
+    float a = 0.f;
+    if (c < n2) {
+      int sidx = rg;
+      for (; sidx + 28 < splits2; sidx += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = slabs2[(size_t)(sidx + 4 * u) * n2 + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+      }
+      for (; sidx < splits2; sidx += 4) a += slabs2[(size_t)sidx * n2 + c];
     }
+    sh[rg][cl] = a;
+    __syncthreads();
+    if (rg == 0 && c < n2) C2[c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
     return;
   }
   const size_t stride = (size_t)main_blocks * blockDim.x;
+  if ((n & 3) == 0 && (((uintptr_t)slabs | (uintptr_t)C) & 15) == 0) {
+    // 16-byte accesses, eight slabs in flight per thread; the additions keep the slab order (same bits as the scalar loop)
+    const size_t n4 = n >> 2;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(slabs);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      int sidx = 0;
+      for (; sidx + 8 <= splits; sidx += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(s4 + (size_t)(sidx + u) * n4 + i);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += v[u];
+      }
+      for (; sidx < splits; ++sidx) a += __builtin_nontemporal_load(s4 + (size_t)sidx * n4 + i);
+      reinterpret_cast<f32x4*>(C)[i] = a;
+    }
+    return;
+  }
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float a = 0.f;
     for (int sidx = 0; sidx < splits; ++sidx) a += slabs[(size_t)sidx * n + i];
@@ -708,9 +742,9 @@ __global__ void __launch_bounds__(256) ltrx_gemm_slab_reduce_kernel(const float*
 
 static void launch_slab_reduce(const float* slabs, int splits, size_t n, float* C, const float* bslabs, int bsplits, size_t nb,
                                float* bias_out, hipStream_t s) {
-  size_t blocks = (n + 255) / 256;
+  size_t blocks = ((n & 3) == 0 ? n / 4 : n) / 256 + 1;
   if (blocks > 2048) blocks = 2048;
-  const size_t bblocks = bias_out ? (nb + 255) / 256 : 0;
+  const size_t bblocks = bias_out ? (nb + 63) / 64 : 0;
   hipLaunchKernelGGL(ltrx_gemm_slab_reduce_kernel, dim3((unsigned)(blocks + bblocks)), dim3(256), 0, s, slabs, splits, n, C,
                      (int)blocks, bslabs, bsplits, nb, bias_out);
 }
