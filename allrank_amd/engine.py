@@ -86,7 +86,7 @@ class FusedTrainer(object):
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
                  optimizer="Adam", weight_decay=0.0, momentum=0.0, nesterov=False,
                  use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None, compact=False,
-                 weight_images=True):
+                 weight_images=True, fc_step=True):
         """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
         products), "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs), or "bf16" -- the THROUGHPUT mode: one bf16
         product per contraction in the dense projections AND in attention (fp32 storage, accumulation, LayerNorm, softmax,
@@ -102,7 +102,11 @@ class FusedTrainer(object):
         optimizer: "Adam" (betas, eps, weight_decay = L2 term), "AdamW" (decoupled weight decay) or "SGD" (momentum, nesterov,
         weight_decay; dampening 0) -- torch.optim's update rules (main.py:82) in one flat-buffer kernel.
         weight_images=False: the GEMMs split the weight operand on the fly in every tile instead of reading the per-step pre-split
-        images (same results bit for bit; kept for A/B measurements)."""
+        images (same results bit for bit; kept for A/B measurements).
+        fc_step=True: a model that is FCModel([H]) -> OutputLayer(H, 1) with the listNet loss (BASELINE configs[1]) trains through
+        the slate-resident step of ltrx_fc_listnet_step -- forward, loss, backward and Adam in two launches that read the batch
+        from HBM once, straight from the caller's tensors (no staging copy, no hipGraph needed); False keeps the GEMM launch
+        sequence for A/B runs.  ``self.fcstep`` tells which one is active."""
         import torch.nn as nn
         from . import _lib as LB
         from .losses import FusedLoss
@@ -381,6 +385,26 @@ class FusedTrainer(object):
         self._graph_pool = None
         self._cap_stream = None
         self._warm = 0
+        self._wver = [p._version for p in self._order]
+        self._images_stale = False
+        self.y_cur = self.y_in                                # labels of the last step() (the caller's tensor in the fcstep path)
+        # ---- slate-resident FC + ListNet step (csrc/ltrx_fcstep.hip): eligibility ----
+        self.keep_fc_out = False                              # tests: also write the FC activations to fc_out[0]
+        self.fcstep = bool(
+            fc_step and self.N == 0 and self.nfc == 1 and self.in_norm is None and self.pos is None and self.fc_act in (0, 1)
+            and self.p_fc == 0.0 and self.n_out == 1 and self.out_act == 0 and loss_name == "listNet" and not compact
+            and gemm == "split_bf16" and optimizer in ("Adam", "AdamW")
+            and self.lib.ltrx_fc_listnet_supported(L, self.fc_sizes[0], self.fc_sizes[1]))
+        if self.fcstep:
+            F_, H_ = self.fc_sizes[0], self.fc_sizes[1]
+            H4 = (H_ + 3) // 4 * 4
+            offs_fc = (0, H_ * F_, H_ * F_ + H4, H_ * F_ + 2 * H4)
+            assert tuple(offs) == offs_fc and self.nflat == offs_fc[3] + 4, (offs, self.nflat)
+            self._fc_ws = torch.empty(max(self.lib.ltrx_fc_listnet_workspace_bytes(B, L, F_, H_, self.nflat), 64), dtype=torch.uint8, device=dev)
+            P = LB.ptr
+            self._fc_a = (B, L, F_, H_, self.fc_act, P(self.flat_p), offs_fc[0], offs_fc[1], offs_fc[2], offs_fc[3], self.nflat,
+                          float(self.loss.eps), float(self.loss.pad))
+            self._fc_b = (P(self.scores_raw), P(self.loss.grad))
 
     # ---- thin launch helpers -----------------------------------------------------------------------------------
     def _st(self):
@@ -445,6 +469,18 @@ class FusedTrainer(object):
                                                         self._ttiles, self._st()), "transpose_batch")
             self.LB.check(self.lib.ltrx_split_image(P(self.flat_t), P(self.flat_ti), self.flat_t.numel(), self._st()), "split_image(W^T)")
         self.LB.check(self.lib.ltrx_split_image(P(self.flat_p), P(self.flat_pi), self.nflat, self._st()), "split_image(W)")
+
+    def _sync_weights(self):
+        """The forward / input-gradient GEMMs read the pre-split images and transposed copies of the weights, which the step
+        refreshes after its own optimizer update.  A weight change made from OUTSIDE (``model.load_state_dict(ckpt)``, a manual
+        re-initialisation, an external optimizer on the aliased parameters) bumps the parameters' autograd version counters --
+        kernel writes through raw pointers do not -- so a changed counter (or a step of the slate-resident FC path, which never
+        touches the images) means: refresh before the next forward."""
+        ver = [p._version for p in self._order]
+        if ver != self._wver or self._images_stale:
+            self._refresh_transposes()
+            self._wver = [p._version for p in self._order]
+            self._images_stale = False
 
     def _img(self, w):
         """address of the pre-split image of a weight view (inside flat_p) or of a transposed copy (inside flat_t); None otherwise"""
@@ -799,6 +835,10 @@ class FusedTrainer(object):
     def step(self, xb, yb, indices=None, global_batch=None, lengths=None):
         """copy the batch into the static input buffers and run (or replay) the step; returns the device loss [1]."""
         self._reattach()
+        if self.fcstep:
+            return self._fc_step(xb, yb, global_batch)
+        self._sync_weights()
+        self.y_cur = self.y_in
         if self.loss.name == "listMLE" and self.shuffle_ties:
             # listMLE.py:17: a fresh random column order per call breaks ties among equal labels at random; the
             # permutation lives in a persistent device buffer, so the refresh is safe under hipGraph replay
@@ -847,6 +887,38 @@ class FusedTrainer(object):
             if after is not None:
                 after()
         return self._graph_loss
+
+    def _fc_step(self, xb, yb, global_batch):
+        """the slate-resident step (ltrx_fc_listnet_step): reads the caller's batch in place -- x once -- and leaves scores in
+        ``self.scores``, d loss / d scores in ``self.loss.grad``, gradients in the flat buffer, the loss in ``self.loss.loss``.  One
+        GPU without clipping: the reducing launch also applies Adam (two launches per step); sharded or clipped: gradients only,
+        then the all-reduce / clip and the flat-buffer Adam as in the general step."""
+        LB, P = self.LB, self.LB.ptr
+        xb = xb.reshape(self.M, -1)
+        if xb.dtype != torch.float32 or not xb.is_contiguous() or (xb.data_ptr() & 15):
+            xb = xb.float().contiguous().clone()
+        yb = yb.reshape(self.B, self.L)
+        if yb.dtype != torch.float32 or not yb.is_contiguous():
+            yb = yb.float().contiguous()
+        LB.require_device(xb, yb)
+        self.y_cur = yb
+        div = float(global_batch if global_batch is not None else self.B * self.world)
+        fused_adam = self.world == 1 and not self.clip
+        hid = P(self.fc_out[0]) if self.keep_fc_out else None
+        if fused_adam:
+            opt = (P(self.flat_m), P(self.flat_v), P(self.step_count), float(self.lr), float(self.betas[0]), float(self.betas[1]),
+                   float(self.eps), self.weight_decay, 1 if self.optimizer == "AdamW" else 0)
+        else:
+            opt = (None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0)
+        LB.check(self.lib.ltrx_fc_listnet_step(P(xb), P(yb), *self._fc_a, div, *self._fc_b, hid, P(self.loss.loss), P(self.flat_g), *opt,
+                                               P(self._fc_ws), self._st()), "fc_listnet_step")
+        if not fused_adam:
+            if self.world > 1 and self.comm_enabled:
+                import torch.distributed as dist
+                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+            self._adam()
+        self._images_stale = True                             # (score()'s GEMM forward reads the weight images: refresh them first)
+        return self.loss.loss
 
     def _eager(self):
         with sharding.shard_context(int(self._divisor), self.group) if self.world > 1 else _null():
@@ -910,7 +982,9 @@ class FusedTrainer(object):
         less than half the rate.  ``yb`` only provides the padding mask; the batch must have the trainer's [B, L] shape (top up
         a short last batch with all-padded slates).  Returns the trainer's score buffer [B, L] (valid until the next call)."""
         self._reattach()
+        self._sync_weights()
         self.y_in.copy_(yb)
+        self.y_cur = self.y_in
         self.mask.copy_(yb == PADDED_Y_VALUE)
         if self.compact:
             self._pack(xb.reshape(self.M, -1).contiguous(), lengths)
@@ -1011,7 +1085,7 @@ def fit_device(model, loss_name, loss_args, train_ds, val_ds, epochs, batch_size
             tot += loss.detach().view(1) * real
             nb += real
             for name in tm:                                   # metrics of the training forward (scores of this very step)
-                v = getattr(EMx, name)(trainer.scores[:real], trainer.y_in[:real], ats=metrics[name]).sum(0)
+                v = getattr(EMx, name)(trainer.scores[:real], trainer.y_cur[:real], ats=metrics[name]).sum(0)
                 tm[name] = v if tm[name] is None else tm[name] + v
         train_loss = float(tot.item()) / max(nb, 1)
         val = evaluate(model, val_ds, metrics)

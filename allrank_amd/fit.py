@@ -277,7 +277,7 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
             if fused:
                 xs, ys, ids = _pad_batch(xb, yb, idx, trainer.B)
                 loss = trainer.step(xs, ys, ids, global_batch=real_glob)
-                scores, labels = trainer.scores[:real], trainer.y_in[:real]
+                scores, labels = trainer.scores[:real], trainer.y_cur[:real]
             else:
                 loss = trainer.step(xb, yb, idx, global_batch=real_glob)
                 scores, labels = trainer.last_scores, yb

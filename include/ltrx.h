@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTRX_VERSION 111 /* 0.1.1: mode / tile / path are call arguments; attention backward workspace depends on (d_k, mode) (round 3) */
+#define LTRX_VERSION 120 /* 0.2.0: slate-resident FC + ListNet step (round 4) */
 
 #define LTRX_OK 0
 #define LTRX_EINVAL (-1)
@@ -339,6 +339,30 @@ int ltrx_posenc_table_bwd(const float* dx, const int64_t* indices, const uint8_t
 int ltrx_scale_inplace(float* x, size_t n, float s, ltrx_stream_t stream);
 int ltrx_out_act_fwd(const float* z, size_t n, int kind, float* y, ltrx_stream_t stream);
 int ltrx_out_act_bwd(const float* dy, const float* y, size_t n, int kind, float* dz, ltrx_stream_t stream);
+
+/* Slate-resident training step of an FCModel([H]) -> OutputLayer(H, 1) -> listNet model (BASELINE configs[1]): forward, loss,
+ * backward and -- optionally -- the Adam update in TWO launches that read the features from HBM once
+ * (allrank_amd/csrc/ltrx_fcstep.hip).  Replaces, for this model family, the call sequence of loss_batch
+ * (allrank/training/train_utils.py:18-29): FCModel.forward (allrank/models/model.py:35-44, one Linear + activation `act`:
+ * 0 = None, 1 = ReLU, no dropout, no input_norm), OutputLayer.forward (model.py:111-117, d_output 1, no activation),
+ * listNet (allrank/models/losses/listNet.py:8-30), autograd's backward of the three, and torch.optim.Adam / AdamW.step.
+ *   x[B,L,F], y[B,L] (pad_value marks padded slots); `params` = ONE flat fp32 buffer holding W1[H,F] at off_w1 (= 0), b1[H] at
+ *   off_b1, w_out[H] at off_wout, b_out[1] at off_bout: adjacent segments, each padded to a multiple of 4 floats, nflat in total;
+ *   `grads` has the same layout and receives d loss / d params; scores[B,L] = model.score(x); dscores (optional) = d loss / d scores;
+ *   hidden_out (optional, tests) = the FC activations [B,L,H]; loss_out[1] = sum of the per-slate losses / batch_divisor.
+ *   exp_avg != NULL: the Adam update is applied to `params` in the reducing launch (step_count: device float, bumped by the
+ *   call; decoupled != 0: AdamW) -- same update rule as ltrx_adam_step; NULL: gradients only (sharded runs all-reduce them first).
+ * Arithmetic: the two contractions (x W1^T and x^T dh) are three bf16 MFMA products per fp32 product with fp32 accumulation, as
+ * in ltrx_gemm_nt / ltrx_gemm_tn; everything else fp32.  Partial gradients are summed in a fixed order (deterministic).
+ * ltrx_fc_listnet_supported: 1 when (L, F, H) fit the kernel (L <= 256, F <= 144 and F % 4 == 0, H <= 96), else 0 and the step
+ * call returns LTRX_EUNSUPPORTED (the caller then runs the GEMM launch sequence). */
+int ltrx_fc_listnet_supported(int L, int F, int H);
+size_t ltrx_fc_listnet_workspace_bytes(int B, int L, int F, int H, size_t nflat);
+int ltrx_fc_listnet_step(const float* x, const float* y, int B, int L, int F, int H, int act, float* params, size_t off_w1,
+                         size_t off_b1, size_t off_wout, size_t off_bout, size_t nflat, float eps, float pad_value,
+                         float batch_divisor, float* scores, float* dscores, float* hidden_out, float* loss_out, float* grads,
+                         float* exp_avg, float* exp_avg_sq, float* step_count, float lr, float beta1, float beta2, float adam_eps,
+                         float weight_decay, int decoupled, void* ws, ltrx_stream_t stream);
 
 /* On-device batch assembly for a CSR training set resident in HBM (allrank_amd/csrc/ltrx_data.hip):
  *   ltrx_fixlength_positions: FixLength (dataset_loading.py:32-93) for the B slates `slates` of a batch: positions[b][l] = the
