@@ -47,9 +47,26 @@ constexpr int FC_MAXHB = FC_MAXH / 16;
 constexpr int FC_NKS = 5;                             // K-steps of 32 features (forward)
 constexpr int FC_NFB = 9;                             // 16-feature blocks (weight gradient)
 constexpr int FC_NLD = 12;                            // float4 loads per thread and slate at the largest shape (768 threads)
+#ifndef LTRX_FC_NPRE
+#define LTRX_FC_NPRE 6
+#endif
+constexpr int FC_NPRE = LTRX_FC_NPRE;                 // ... of which this many are requested one slate ahead
 constexpr size_t FC_SMEM = 2 * (size_t)FC_PLANE + (size_t)(FC_MAXHB + 3) * FC_ROWS * sizeof(float);
 
 #define FC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+#ifdef LTRX_FC_STAMP        // lab builds only (tools/lab/lib_variant.sh): cycle stamps of workgroup LTRX_FC_STAMP, [wave][slate][phase]
+__device__ unsigned long long g_fc_stamps[12][10][10];
+#define FC_STAMP(it, ph)                                                                                              \
+  do {                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+    if (blockIdx.x == LTRX_FC_STAMP && (threadIdx.x & 63) == 0 && (it) < 10)                                           \
+      g_fc_stamps[threadIdx.x >> 6][it][ph] = __builtin_readcyclecounter();                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+  } while (0)
+#else
+#define FC_STAMP(it, ph)
+#endif
 
 // byte offset of 16-byte chunk `col8` (features 8 col8 .. +7) of row `row` inside a plane
 __device__ __forceinline__ int plane_off(int row, int col8) {
@@ -66,6 +83,13 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& l
     h[e] = (__bf16)x[e];
     l[e] = (__bf16)(x[e] - (float)h[e]);
   }
+}
+
+// barrier that orders LDS only: __syncthreads() also drains vmcnt(0), i.e. it would wait for the next slate's prefetch
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // sum over the 16 lanes of a DPP row (every lane of the row gets the total; fixed order)
@@ -94,7 +118,9 @@ struct FcArgs {
   float eps, pad, inv_div;
 };
 
-template <bool RELU>
+// FULL: F in (128, 144] -- every K-step / feature block exists, the loops carry no bounds checks (straight-line code the
+// compiler can software-pipeline); otherwise the same loops skip the steps beyond F at run time.
+template <bool RELU, bool FULL>
 __global__ void __launch_bounds__(768) ltrx_fc_listnet_kernel(const FcArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* hi = smem;
@@ -102,6 +128,7 @@ __global__ void __launch_bounds__(768) ltrx_fc_listnet_kernel(const FcArgs a) {
   float* s_part = reinterpret_cast<float*>(smem + 2 * FC_PLANE);      // [FC_MAXHB][256]
   float* ybuf = s_part + FC_MAXHB * FC_ROWS;
   float* dbuf = ybuf + FC_ROWS;                                        // d loss / d score of the slate (0 beyond L / padded)
+  float* misc = dbuf + FC_ROWS;                                        // cross-wave softmax statistics
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n16 = lane & 15, kg = lane >> 4;
   const int nthr = blockDim.x, nhb = nthr >> 7;
   const int hb = wave >> 1, rh = wave & 1;
@@ -109,6 +136,18 @@ __global__ void __launch_bounds__(768) ltrx_fc_listnet_kernel(const FcArgs a) {
   const int nks = (F + 31) >> 5, nfb = (F + 15) >> 4;
 
   if (a.step_count && blockIdx.x == 0 && tid == 0) a.step_count[0] += 1.0f;   // (the reduce + Adam launch reads it)
+  // the first slate's first half is requested before anything else (it travels while the image is being zeroed)
+  float4 va[FC_NPRE];
+  {
+    const float4* x4 = reinterpret_cast<const float4*>(a.x + (size_t)blockIdx.x * L * F);
+    const int t4 = L * (F >> 2);
+#pragma unroll
+    for (int j = 0; j < FC_NPRE; ++j) {
+      const int q = tid + nthr * j;
+      va[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < t4) va[j] = x4[q];
+    }
+  }
 
   // ---- once per workgroup: zero the image (rows >= L and columns >= F stay zero for the whole kernel) ----
   {
@@ -116,27 +155,12 @@ __global__ void __launch_bounds__(768) ltrx_fc_listnet_kernel(const FcArgs a) {
     for (int o = tid * 16; o < 2 * FC_PLANE; o += nthr * 16) *reinterpret_cast<f32x4*>(smem + o) = z;
     for (int i = tid; i < (FC_MAXHB + 3) * FC_ROWS; i += nthr) s_part[i] = 0.f;
   }
-  // ---- once per workgroup: this wave's rows of W1 as pre-split B fragments (lane (n16, kg): hidden unit 16 hb + n16, features
-  //      32 ks + 8 kg .. +7), its bias and output weight ----
+  // ---- this wave's rows of W1 (lane (n16, kg): hidden unit 16 hb + n16, features 32 ks + 8 kg .. +7), its bias and output weight.
+  //      The fragments are re-read (L2) and re-split for every slate instead of living in 40 registers for the whole kernel: with
+  //      them resident the weight-gradient accumulators spilled (3 of 9 tiles through scratch per K-step) ----
   const int hrow = hb * 16 + n16;
   const bool hok = hrow < H;
-  bf16x8 wh[FC_NKS], wl[FC_NKS];
-#pragma unroll
-  for (int ks = 0; ks < FC_NKS; ++ks) {
-    const int c0 = 32 * ks + 8 * kg;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    if (hok && c0 < F) {
-      const float4 p = *reinterpret_cast<const float4*>(a.w1 + (size_t)hrow * F + c0);
-      v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
-      if (c0 + 4 < F) {
-        const float4 q = *reinterpret_cast<const float4*>(a.w1 + (size_t)hrow * F + c0 + 4);
-        v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
-      }
-    }
-    split8(v, wh[ks], wl[ks]);
-  }
+  const float* wrow = a.w1 + (size_t)(hok ? hrow : 0) * F;
   const float b1n = hok ? a.b1[hrow] : 0.f;
   const float won = hok ? a.wout[hrow] : 0.f;
   const float bout = a.bout[0];
@@ -145,7 +169,7 @@ __global__ void __launch_bounds__(768) ltrx_fc_listnet_kernel(const FcArgs a) {
 #pragma unroll
   for (int fb = 0; fb < FC_NFB; ++fb) out[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dwo = 0.f, db1 = 0.f;              // d w_out[hrow], d b1[hrow] (this lane's rows)
-  float dbo = 0.f, loss_acc = 0.f;         // wave 0: d b_out, sum of the per-slate losses
+  float dbo = 0.f, loss_acc = 0.f;         // waves 0-3: d b_out over their rows; wave 0: sum of the per-slate losses
 
   const int nf4 = F >> 2, total4 = L * nf4;
   const float inv_nf4 = 1.0f / (float)nf4;
@@ -169,9 +193,64 @@ __global__ void __launch_bounds__(768) ltrx_fc_listnet_kernel(const FcArgs a) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) ba[q] = brow * 128 + ((2 * (q ^ bsv) + (piece >> 1)) << 4) + (piece & 1) * 8;
   const int bt = 2 * FC_PANEL + brow * 32 + ((piece >> 1) << 4) + (piece & 1) * 8;
+
+  // staging of one float4 (4 consecutive features of one row): split, two 8-byte LDS stores
+  auto stage_at = [&](int o, const float4& p) {
+    bf16x4 h_, l_;
+    const float xv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h_[e] = (__bf16)xv[e];
+      l_[e] = (__bf16)(xv[e] - (float)h_[e]);
+    }
+    *reinterpret_cast<bf16x4*>(hi + o) = h_;
+    *reinterpret_cast<bf16x4*>(lo + o) = l_;
+  };
+  auto stage_off = [&](int q) {
+    const int row = (int)(((float)q + 0.5f) * inv_nf4);        // == q / nf4 (exact for q < 2^16; checked offline)
+    const int c4 = q - row * nf4;
+    return plane_off(row, c4 >> 1) + (c4 & 1) * 8;
+  };
+  // a thread stages the same image positions for every slate: the FC_NLD offsets (/ 8, 16 bits each) live packed in 6 registers
+  // instead of being re-derived (a float multiply, a swizzle, a panel select: ~18 VALU per float4, ~2 k cycles per SIMD and slate)
+  unsigned so[FC_NLD / 2];
+#pragma unroll
+  for (int j = 0; j < FC_NLD; j += 2) {
+    const int q0 = tid + nthr * j, q1 = tid + nthr * (j + 1);
+    const unsigned o0 = q0 < total4 ? (unsigned)stage_off(q0) >> 3 : 0u, o1 = q1 < total4 ? (unsigned)stage_off(q1) >> 3 : 0u;
+    so[j >> 1] = o0 | (o1 << 16);
+  }
+  auto stage4 = [&](int q, const float4& p) {
+    const int row = (int)(((float)q + 0.5f) * inv_nf4);
+    const int c4 = q - row * nf4;
+    bf16x4 h_, l_;
+    const float xv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h_[e] = (__bf16)xv[e];
+      l_[e] = (__bf16)(xv[e] - (float)h_[e]);
+    }
+    const int o = plane_off(row, c4 >> 1) + (c4 & 1) * 8;
+    *reinterpret_cast<bf16x4*>(hi + o) = h_;
+    *reinterpret_cast<bf16x4*>(lo + o) = l_;
+  };
+  // The first FC_NPRE float4s per thread of a slate are requested one slate AHEAD -- after the forward MFMAs of the slate before, so
+  // that they travel during its ListNet and weight-gradient phases (the barriers in between order LDS only, they do not drain the
+  // vector-memory counter); the rest is requested at the top of the slate's own iteration.
+  auto prefetch = [&](int bb, int tid_, int total4_) {
+    const float4* x4 = reinterpret_cast<const float4*>(a.x + (size_t)bb * total4_ * 4);
+#pragma unroll
+    for (int j = 0; j < FC_NPRE; ++j) {
+      const int q = tid_ + nthr * j;
+      va[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bb < a.B && q < total4_) va[j] = x4[q];
+    }
+  };
   __syncthreads();
 
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+  int it_ = 0;
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x, ++it_) {
+    FC_STAMP(it_, 0);
     // hipcc hoists every address / predicate that does not depend on the slate out of this loop and then spills what it hoisted
     // (150 VGPRs, 126 SGPRs): opaque re-definitions keep those one-instruction values inside the loop
     int L_ = L, total4_ = total4;
@@ -179,103 +258,107 @@ __global__ void __launch_bounds__(768) ltrx_fc_listnet_kernel(const FcArgs a) {
     asm volatile("" : "+v"(fa[0]), "+v"(fa[1]), "+v"(ba[0]), "+v"(ba[1]), "+v"(ba[2]), "+v"(ba[3]));
     int ft_ = ft, bt_ = bt, tid_ = tid;
     asm volatile("" : "+v"(ft_), "+v"(bt_), "+v"(tid_));
-    // ---- stage the slate: coalesced float4 loads of the contiguous [L_, F] block, split, 8-byte LDS stores ----
+    bf16x8 wh[FC_NKS], wl[FC_NKS];
     {
+      // ---- requests: the second half of the slate, its labels; while they travel the first half (requested a slate ago) is split and
+      //      stored; the W1 fragments are requested (L2) into the registers that half has left; then the second half is stored ----
       const float4* x4 = reinterpret_cast<const float4*>(a.x + (size_t)b * L_ * F);
-      float4 v[FC_NLD];
+      float4 vb[FC_NLD - FC_NPRE];
 #pragma unroll
-      for (int j = 0; j < FC_NLD; ++j) {
+      for (int j = FC_NPRE; j < FC_NLD; ++j) {
         const int q = tid_ + nthr * j;
-        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < total4_) v[j] = x4[q];
+        vb[j - FC_NPRE] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < total4_) vb[j - FC_NPRE] = x4[q];
       }
       for (int i = tid_; i < FC_ROWS; i += nthr) ybuf[i] = (i < L_) ? a.y[(size_t)b * L_ + i] : a.pad;
 #pragma unroll
-      for (int j = 0; j < FC_NLD; ++j) {
+      for (int j = 0; j < FC_NPRE; ++j) {
         const int q = tid_ + nthr * j;
-        if (q < total4_) {
-          const int row = (int)(((float)q + 0.5f) * inv_nf4);       // == q / nf4 (exact for q < 2^16; checked offline)
-          const int c4 = q - row * nf4;
-          bf16x4 h, l;
-          const float xv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+        if (q < total4_) stage_at((int)(((so[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) << 3), va[j]);
+      }
+      float4 wr[2 * FC_NKS];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            h[e] = (__bf16)xv[e];
-            l[e] = (__bf16)(xv[e] - (float)h[e]);
-          }
-          const int o = plane_off(row, c4 >> 1) + (c4 & 1) * 8;
-          *reinterpret_cast<bf16x4*>(hi + o) = h;
-          *reinterpret_cast<bf16x4*>(lo + o) = l;
-        }
+      for (int ks = 0; ks < FC_NKS; ++ks) {
+        const int c0 = 32 * ks + 8 * kg;
+        wr[2 * ks] = make_float4(0.f, 0.f, 0.f, 0.f);
+        wr[2 * ks + 1] = wr[2 * ks];
+        if (hok && c0 < F) wr[2 * ks] = *reinterpret_cast<const float4*>(wrow + c0);
+        if (hok && c0 + 4 < F) wr[2 * ks + 1] = *reinterpret_cast<const float4*>(wrow + c0 + 4);
+      }
+#pragma unroll
+      for (int j = FC_NPRE; j < FC_NLD; ++j) {
+        const int q = tid_ + nthr * j;
+        if (q < total4_) stage_at((int)(((so[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) << 3), vb[j - FC_NPRE]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < FC_NKS; ++ks) {
+        const float v[8] = {wr[2 * ks].x, wr[2 * ks].y, wr[2 * ks].z, wr[2 * ks].w,
+                            wr[2 * ks + 1].x, wr[2 * ks + 1].y, wr[2 * ks + 1].z, wr[2 * ks + 1].w};
+        split8(v, wh[ks], wl[ks]);
       }
       // slates longer than FC_NLD * blockDim float4s (small workgroups): the rest in a plain loop
-      for (int q = tid_ + nthr * FC_NLD; q < total4_; q += nthr) {
-        const float4 p = x4[q];
-        const int row = (int)(((float)q + 0.5f) * inv_nf4);
-        const int c4 = q - row * nf4;
-        bf16x4 h, l;
-        const float xv[4] = {p.x, p.y, p.z, p.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          h[e] = (__bf16)xv[e];
-          l[e] = (__bf16)(xv[e] - (float)h[e]);
-        }
-        const int o = plane_off(row, c4 >> 1) + (c4 & 1) * 8;
-        *reinterpret_cast<bf16x4*>(hi + o) = h;
-        *reinterpret_cast<bf16x4*>(lo + o) = l;
-      }
+      for (int q = tid_ + nthr * FC_NLD; q < total4_; q += nthr) stage4(q, x4[q]);
     }
-    __syncthreads();
+    FC_STAMP(it_, 1);
+    lds_barrier();
+    FC_STAMP(it_, 2);
 
     // ---- forward: h[t] = act(x[rows of tile t] W1[hrow]^T + b1)   (D layout: lane (n16, kg) holds rows 4 kg + i of the tile) ----
     f32x4 h[8];
+    // A fragments of K-step ks of tile pair tp (rows 32 tp + n16 and + 16 of this wave's half): hi / lo of both tiles
+    auto load_frag = [&](int tp, int ks, bf16x8 (&fr)[4]) {
+      if (ks < 4) {
+        const int o = fa[ks & 1] + tp * 4096 + (ks >> 1) * FC_PANEL;
+        fr[0] = *reinterpret_cast<const bf16x8*>(hi + o);
+        fr[1] = *reinterpret_cast<const bf16x8*>(lo + o);
+        fr[2] = *reinterpret_cast<const bf16x8*>(hi + o + 2048);
+        fr[3] = *reinterpret_cast<const bf16x8*>(lo + o + 2048);
+      } else {                                              // features 128 .. 143 live in the tail panel; 144 .. 159 do not exist
+        const int o = ft_ + tp * 1024;
+        fr[0] = *reinterpret_cast<const bf16x8*>(hi + o);
+        fr[1] = *reinterpret_cast<const bf16x8*>(lo + o);
+        fr[2] = *reinterpret_cast<const bf16x8*>(hi + o + 512);
+        fr[3] = *reinterpret_cast<const bf16x8*>(lo + o + 512);
+        if (kg >= 2) {
 #pragma unroll
-    for (int tp = 0; tp < 4; ++tp) {
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      if (128 * rh + 32 * tp < L_) {                       // (wave-uniform) tiles entirely beyond the slate: h = act(b1), unused
+          for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int ks = 0; ks < FC_NKS; ++ks) {
-          if (ks < nks) {
-            bf16x8 ah, al, bh, bl;
-            if (ks < 4) {
-              const int o = fa[ks & 1] + tp * 4096 + (ks >> 1) * FC_PANEL;
-              ah = *reinterpret_cast<const bf16x8*>(hi + o);
-              al = *reinterpret_cast<const bf16x8*>(lo + o);
-              bh = *reinterpret_cast<const bf16x8*>(hi + o + 2048);
-              bl = *reinterpret_cast<const bf16x8*>(lo + o + 2048);
-            } else {                                        // features 128 .. 143 live in the tail panel; 144 .. 159 do not exist
-              const int o = ft_ + tp * 1024;
-              ah = *reinterpret_cast<const bf16x8*>(hi + o);
-              al = *reinterpret_cast<const bf16x8*>(lo + o);
-              bh = *reinterpret_cast<const bf16x8*>(hi + o + 512);
-              bl = *reinterpret_cast<const bf16x8*>(lo + o + 512);
-              if (kg >= 2) {
+            for (int e = 0; e < 8; ++e) fr[q][e] = (__bf16)0.f;
+        }
+      }
+    };
+    {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                  ah[e] = (__bf16)0.f; al[e] = (__bf16)0.f; bh[e] = (__bf16)0.f; bl[e] = (__bf16)0.f;
-                }
-              }
+      for (int tp = 0; tp < 4; ++tp) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (FULL || 128 * rh + 32 * tp < L_) {             // (wave-uniform) tiles entirely beyond the slate: h = act(b1), unused
+#pragma unroll
+          for (int ks = 0; ks < FC_NKS; ++ks) {
+            if (FULL || ks < nks) {
+              bf16x8 fr[4];
+              load_frag(tp, ks, fr);
+              acc0 = FC_MFMA(fr[1], wh[ks], acc0);
+              acc1 = FC_MFMA(fr[3], wh[ks], acc1);
+              acc0 = FC_MFMA(fr[0], wl[ks], acc0);
+              acc1 = FC_MFMA(fr[2], wl[ks], acc1);
+              acc0 = FC_MFMA(fr[0], wh[ks], acc0);
+              acc1 = FC_MFMA(fr[2], wh[ks], acc1);
             }
-            acc0 = FC_MFMA(al, wh[ks], acc0);
-            acc1 = FC_MFMA(bl, wh[ks], acc1);
-            acc0 = FC_MFMA(ah, wl[ks], acc0);
-            acc1 = FC_MFMA(bh, wl[ks], acc1);
-            acc0 = FC_MFMA(ah, wh[ks], acc0);
-            acc1 = FC_MFMA(bh, wh[ks], acc1);
           }
         }
-      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float u = acc0[i] + b1n, w = acc1[i] + b1n;
-        if (RELU) {
-          u = fmaxf(u, 0.f);
-          w = fmaxf(w, 0.f);
+        for (int i = 0; i < 4; ++i) {
+          float u = acc0[i] + b1n, w = acc1[i] + b1n;
+          if (RELU) {
+            u = fmaxf(u, 0.f);
+            w = fmaxf(w, 0.f);
+          }
+          h[2 * tp][i] = u;
+          h[2 * tp + 1][i] = w;
         }
-        h[2 * tp][i] = u;
-        h[2 * tp + 1][i] = w;
       }
     }
+    prefetch(b + gridDim.x, tid_, total4_);                 // (in flight until the top of the next iteration)
     // score partials: sum over this wave's 16 hidden units of h * w_out, per row
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -296,71 +379,75 @@ __global__ void __launch_bounds__(768) ltrx_fc_listnet_kernel(const FcArgs a) {
           if (r < L_ && hok) hp[r * H] = h[t][i];
         }
     }
-    __syncthreads();
+    FC_STAMP(it_, 3);
+    lds_barrier();
+    FC_STAMP(it_, 4);
 
-    // ---- scores + ListNet (listNet.py:8-30) by wave 0: four rows per lane ----
-    if (wave == 0) {
-      float sv[4], yv[4];
-      bool val[4];
-      float smax = -INFINITY, ymax = -INFINITY;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = lane + 64 * j;
+    // ---- scores + ListNet (listNet.py:8-30) by waves 0-3, one row per lane.  Softmax statistics are combined across the four
+    //      waves as (max, sum of exp(. - max)) pairs: S = sum_w S_w exp(m_w - M) -- the factor is exactly 1 for the wave that holds the
+    //      maximum; P = exp(s - M) / S as the reference computes it ----
+    {
+      float* red = misc;                                          // [4][4]: m_w, S_w, my_w, Sy_w;   [16 .. 24): lsum_w, rsum_w
+      float sv = -INFINITY, yv = -INFINITY, P = 0.f, T = 0.f, rr = 0.f;
+      bool val = false;
+      const int r = tid_;
+      if (wave < 4) {
         float s = bout;
         for (int q = 0; q < nhb; ++q) s += s_part[q * FC_ROWS + r];
         const float yy = ybuf[r];
-        val[j] = (r < L_) && (yy != a.pad);
+        val = (r < L_) && (yy != a.pad);
         if (r < L_) a.scores[(size_t)b * L_ + r] = s;
-        sv[j] = val[j] ? s : -INFINITY;
-        yv[j] = val[j] ? yy : -INFINITY;
-        smax = fmaxf(smax, sv[j]);
-        ymax = fmaxf(ymax, yv[j]);
+        sv = val ? s : -INFINITY;
+        yv = val ? yy : -INFINITY;
+        const float mw = wave_max(sv), myw = wave_max(yv);
+        const float e = val ? expf(sv - mw) : 0.f, f = val ? expf(yv - myw) : 0.f;
+        const float sw = wave_sum(e), syw = wave_sum(f);
+        if (lane == 0) *reinterpret_cast<f32x4*>(&red[4 * wave]) = f32x4{mw, sw, myw, syw};
       }
-      smax = wave_max(smax);
-      ymax = wave_max(ymax);
-      float e[4], f[4], ssum = 0.f, ysum = 0.f;
+      lds_barrier();
+      if (wave < 4) {
+        f32x4 st[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        e[j] = val[j] ? expf(sv[j] - smax) : 0.f;
-        f[j] = val[j] ? expf(yv[j] - ymax) : 0.f;
-        ssum += e[j];
-        ysum += f[j];
+        for (int w = 0; w < 4; ++w) st[w] = *reinterpret_cast<const f32x4*>(&red[4 * w]);
+        const float M = fmaxf(fmaxf(st[0][0], st[1][0]), fmaxf(st[2][0], st[3][0]));
+        const float MY = fmaxf(fmaxf(st[0][2], st[1][2]), fmaxf(st[2][2], st[3][2]));
+        float S = 0.f, SY = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          if (st[w][1] > 0.f) S += st[w][1] * expf(st[w][0] - M);
+          if (st[w][3] > 0.f) SY += st[w][3] * expf(st[w][2] - MY);
+        }
+        const float inv_s = S > 0.f ? 1.0f / S : 0.f;            // fully padded slate: contributes 0 (reference: NaN)
+        const float inv_y = SY > 0.f ? 1.0f / SY : 0.f;
+        P = val ? expf(sv - M) * inv_s : 0.f;
+        T = val ? expf(yv - MY) * inv_y : 0.f;
+        rr = (P > 0.f) ? P / (P + a.eps) : 0.f;
+        const float lt = (T > 0.f) ? T * logf(P + a.eps) : 0.f;
+        const float lw = wave_sum(lt), rw = wave_sum(T * rr);
+        if (lane == 0) {
+          red[16 + 2 * wave] = lw;
+          red[17 + 2 * wave] = rw;
+        }
       }
-      ssum = wave_sum(ssum);
-      ysum = wave_sum(ysum);
-      const float inv_s = ssum > 0.f ? 1.0f / ssum : 0.f;        // fully padded slate: contributes 0 (reference: NaN)
-      const float inv_y = ysum > 0.f ? 1.0f / ysum : 0.f;
-      float lsum = 0.f, rsum = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        e[j] *= inv_s;                                            // P
-        f[j] *= inv_y;                                            // T
-        if (f[j] > 0.f) lsum += f[j] * logf(e[j] + a.eps);
-        rsum += f[j] * (e[j] / (e[j] + a.eps));
-      }
-      lsum = wave_sum(lsum);
-      rsum = wave_sum(rsum);
-      loss_acc += -lsum;
-      float gs = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = lane + 64 * j;
-        const float P = e[j], T = f[j];
-        const float rr = (P > 0.f) ? P / (P + a.eps) : 0.f;
-        const float g = (P * rsum - T * rr) * a.inv_div;          // padded / beyond L_: P = T = 0 -> exactly 0
+      lds_barrier();
+      if (wave < 4) {
+        const float R = (red[17] + red[19]) + (red[21] + red[23]);
+        const float g = (P * R - T * rr) * a.inv_div;             // padded / beyond L: P = T = 0 -> exactly 0
         dbuf[r] = g;
-        gs += g;
         if (a.dscores && r < L_) a.dscores[(size_t)b * L_ + r] = g;
+        dbo += g;
+        if (wave == 0) loss_acc -= (red[16] + red[18]) + (red[20] + red[22]);
       }
-      dbo += wave_sum(gs);
     }
-    __syncthreads();
+    FC_STAMP(it_, 5);
+    lds_barrier();
+    FC_STAMP(it_, 6);
 
     // ---- backward: dh = dscore (x) w_out (* relu'), d w_out += dscore h, d b1 += dh, dW1^T += x^T dh on the matrix cores ----
 #pragma unroll
     for (int kp = 0; kp < 4; ++kp) {
       const int R0 = 128 * rh + 32 * kp;
-      if (R0 < L_) {                                               // (wave-uniform)
+      if (R0 < L_) {                                              // (wave-uniform)
         const f32x4 d0 = *reinterpret_cast<const f32x4*>(&dbuf[R0 + 4 * kg]);
         const f32x4 d1 = *reinterpret_cast<const f32x4*>(&dbuf[R0 + 16 + 4 * kg]);
         float dh[8];
@@ -385,7 +472,7 @@ __global__ void __launch_bounds__(768) ltrx_fc_listnet_kernel(const FcArgs a) {
         // column i16 of it: rows R + 4 kg + 0..3 of feature 16 fb + n16
 #pragma unroll
         for (int fb = 0; fb < FC_NFB; ++fb) {
-          if (fb < nfb) {
+          if (FULL || fb < nfb) {
             const int o0 = (fb < 8) ? ba[fb & 3] + kp * 4096 + (fb >> 2) * FC_PANEL : bt_ + kp * 1024;
             const int o1 = o0 + ((fb < 8) ? 2048 : 512);
             const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(hi + o0));
@@ -401,7 +488,9 @@ __global__ void __launch_bounds__(768) ltrx_fc_listnet_kernel(const FcArgs a) {
         }
       }
     }
-    __syncthreads();                                              // the image is free for the next slate
+    FC_STAMP(it_, 7);
+    lds_barrier();                                                // the image is free for the next slate
+    FC_STAMP(it_, 8);
   }
 
   // ---- one partial gradient per workgroup: the two row halves are added through LDS (the image is dead), fixed order ----
@@ -412,6 +501,10 @@ __global__ void __launch_bounds__(768) ltrx_fc_listnet_kernel(const FcArgs a) {
   db1 += __shfl_xor(db1, 32, 64);
   f32x4* sc = reinterpret_cast<f32x4*>(smem);                     // [hb][fb][lane]
   float* sc2 = reinterpret_cast<float*>(smem + (size_t)FC_MAXHB * FC_NFB * 64 * sizeof(f32x4));   // [hb][2][16]
+  if (wave < 4) {
+    const float t = wave_sum(dbo);
+    if (lane == 0) misc[32 + wave] = t;
+  }
   if (rh == 1) {
 #pragma unroll
     for (int fb = 0; fb < FC_NFB; ++fb) sc[(hb * FC_NFB + fb) * 64 + lane] = out[fb];
@@ -434,7 +527,7 @@ __global__ void __launch_bounds__(768) ltrx_fc_listnet_kernel(const FcArgs a) {
       slab[a.off_b1 + hrow] = hok ? db1 + sc2[(hb * 2 + 1) * 16 + n16] : 0.f;
     }
   }
-  if (wave == 0 && lane < 4) slab[a.off_bout + lane] = (lane == 0) ? dbo : 0.f;
+  if (wave == 0 && lane < 4) slab[a.off_bout + lane] = (lane == 0) ? (misc[32] + misc[33]) + (misc[34] + misc[35]) : 0.f;
   if (wave == 0 && lane >= 4 && lane < 8) slab[a.nflat + lane - 4] = (lane == 4) ? loss_acc : 0.f;
 }
 
@@ -452,18 +545,28 @@ struct FcAdam {
 __global__ void __launch_bounds__(1024) ltrx_fc_reduce_kernel(const float* __restrict__ slab, int nwg, int stride, int nflat,
                                                                float* __restrict__ grads, float* __restrict__ loss_out,
                                                                float inv_div, const FcAdam ad) {
-  __shared__ f32x4 part[16][64];
-  const int col = threadIdx.x & 63, gq = threadIdx.x >> 6;
-  const int c4 = blockIdx.x * 64 + col, n4 = (nflat >> 2) + 1;
+  // 16 float4 columns x 64 groups of partials per workgroup (~200 workgroups at H x F = 96 x 136): every thread has its
+  // nwg / 64 loads in flight at once; the 64 group sums are combined in two fixed-order levels through LDS
+  __shared__ f32x4 part[64][16];
+  __shared__ f32x4 part2[8][16];
+  const int col = threadIdx.x & 15, gq = threadIdx.x >> 4;
+  const int c4 = blockIdx.x * 16 + col, n4 = (nflat >> 2) + 1;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (c4 < n4)
-    for (int g = gq; g < nwg; g += 16) acc += *reinterpret_cast<const f32x4*>(slab + (size_t)g * stride + 4 * c4);
+    for (int g = gq; g < nwg; g += 64) acc += *reinterpret_cast<const f32x4*>(slab + (size_t)g * stride + 4 * c4);
   part[gq][col] = acc;
   __syncthreads();
-  if (gq != 0 || c4 >= n4) return;
-  f32x4 t = part[0][col];
+  if (gq < 8) {
+    f32x4 u = part[8 * gq][col];
 #pragma unroll
-  for (int q = 1; q < 16; ++q) t += part[q][col];
+    for (int q = 1; q < 8; ++q) u += part[8 * gq + q][col];
+    part2[gq][col] = u;
+  }
+  __syncthreads();
+  if (gq != 0 || c4 >= n4) return;
+  f32x4 t = part2[0][col];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) t += part2[q][col];
   if (4 * c4 >= nflat) {
     loss_out[0] = t[0] * inv_div;
     return;
@@ -503,6 +606,12 @@ int fc_workgroups(int B) {
 
 }  // namespace
 
+#ifdef LTRX_FC_STAMP
+extern "C" int ltrx_debug_fc_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fc_stamps), sizeof(g_fc_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int ltrx_fc_listnet_supported(int L, int F, int H) {
   return (L > 0 && L <= FC_ROWS && F > 0 && F <= FC_MAXF && (F & 3) == 0 && H > 0 && H <= FC_MAXH) ? 1 : 0;
 }
@@ -534,10 +643,10 @@ extern "C" int ltrx_fc_listnet_step(const float* x, const float* y, int B, int L
   if (exp_avg && (!exp_avg_sq || !step_count)) return LTRX_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int rc = ltrx_once_per_device(g_fc_attr, []() -> int {
-    if (hipFuncSetAttribute((const void*)ltrx_fc_listnet_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_SMEM) != hipSuccess)
-      return LTRX_EHIP;
-    if (hipFuncSetAttribute((const void*)ltrx_fc_listnet_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_SMEM) != hipSuccess)
-      return LTRX_EHIP;
+    const void* ks[4] = {(const void*)ltrx_fc_listnet_kernel<false, false>, (const void*)ltrx_fc_listnet_kernel<true, false>,
+                         (const void*)ltrx_fc_listnet_kernel<false, true>, (const void*)ltrx_fc_listnet_kernel<true, true>};
+    for (int i = 0; i < 4; ++i)
+      if (hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)FC_SMEM) != hipSuccess) return LTRX_EHIP;
     return LTRX_OK;
   });
   if (rc != LTRX_OK) return rc;
@@ -566,11 +675,16 @@ extern "C" int ltrx_fc_listnet_step(const float* x, const float* y, int B, int L
   a.pad = pad_value;
   a.inv_div = 1.0f / batch_divisor;
   const int nwg = fc_workgroups(B);
-  const int nhb = (H + 15) / 16;
-  if (act)
-    hipLaunchKernelGGL(ltrx_fc_listnet_kernel<true>, dim3(nwg), dim3(128 * nhb), FC_SMEM, s, a);
+  const int nhb = (H + 15) / 16 < 2 ? 2 : (H + 15) / 16;      // (at least four waves: ListNet runs one slate row per lane on waves 0-3)
+  const bool full = F > 128;
+  if (act && full)
+    hipLaunchKernelGGL((ltrx_fc_listnet_kernel<true, true>), dim3(nwg), dim3(128 * nhb), FC_SMEM, s, a);
+  else if (act)
+    hipLaunchKernelGGL((ltrx_fc_listnet_kernel<true, false>), dim3(nwg), dim3(128 * nhb), FC_SMEM, s, a);
+  else if (full)
+    hipLaunchKernelGGL((ltrx_fc_listnet_kernel<false, true>), dim3(nwg), dim3(128 * nhb), FC_SMEM, s, a);
   else
-    hipLaunchKernelGGL(ltrx_fc_listnet_kernel<false>, dim3(nwg), dim3(128 * nhb), FC_SMEM, s, a);
+    hipLaunchKernelGGL((ltrx_fc_listnet_kernel<false, false>), dim3(nwg), dim3(128 * nhb), FC_SMEM, s, a);
   LTRX_LAUNCH_CHECK();
   FcAdam ad;
   ad.p = exp_avg ? params : nullptr;
@@ -584,7 +698,7 @@ extern "C" int ltrx_fc_listnet_step(const float* x, const float* y, int B, int L
   ad.wd = weight_decay;
   ad.decoupled = decoupled;
   const int n4 = (int)(nflat >> 2) + 1;
-  hipLaunchKernelGGL(ltrx_fc_reduce_kernel, dim3((n4 + 63) / 64), dim3(1024), 0, s, (const float*)ws, nwg, a.stride, (int)nflat, grads,
+  hipLaunchKernelGGL(ltrx_fc_reduce_kernel, dim3((n4 + 15) / 16), dim3(1024), 0, s, (const float*)ws, nwg, a.stride, (int)nflat, grads,
                      loss_out, 1.0f / batch_divisor, ad);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;

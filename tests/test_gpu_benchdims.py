@@ -113,6 +113,8 @@ def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=
     x, y = _batch(rng, B, L, cfg["n_features"], ragged)
     mask = y == -1
     ft = FusedTrainer(model, loss_name, dict(loss_args or {}), B, L, lr=LR, use_graph=True, gemm=gemm)
+    if getattr(ft, "fcstep", False):          # the slate-resident FC + ListNet step keeps no activations unless asked to
+        ft.keep_fc_out = True
     if set_perm is not None:
         ft.shuffle_ties = False
         ft.loss.set_perm(torch.tensor(set_perm))
@@ -194,6 +196,7 @@ GRAD_RMS_TOL = 2e-4
 CFG3 = dict(n_features=136, fc_sizes=[512], fc_activation=None, fc_input_norm=False, N=2, d_ff=2048, h=8, output_activation=None)
 CFG5 = dict(n_features=1024, fc_sizes=[512], fc_activation=None, fc_input_norm=False, N=2, d_ff=2048, h=8, output_activation=None)
 CFG1_FC = dict(n_features=136, fc_sizes=[96], fc_activation=None, fc_input_norm=False, N=0, d_ff=0, h=1, output_activation=None)
+CFG1_FC_RELU = dict(n_features=136, fc_sizes=[96], fc_activation="ReLU", fc_input_norm=False, N=0, d_ff=0, h=1, output_activation=None)
 CFG1_MLP = dict(n_features=136, fc_sizes=[256, 512, 1024, 512, 256], fc_activation="ReLU", fc_input_norm=False, N=0, d_ff=0, h=1,
                 output_activation=None)          # the reference's reproducibility/configs/ndcgloss2pp_mlp.json stack
 
@@ -289,11 +292,14 @@ def test_fused_step_at_config4_losses_matches_fp64_oracle(loss_name, loss_args, 
     _check(rows, "cfg4/" + loss_name)
 
 
-@pytest.mark.parametrize("name,cfg", [("fc96", CFG1_FC), ("mlp", CFG1_MLP)])
-def test_fused_step_at_config2_dimensions_matches_fp64_oracle(name, cfg):
+@pytest.mark.parametrize("name,cfg,B", [("fc96", CFG1_FC, 256), ("fc96_relu", CFG1_FC_RELU, 256), ("fc96_b2048", CFG1_FC, 2048),
+                                        ("mlp", CFG1_MLP, 256)])
+def test_fused_step_at_config2_dimensions_matches_fp64_oracle(name, cfg, B):
     """BASELINE configs[1]: F=136, slate 240, 256 slates, FCModel + ListNet (model.py:35-44, listNet.py:8-30): FC[96] (what
-    bench.py --workload fc_listnet runs) and the reference's MLP [256, 512, 1024, 512, 256] + ReLU."""
-    B, L = 256, 240
+    bench.py --workload fc_listnet runs: the slate-resident step of csrc/ltrx_fcstep.hip, also with ReLU and at the large-batch
+    point of 2048 slates = 8 slates per workgroup) and the reference's MLP [256, 512, 1024, 512, 256] + ReLU (GEMM launch
+    sequence)."""
+    L = 240
     rows = _run(cfg, B, L, "split_bf16", "listNet", lambda s, t: O.listnet(s, t, dtype=np.float64), steps=3,
                 ragged=[(1, 200), (3, 17), (50, 1), (200, 100)], seed=25)
     _log("cfg2_%s_split_bf16" % name, rows)

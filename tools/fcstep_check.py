@@ -140,6 +140,10 @@ def timing(B, L=240, F=136, H=96, act=None, steps=200):
 def main():
     quick = "--quick" in sys.argv
     ok = True
+    if "--timing-only" in sys.argv:            # e.g. --timing-only 256,2048   (for rocprofv3 runs)
+        for B in [int(v) for v in sys.argv[sys.argv.index("--timing-only") + 1].split(",")]:
+            timing(B, steps=50)
+        return 0
     cases = [(3, 16, 20, 16, None), (5, 100, 64, 48, "ReLU"), (7, 240, 136, 96, None), (7, 240, 136, 96, "ReLU"), (4, 256, 144, 96, "ReLU"),
              (9, 37, 136, 80, None), (6, 129, 128, 33, "ReLU"), (300, 240, 136, 96, None), (600, 240, 136, 96, "ReLU")]
     if quick:
