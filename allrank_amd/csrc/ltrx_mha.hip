@@ -573,9 +573,16 @@ extern "C" int ltrx_mha_fwd(const float* q, const float* k, const float* v, cons
   return LTRX_OK;
 }
 
+// The split-bf16 backward hands dS[B, h, LK, LK] (LK = L rounded up to 64) from its dK/dV kernel to its dQ kernel through the
+// workspace: 134 MB at 64 x 8 x 240, 537 MB at 16 x 8 x 1024 -- and 8.6 GB at 64 x 8 x 2048.  Above LTRX_MHA_DS_BUDGET_BYTES the call
+// uses the exact-fp32 kernels instead (workspace B L h floats, no O(L^2) memory) -- same contract, fp32 MFMA rate.
+static bool res_bwd_selected(int B, int L, int h, int d_k) {
+  return ltrx_mha_res_bwd_fits(L, d_k) && ltrx_mha_res_bwd_ws_bytes(B, L, h) <= (size_t)LTRX_MHA_DS_BUDGET_BYTES;
+}
+
 extern "C" size_t ltrx_mha_bwd_workspace_bytes(int B, int L, int h, int d_k, int mode) {
   if (B <= 0 || L <= 0 || h <= 0 || d_k <= 0) return 0;
-  if (mode != 0 && ltrx_mha_res_bwd_fits(L, d_k)) return ltrx_mha_res_bwd_ws_bytes(B, L, h);     // the dS exchange
+  if (mode != 0 && res_bwd_selected(B, L, h, d_k)) return ltrx_mha_res_bwd_ws_bytes(B, L, h);     // the dS exchange
   return (size_t)B * L * h * sizeof(float);
 }
 
@@ -592,7 +599,7 @@ extern "C" int ltrx_mha_bwd(const float* q, const float* k, const float* v, cons
   if (d_row_stride % 4 != 0 || d_row_stride < h * d_k) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* delta = (float*)ws;
-  if (mode != 0 && ltrx_mha_res_bwd_fits(L, d_k))
+  if (mode != 0 && res_bwd_selected(B, L, h, d_k))
     return ltrx_mha_bwd_res_launch(q, k, v, key_pad_mask, o, dout, lse, B, L, h, d_k, row_stride, o_row_stride, dq, dk, dv, d_row_stride,
                                    ws, p_drop, seed, seed_step, cu_seqlens, slate_order, mode == 2, s);
   const DropCfg drop = make_drop(p_drop, seed);

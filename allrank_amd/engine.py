@@ -380,7 +380,11 @@ class FusedTrainer(object):
         self.graph_fwd, self._warm_fwd = None, 0
         self.probe = None                                     # list collecting (start, end) events of the FFN1 GEMM (eager steps only)
         # captured steps: {(batch divisor, collectives on?): [(hipGraph segment, collective to launch after it | None), ...]}
-        self._graphs = {}
+        import collections
+        self._graphs = collections.OrderedDict()
+        self.max_graphs = 4
+        self._warned_evict = False
+        self.capture_fallback = None                          # repr of the capture error if a sharded run fell back to eager steps
         self._seg_break = None                                # set while capturing: ends the current segment (see _capture)
         self._graph_pool = None
         self._cap_stream = None
@@ -390,6 +394,7 @@ class FusedTrainer(object):
         self.y_cur = self.y_in                                # labels of the last step() (the caller's tensor in the fcstep path)
         # ---- slate-resident FC + ListNet step (csrc/ltrx_fcstep.hip): eligibility ----
         self.keep_fc_out = False                              # tests: also write the FC activations to fc_out[0]
+        self.keep_loss_grad = False                           # tests: also write d loss / d scores to self.loss.grad (4 B per item)
         self.fcstep = bool(
             fc_step and self.N == 0 and self.nfc == 1 and self.in_norm is None and self.pos is None and self.fc_act in (0, 1)
             and self.p_fc == 0.0 and self.n_out == 1 and self.out_act == 0 and loss_name == "listNet" and not compact
@@ -863,25 +868,39 @@ class FusedTrainer(object):
         # The batch divisor is a by-value launch argument of the loss kernels (include/ltrx.h: `batch_divisor`), i.e. a captured
         # step keeps the divisor it was captured with.  Captured steps are therefore keyed by the divisor: the short last batch of
         # an epoch (DataLoader drop_last=False, dataset_loading.py:245; it arrives topped up with padded slates and global_batch =
-        # its real slate count) gets its own capture; beyond four distinct divisors a step runs eagerly.
+        # its real slate count) gets its own capture.  The captures form an LRU of ``max_graphs`` (4) entries: a fifth distinct
+        # divisor evicts the least recently used one (and says so once) instead of silently running eagerly.
         key = (self._divisor, bool(self.comm_enabled))
         segs = self._graphs.get(key)
         if segs is None:
-            if self._warm < 2 or len(self._graphs) >= 4:
+            if self._warm < 2:
                 self._warm += 1                       # warm-up outside capture (lazy module loads, kernel attributes, workspaces)
                 return self._eager()
+            if len(self._graphs) >= self.max_graphs:
+                old_key = next(iter(self._graphs))
+                del self._graphs[old_key]
+                if not self._warned_evict:
+                    import warnings
+                    self._warned_evict = True
+                    warnings.warn("allrank_amd: more than %d distinct batch divisors in flight -- evicting the least recently used captured "
+                                  "step (divisor %g); every new divisor costs one re-capture" % (self.max_graphs, old_key[0]))
             try:
                 segs = self._graphs[key] = self._capture()
-            except Exception as exc:                  # noqa: BLE001
-                if self.world == 1:
+            except RuntimeError as exc:
+                # sharded only, and only for errors of the capture mechanism itself (a collective backend that cannot live next to a
+                # stream capture): the eager step is the same arithmetic (tests/dist_equiv_worker.py), only with launch overhead.  Any
+                # other error -- a failed LB.check, a shape error, out of memory -- is a bug in the captured path and is raised.
+                msg = str(exc)
+                if self.world == 1 or not any(t in msg for t in ("capture", "Capture", "hipErrorStreamCapture", "cudaErrorStreamCapture")):
                     raise
-                # sharded: a collective backend that cannot live next to a stream capture must not take the job down --
-                # the eager step is the same arithmetic (tests/dist_equiv_worker.py), only with launch overhead
                 import warnings
                 warnings.warn("allrank_amd: hipGraph capture of the sharded step failed (%r); running eagerly" % (exc,))
+                self.capture_fallback = repr(exc)     # queryable: tests/dist_equiv_worker.py asserts it stays None
                 self.use_graph = False
                 self._graphs.clear()
                 return self._eager()
+        else:
+            self._graphs.move_to_end(key)
         for g, after in segs:                         # (capture only records: the replay executes this step)
             g.replay()
             if after is not None:
@@ -890,7 +909,7 @@ class FusedTrainer(object):
 
     def _fc_step(self, xb, yb, global_batch):
         """the slate-resident step (ltrx_fc_listnet_step): reads the caller's batch in place -- x once -- and leaves scores in
-        ``self.scores``, d loss / d scores in ``self.loss.grad``, gradients in the flat buffer, the loss in ``self.loss.loss``.  One
+        ``self.scores``, d loss / d scores in ``self.loss.grad`` (with ``keep_loss_grad``), gradients in the flat buffer, the loss in ``self.loss.loss``.  One
         GPU without clipping: the reducing launch also applies Adam (two launches per step); sharded or clipped: gradients only,
         then the all-reduce / clip and the flat-buffer Adam as in the general step."""
         LB, P = self.LB, self.LB.ptr
@@ -910,7 +929,8 @@ class FusedTrainer(object):
                    float(self.eps), self.weight_decay, 1 if self.optimizer == "AdamW" else 0)
         else:
             opt = (None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0)
-        LB.check(self.lib.ltrx_fc_listnet_step(P(xb), P(yb), *self._fc_a, div, *self._fc_b, hid, P(self.loss.loss), P(self.flat_g), *opt,
+        LB.check(self.lib.ltrx_fc_listnet_step(P(xb), P(yb), *self._fc_a, div, self._fc_b[0], self._fc_b[1] if self.keep_loss_grad else None,
+                                               hid, P(self.loss.loss), P(self.flat_g), *opt,
                                                P(self._fc_ws), self._st()), "fc_listnet_step")
         if not fused_adam:
             if self.world > 1 and self.comm_enabled:

@@ -173,10 +173,17 @@ def _batch_shape(dl):
     Also returns the fraction of valid (non-padded) slots over a sample of the set (the auto choice of variable-length execution)."""
     try:
         bsz, ds = int(dl.batch_size), dl.dataset
-        items = [ds[i] for i in range(0, len(ds), max(1, len(ds) // 32))][:32]
+        # The probe indexes dataset items; the reference's FixLength transform draws from the GLOBAL numpy generator when it
+        # subsamples a long slate (dataset_loading.py:70), so the generator state is saved and restored around it -- a seeded run draws
+        # the same subsamples with and without the probe (ADVICE r3).
+        st = np.random.get_state()
+        try:
+            items = [ds[i] for i in range(0, len(ds), max(1, len(ds) // 32))][:32]
+        finally:
+            np.random.set_state(st)
         ys = torch.stack([torch.as_tensor(it[1]).float() for it in items])
         return bsz, int(items[0][0].shape[0]), float((ys != PADDED_Y_VALUE).float().mean())
-    except Exception:                                     # noqa: BLE001 -- any custom iterable
+    except (AttributeError, TypeError, IndexError, KeyError):          # loaders without batch_size / an indexable dataset
         first = next(iter(dl))
         return int(first[0].shape[0]), int(first[0].shape[1]), float((first[1] != PADDED_Y_VALUE).float().mean())
 
@@ -284,7 +291,8 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
             tot += loss.detach().float().reshape(()) * real_glob          # (sharded: this rank's share of the global-batch loss)
             num += real
             for name, ats in metrics.items():
-                v = getattr(EM, name)(scores, labels, ats=ats).sum(0)
+                # (a rank whose shard of a short last batch is empty contributes zeros -- every rank keeps the same stats layout)
+                v = getattr(EM, name)(scores, labels, ats=ats).sum(0) if real > 0 else torch.zeros(len(ats), device=device)
                 tm[name] = v if tm[name] is None else tm[name] + v
         stats = torch.cat([tot.reshape(1), torch.tensor([float(num)], device=device)] + [tm[n].float() for n in metrics if tm[n] is not None])
         if world > 1:

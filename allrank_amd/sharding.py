@@ -9,33 +9,51 @@ With no context active everything degenerates to the single-GPU case.  Gradients
 across ranks by allrank_amd.parallel -- each rank already divides by the global divisor.
 """
 import contextlib
+import threading
 
-_state = {"global_batch": None, "group": None, "active": False, "deferred": None}
+_DEFAULT = {"global_batch": None, "group": None, "active": False, "deferred": None}
+
+
+class _Local(threading.local):
+    """the shard context of THIS thread (like ops.arithmetic): two replica threads of one process -- the reference's
+    nn.DataParallel layout, allrank/models/model_utils.py:40-53 -- must not see each other's divisor / group / deferral hook"""
+
+    def __init__(self):
+        self.state = dict(_DEFAULT)
+
+
+_tls = _Local()
+
+
+def _st():
+    return _tls.state
 
 
 def active():
-    return _state["active"]
+    return _st()["active"]
 
 
 def group():
-    return _state["group"]
+    return _st()["group"]
 
 
 def batch_divisor(local_batch):
-    gb = _state["global_batch"]
-    return float(gb if (_state["active"] and gb is not None) else local_batch)
+    st = _st()
+    gb = st["global_batch"]
+    return float(gb if (st["active"] and gb is not None) else local_batch)
 
 
 def allreduce_sum_(t):
     """in-place all-reduce(sum) of a small device tensor across the shard group (no-op when not sharded)."""
-    if _state["active"]:
+    st = _st()
+    if st["active"]:
         import torch.distributed as dist
-        grp = _state["group"]
+        grp = st["group"]
 
         def launch():
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=grp)
-        if _state["deferred"] is not None:     # a step is being captured: the collective runs between two hipGraph segments
-            _state["deferred"](launch)
+        if st["deferred"] is not None:         # a step is being captured: the collective runs between two hipGraph segments
+            st["deferred"](launch)
         else:
             launch()
     return t
@@ -46,9 +64,10 @@ def shard_context(global_batch, group=None, deferred=None):
     """with shard_context(global_batch=G): loss = approxNDCGLoss(scores_local, y_local)  # -> this rank's share
     ``deferred(launch)``: instead of issuing a normaliser all-reduce, hand it to this callback (FusedTrainer._capture: the
     collective becomes the host action between two captured segments of the step)."""
-    prev = dict(_state)
-    _state.update(global_batch=int(global_batch), group=group, active=True, deferred=deferred)
+    st = _st()
+    prev = dict(st)
+    st.update(global_batch=int(global_batch), group=group, active=True, deferred=deferred)
     try:
         yield
     finally:
-        _state.update(prev)
+        st.update(prev)

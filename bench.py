@@ -226,7 +226,7 @@ def cpu_baseline(w, L, seconds_budget=20.0):
     return out
 
 
-def measure_hbm_traffic(M, N, K, timeout_s=90):
+def measure_hbm_traffic(M, N, K, timeout_s=90, script="gemm_one.py", env_extra=None, kernels=("nt256",)):
     """HBM-side bytes per launch of the dominant GEMM kernel at the benchmarked shape, from rocprofv3 PMC counters collected
     the way MI355X_MICROARCH.md (HBM section) prescribes: separate --pmc passes (FETCH_SIZE, then WRITE_SIZE; --kernel-trace only
     beside them), counters in KB, FETCH_SIZE doubled on gfx950 (it tallies 128-B requests at 64 B for wide coalesced reads).
@@ -244,19 +244,21 @@ def measure_hbm_traffic(M, N, K, timeout_s=90):
         d = tempfile.mkdtemp(prefix="ltrx_pmc_")
         try:
             env = dict(os.environ, GM=str(M), GN=str(N), GK=str(K), GONLY="nt", TMPDIR=d)
+            env.update(env_extra or {})
             subprocess.run([exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--",
-                            sys.executable, os.path.join(root, "tools", "gemm_one.py")], cwd=d, env=env, timeout=timeout_s,
+                            sys.executable, os.path.join(root, "tools", script)], cwd=d, env=env, timeout=timeout_s,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not files:
                 return None, "no counter_collection.csv from the %s pass" % counter
-            per = []
-            for r in csv.DictReader(open(files[0])):
-                if "nt256" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                    per.append(float(r["Counter_Value"]))
-            if len(per) < 2:
-                return None, "kernel not found in the %s pass" % counter
-            vals[counter] = sum(per[1:]) / (len(per) - 1)
+            tot = 0.0
+            rows_ = list(csv.DictReader(open(files[0])))
+            for kn in kernels:                  # (several kernels: the launches of one step; their per-launch means are summed)
+                per = [float(r["Counter_Value"]) for r in rows_ if kn in r["Kernel_Name"] and r["Counter_Name"] == counter]
+                if len(per) < 2:
+                    return None, "kernel %s not found in the %s pass" % (kn, counter)
+                tot += sum(per[1:]) / (len(per) - 1)
+            vals[counter] = tot
         except Exception as e:
             return None, "%s pass failed: %r" % (counter, e)
         finally:
@@ -264,7 +266,7 @@ def measure_hbm_traffic(M, N, K, timeout_s=90):
     rd, wr = 2.0 * vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
     return rd + wr, dict(read_bytes=rd, write_bytes=wr, fetch_size_kb_raw=vals["FETCH_SIZE"], write_size_kb_raw=vals["WRITE_SIZE"],
                          correction="FETCH_SIZE x 2 (gfx950, wide coalesced reads; MI355X_MICROARCH.md HBM section), counters in KB",
-                         collection="two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of tools/gemm_one.py after the timed region, mean of launches 2..5")
+                         collection="two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of tools/%s after the timed region, mean of launches 2..5" % script)
 
 
 def _self_spawn(n):
@@ -471,15 +473,32 @@ def main():
                         frac=round(ach / PEAK_HBM_GBPS, 4), traffic=None, avg_launch_us=round(k["sec"] * 1e6, 1),
                         algorithmic_bytes_per_launch=by)
         if not w["N"]:
-            # FCModel-only workloads (BASELINE configs[1]): 53 kFLOP per item against 552 B -- the step is HBM / launch bound, not MFMA
-            # bound, so the roofline is quoted for the whole step: SURVEY 8(d)'s algorithmic bytes per item (features once, label, score
-            # and gradient round trip) x items per step / the timed step
+            # FCModel-only workloads (BASELINE configs[1]): 53 kFLOP per item against 552 B -- the HBM roofline binds.  Algorithmic bytes
+            # per step = SURVEY 8(d)'s per-item figure (features once, label, score) x items per step; the step is the two launches of
+            # ltrx_fc_listnet_step (slate-resident forward / loss / backward kernel + partial reduce with Adam), timed with HIP events
+            # on the launch stream over steps that follow the timed region
             by = float(4 * w["n_features"] + 8) * B * L
-            ach = by / (dt / args.steps) / 1e9
-            roof = dict(kernel="whole step (FC GEMMs + score head + ListNet + Adam: ~15 launches, profiles/r03_bench_fc_listnet_kernel_stats.md)",
-                        bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(ach / PEAK_HBM_GBPS, 4), traffic=None,
-                        algorithmic_bytes_per_launch=by, avg_launch_us=round(dt / args.steps * 1e6, 1),
-                        note="launch / latency bound at this size: 0.2 ms per step of ~15 kernels of 5-50 us")
+            fcstep = bool(getattr(trainer, "fcstep", False))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(20):
+                one_step(args.warmup + args.steps + i)
+            e1.record()
+            torch.cuda.synchronize()
+            step_us = e0.elapsed_time(e1) / 20 * 1e3
+            traffic, traffic_detail = (None, "skipped")
+            if fcstep and not args.no_side_pass and world == 1:
+                traffic, traffic_detail = measure_hbm_traffic(0, 0, 0, script="fc_one.py", kernels=("ltrx_fc_listnet_kernel", "ltrx_fc_reduce_kernel"),
+                                                              env_extra=dict(FB=str(B), FL=str(L), FF=str(w["n_features"]), FH=str(w["fc_sizes"][0])))
+            ach = by / (step_us * 1e-6) / 1e9
+            roof = dict(kernel=("ltrx_fc_listnet_kernel + ltrx_fc_reduce_kernel (the whole step: two launches; per-kernel split in "
+                                "profiles/r04_bench_fc_listnet_kernel_stats.md)" if fcstep else
+                                "whole step (FC GEMMs + score head + ListNet + Adam: ~15 launches)"),
+                        bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(ach / PEAK_HBM_GBPS, 4),
+                        traffic=traffic, traffic_detail=traffic_detail, algorithmic_bytes_per_launch=by, avg_launch_us=round(step_us, 1),
+                        timing="HIP events around 20 training steps after the timed region (both launches of a step)",
+                        host_bound_note="wall-clock per step in the timed region: %.1f us" % (dt / args.steps * 1e6))
         loss_roof = None
         if w["loss"].startswith("neuralNDCG"):
             # the Sinkhorn kernels are VALU bound (no contraction): algorithmic flops = n^2 x (4 per forward step + 6 per backward step)
@@ -527,6 +546,45 @@ def main():
                 out["value_at_64_slates_per_gpu"] = round(20 * 64 * L / (time.perf_counter() - t0), 1)
             except Exception as e:      # never let the side measurement break the contract line
                 out["value_at_64_slates_per_gpu"] = "failed: %r" % (e,)
+        if world == 1 and not w["N"] and args.engine == "fused" and not args.no_side_pass:
+            try:           # the large-batch point ("and a large-batch point, e.g. 2048/GPU"): 8 slates per workgroup
+                Bl = 2048
+                xl, yl, il = synth_batch(2 * Bl, L, w["n_features"], 4242, device)
+                ml = build_model(w, device, args.dropout)
+                tl = FusedTrainer(ml, w["loss"], w.get("loss_args", {}), Bl, L, lr=1e-3, world_size=1, use_graph=True, gemm=args.gemm)
+                for i in range(6):
+                    tl.step(xl[(i % 2) * Bl:(i % 2 + 1) * Bl], yl[(i % 2) * Bl:(i % 2 + 1) * Bl], il[(i % 2) * Bl:(i % 2 + 1) * Bl])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(40):
+                    tl.step(xl[(i % 2) * Bl:(i % 2 + 1) * Bl], yl[(i % 2) * Bl:(i % 2 + 1) * Bl], il[(i % 2) * Bl:(i % 2 + 1) * Bl])
+                torch.cuda.synchronize()
+                tsec = (time.perf_counter() - t0) / 40
+                byl = float(4 * w["n_features"] + 8) * Bl * L
+                trl, trd = (measure_hbm_traffic(0, 0, 0, script="fc_one.py", kernels=("ltrx_fc_listnet_kernel", "ltrx_fc_reduce_kernel"),
+                                                env_extra=dict(FB=str(Bl), FL=str(L), FF=str(w["n_features"]), FH=str(w["fc_sizes"][0])))
+                            if getattr(tl, "fcstep", False) else (None, "not the slate-resident step"))
+                out["large_batch_2048_slates"] = {"value": round(Bl * L / tsec, 1), "unit": "slate-items/s", "us_per_step": round(tsec * 1e6, 1),
+                                                  "algorithmic_bytes_per_step": byl, "achieved_gbps": round(byl / tsec / 1e9, 1),
+                                                  "hbm_roofline_frac": round(byl / tsec / 1e9 / PEAK_HBM_GBPS, 4), "traffic": trl,
+                                                  "traffic_over_algorithmic": (round(trl / byl, 3) if trl else None), "traffic_detail": trd}
+                del tl, ml, xl, yl, il
+            except Exception as e:
+                out["large_batch_2048_slates"] = "failed: %r" % (e,)
+            try:           # A/B: the same workload through the GEMM launch sequence (FusedTrainer(fc_step=False), hipGraph)
+                mg = build_model(w, device, args.dropout)
+                tg = FusedTrainer(mg, w["loss"], w.get("loss_args", {}), B, L, lr=1e-3, world_size=1, use_graph=True, gemm=args.gemm, fc_step=False)
+                for i in range(6):
+                    tg.step(x[:B], y[:B], idx[:B])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(20):
+                    tg.step(x[:B], y[:B], idx[:B])
+                torch.cuda.synchronize()
+                out["value_gemm_launch_sequence"] = round(20 * B * L / (time.perf_counter() - t0), 1)
+                del tg, mg
+            except Exception as e:
+                out["value_gemm_launch_sequence"] = "failed: %r" % (e,)
         out["comm"] = comm
         if world == 1 and not args.no_side_pass:
             try:          # what a caller that hands over HOST batches (the reference's DataLoader, train_utils.py:95) would add per step

@@ -40,6 +40,9 @@ extern "C" {
 #define LTRX_EHIP (-1000)
 
 #define LTRX_MAX_SLATE_LEN 2048        /* loss kernels stage a slate (and its per-item work arrays) in LDS */
+#define LTRX_MHA_DS_BUDGET_BYTES (2147483648ull) /* ltrx_mha_bwd, modes 1 / 2: the dS hand-over workspace is B h LK^2 floats (LK = L rounded
+                                                    up to 64); a call that would need more than this runs the exact-fp32 kernels
+                                                    (workspace B L h floats) instead -- ltrx_mha_bwd_workspace_bytes says which */
 #define LTRX_MAX_METRIC_SLATE_LEN 8192 /* ltrx_ndcg_at / ltrx_mrr_at: validation sets are padded to their longest slate
                                           (allrank/data/dataset_loading.py:185-194); 16 B per item of the 160 KB LDS */
 

@@ -67,6 +67,7 @@ def main():
                 assert abs(tot.item() - l1.item()) <= 1e-5 * (1 + abs(l1.item())), (loss_name, tot.item(), l1.item())
                 gerr = (tg.flat_g - t1.flat_g).abs().max().item() / max(t1.flat_g.abs().max().item(), 1e-12)
                 assert gerr < 2e-4, (loss_name, "grad vs one rank", gerr)
+        assert tg.capture_fallback is None, (loss_name, tg.capture_fallback)          # the captured sharded path really ran
         assert tg.graph is not None and len(tg.graph) >= 1 + len(tg._buckets), (loss_name, "segments", None if tg.graph is None else len(tg.graph))
     # count-normalised pointwise losses through the plugin functions: the rank shares (each divided by the GLOBAL count,
     # all-reduced inside the loss) add up to the single-process value, and so do the gradients

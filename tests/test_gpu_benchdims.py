@@ -114,7 +114,7 @@ def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=
     mask = y == -1
     ft = FusedTrainer(model, loss_name, dict(loss_args or {}), B, L, lr=LR, use_graph=True, gemm=gemm)
     if getattr(ft, "fcstep", False):          # the slate-resident FC + ListNet step keeps no activations unless asked to
-        ft.keep_fc_out = True
+        ft.keep_fc_out = ft.keep_loss_grad = True
     if set_perm is not None:
         ft.shuffle_ties = False
         ft.loss.set_perm(torch.tensor(set_perm))

@@ -55,7 +55,7 @@ def _run(B, L, F, H, act, seed, steps=3, optimizer="Adam", weight_decay=0.0, cli
     cross = (H % 4 == 0)                       # (the GEMM launch sequence needs H % 4 == 0)
     f2 = FusedTrainer(m2, "listNet", {}, B, L, fc_step=False, **kw) if cross else None
     assert f1.fcstep and (f2 is None or not f2.fcstep)
-    f1.keep_fc_out = True
+    f1.keep_fc_out = f1.keep_loss_grad = True
     keys = list(params)
     n1, n2 = dict(m1.named_parameters()), dict(m2.named_parameters())
     worst = dict(loss=0.0, score=0.0, grad=0.0, w=0.0, oloss=0.0, oscore=0.0, ograd=0.0, dsc=0.0)

@@ -128,6 +128,30 @@ def test_fused_step_short_last_batch_is_normalised_by_its_real_slate_count():
         assert ft.graph is not None          # the full batches did get their graph
 
 
+def test_captured_steps_form_an_lru_over_batch_divisors():
+    """captured steps are keyed by the batch divisor; a fifth distinct divisor evicts the least recently used
+    capture (one warning) instead of silently running eagerly, and every divisor -- captured, evicted, re-captured -- gives the
+    loss of the eager step on the same weights."""
+    import copy
+    import warnings
+    from allrank_amd.engine import FusedTrainer
+    L, F, bs = 30, 20, 16
+    x, y, _ = (t.to(DEV) for t in _data(16, L, F, 9))
+    m_g = _model(F)
+    m_e = copy.deepcopy(m_g)
+    tg = FusedTrainer(m_g, "approxNDCGLoss", {}, bs, L, lr=1e-3, use_graph=True)
+    te = FusedTrainer(m_e, "approxNDCGLoss", {}, bs, L, lr=1e-3, use_graph=False)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for div in (16, 16, 16, 15, 14, 13, 12, 11, 16, 15, 11, 12):
+            lg, le = tg.step(x, y, None, global_batch=div), te.step(x, y, None, global_batch=div)
+            assert torch.equal(lg, le) and torch.equal(tg.flat_p, te.flat_p), div
+            assert len(tg._graphs) <= tg.max_graphs
+    assert tg.use_graph and len(tg._graphs) == tg.max_graphs
+    assert sum("evicting the least recently used" in str(w.message) for w in rec) == 1
+    assert (11.0, True) in tg._graphs and (12.0, True) in tg._graphs     # the most recent divisors are the live captures
+
+
 @pytest.mark.parametrize("name,kw", [("Adam", dict(lr=2e-3, betas=(0.8, 0.95), eps=1e-6, weight_decay=0.01)),
                                      ("AdamW", dict(lr=2e-3, weight_decay=0.05)),
                                      ("SGD", dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-3)),

@@ -672,6 +672,20 @@ def test_sharded_step_equals_single_rank_step():
     assert "EQUIV_OK" in out.stdout, out.stdout[-2000:]
 
 
+def test_sharded_fit_with_uneven_last_batch_equals_one_rank():
+    """``fit()`` on 2 ranks (gloo, one GPU) over batches of 16 / 16 / 1 slates -- the last one leaves rank 1 without a
+    slate -- reproduces the 1-rank epoch losses and weights (tests/dist_fit_worker.py)."""
+    import subprocess
+    import sys
+    script = os.path.join(ROOT, "tests", "dist_fit_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), script]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    assert "FIT_EQUIV_OK" in out.stdout, out.stdout[-2000:]
+
+
 def test_neuralndcg_block_resident_path_equals_general_path():
     """the block-resident kernels (L <= 240: 2 x 2 / 4 x 4 / 6 x 6 tiles on 16 waves, 15 x 5 tiles on 12 waves) and the general
     L2-streaming kernels agree with each other and the oracle; L = 250 runs the general kernels on both paths; the 3-item slates

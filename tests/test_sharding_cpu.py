@@ -93,3 +93,30 @@ def test_shard_slates_partition():
         spans = [parallel.shard_slates(n, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+def test_shard_context_is_thread_local():
+    """two replica threads of one process (the reference's nn.DataParallel layout, model_utils.py:40-53) each see their own
+    divisor; a thread that never entered a context sees none"""
+    import threading
+    from allrank_amd import sharding
+    seen, barrier = {}, threading.Barrier(3)
+
+    def replica(name, gb):
+        if gb is None:
+            barrier.wait()
+            seen[name] = (sharding.active(), sharding.batch_divisor(5))
+            barrier.wait()
+            return
+        with sharding.shard_context(gb):
+            barrier.wait()                               # all three threads are inside their (non-)contexts at the same time
+            seen[name] = (sharding.active(), sharding.batch_divisor(5))
+            barrier.wait()
+
+    ts = [threading.Thread(target=replica, args=a) for a in (("a", 16), ("b", 48), ("c", None))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(30)
+    assert seen == {"a": (True, 16.0), "b": (True, 48.0), "c": (False, 5.0)}
+    assert not sharding.active()

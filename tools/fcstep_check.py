@@ -54,7 +54,7 @@ def case(B, L, F, H, act, seed, steps=3):
     f2 = FusedTrainer(m2, "listNet", {}, B, L, lr=1e-3, use_graph=False, fc_step=False) if cross else None
     assert f1.fcstep and (f2 is None or not f2.fcstep)
     adam = M.Adam({k: v.astype(np.float64) for k, v in params.items()}, lr=1e-3)
-    f1.keep_fc_out = True
+    f1.keep_fc_out = f1.keep_loss_grad = True
     keys = list(params)
     n1, n2 = dict(m1.named_parameters()), dict(m2.named_parameters())
     worst = dict(loss=0.0, score=0.0, grad=0.0, w=0.0, oloss=0.0, oscore=0.0, ograd=0.0, dsc=0.0)
