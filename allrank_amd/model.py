@@ -7,12 +7,14 @@ torch RNG state -- bit-identical initial weights: the construction below draws f
 order as the reference (one prototype nn.Linear deep-copied 4x per attention block, the encoder layer cloned N
 times, Xavier-uniform over parameters() with dim > 1 in registration order).
 
-Arithmetic: the per-slate self-attention (flash-style, fp32 MFMA) and the custom LayerNorm (+ fused residual add)
-run in hand-written HIP kernels (allrank_amd/ops.py -> libltrx.so).  The dense projections are plain library GEMMs
-(torch.nn.functional.linear -> hipBLASLt), with Q, K and V computed by ONE [3d, d] GEMM so that the attention
-kernel reads q/k/v as strided views of a single buffer.  Dropout follows torch semantics (nn.Dropout on the
-residual branches / activations); the attention-probability dropout of transformer.py:154-155 happens inside the fused
-attention kernel (counter-based mask regenerated in the backward; same distribution, different random stream).
+Arithmetic: every contraction -- the dense projections (``ops.linear`` -> ltrx_gemm_nt / ltrx_gemm_tn) and the per-slate
+self-attention (``ops.attention_packed`` -> ltrx_mha_fwd / ltrx_mha_bwd) -- runs on the bf16 matrix cores as three bf16 products
+per fp32 product with fp32 accumulation ("split-bf16", fp32-class accuracy; ``ops.arithmetic(linear="hipblaslt", attention=0)``
+selects torch's fp32 library GEMMs and the exact-fp32 MFMA attention kernels instead); Q, K and V come from ONE [3d, d] GEMM so that
+the attention kernel reads q / k / v as strided views of a single buffer.  The custom LayerNorm (+ fused residual add) is a
+hand-written kernel too (allrank_amd/ops.py -> libltrx.so).  Dropout follows torch semantics (nn.Dropout on the residual branches
+/ activations); the attention-probability dropout of transformer.py:154-155 happens inside the fused attention kernel
+(counter-based mask regenerated in the backward; same distribution, different random stream).
 """
 import copy
 
