@@ -236,9 +236,11 @@ def backward(p, cfg, cache, gscores, relu_masks=None, fc_relu_masks=None):
 
 
 class Adam(object):
-    """torch.optim.Adam defaults (betas .9/.999, eps 1e-8, no weight decay, no amsgrad)."""
-    def __init__(self, params, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam (betas .9/.999, eps 1e-8, amsgrad off) restated: ``weight_decay`` adds wd * p to the gradient (torch.optim.Adam's
+    L2 term); ``decoupled=True`` is torch.optim.AdamW: p <- p (1 - lr wd) before the moment update, the gradient untouched."""
+    def __init__(self, params, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, weight_decay=0.0, decoupled=False):
         self.lr, self.b1, self.b2, self.eps, self.t = lr, b1, b2, eps, 0
+        self.wd, self.decoupled = weight_decay, decoupled
         self.m = {k: np.zeros_like(v) for k, v in params.items()}
         self.v = {k: np.zeros_like(v) for k, v in params.items()}
 
@@ -248,10 +250,15 @@ class Adam(object):
         bc2 = 1 - self.b2 ** self.t
         for k in params:
             g = grads[k].astype(params[k].dtype)
+            w = params[k]
+            if self.wd and self.decoupled:
+                w = w * (1 - self.lr * self.wd)
+            elif self.wd:
+                g = g + self.wd * w
             self.m[k] = self.b1 * self.m[k] + (1 - self.b1) * g
             self.v[k] = self.b2 * self.v[k] + (1 - self.b2) * g * g
             denom = np.sqrt(self.v[k]) / math.sqrt(bc2) + self.eps
-            params[k] = (params[k] - (self.lr / bc1) * self.m[k] / denom).astype(params[k].dtype)
+            params[k] = (w - (self.lr / bc1) * self.m[k] / denom).astype(params[k].dtype)
 
 
 def train_step(p, cfg, opt, x, y, loss_fn):

@@ -1,9 +1,8 @@
-"""torchrun worker for test_sharded_fit_with_uneven_last_batch_equals_one_rank (2 ranks on one GPU, gloo): the drop-in epoch loop
+"""worker of test_sharded_fit_with_uneven_last_batch_equals_one_rank (2 ranks on one GPU, gloo): the drop-in epoch loop
 ``allrank_amd.fit.fit`` (reference signature, allrank/training/train_utils.py:78-147) on 33 slates with a global batch of 16 --
 batches of 16 / 16 / 1 slates, i.e. the last batch gives rank 0 one slate and rank 1 none (DataLoader drop_last=False,
-allrank/data/dataset_loading.py:245) -- against the same loop on one rank (world 1 is run inside rank 0's process first, on a copy of
-the model): same per-epoch training loss (the reference's loss on the gathered batch) and the same trained weights."""
-import copy
+allrank/data/dataset_loading.py:245) -- against the same loop on one rank (``--ref``: a plain single process, run first by the test):
+same per-epoch training loss (the reference's loss on the gathered batch) and the same trained weights."""
 import os
 import sys
 import tempfile
@@ -64,42 +63,52 @@ def run_fit(model, loss_name, tr, va, epochs, tmp):
 
 
 def main():
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    """``--ref FILE``: one process, no process group: fit() on one rank, results saved to FILE.
+    ``--cmp FILE`` (under torchrun, 2 ranks): the sharded fit(), compared on rank 0 with FILE."""
+    import datetime
+    mode, path = sys.argv[1], sys.argv[2]
     torch.cuda.set_device(0)
     L, F = 30, 20
     tr, va = data(33, L, F, 1), data(16, L, F, 2)
-    ok = True
-    for loss_name in ("approxNDCGLoss", "neuralNDCG"):
-        base = build(F)
-        ref = None
-        if rank == 0:                                         # one rank, before the process group exists: world == 1 inside fit()
-            m1 = copy.deepcopy(base)
+    jobs = ("approxNDCGLoss", "neuralNDCG")
+    if mode == "--ref":
+        out = {}
+        for loss_name in jobs:
+            m1 = build(F)
             with tempfile.TemporaryDirectory() as tmp:
                 l1, r1 = run_fit(m1, loss_name, tr, va, 2, tmp)
             assert FIT.last_run["engine"] == "fused", FIT.last_run
-            ref = (l1, {k: v.detach().clone() for k, v in m1.state_dict().items()}, r1)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        try:
-            m2 = copy.deepcopy(base)
+            out[loss_name] = (l1, {k: v.detach().cpu().clone() for k, v in m1.state_dict().items()},
+                              {k: float(v) for k, v in r1["val_metrics"].items()})
+        torch.save(out, path)
+        print("FIT_REF_OK")
+        return
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        ref = torch.load(path) if rank == 0 else None
+        for loss_name in jobs:
+            m2 = build(F)
             with tempfile.TemporaryDirectory() as tmp:
                 l2, r2 = run_fit(m2, loss_name, tr, va, 2, tmp)
             assert FIT.last_run["engine"] == "fused", FIT.last_run
             if rank == 0:
-                l1, w1, r1 = ref
+                l1, w1, v1 = ref[loss_name]
                 for a, b in zip(l1, l2):
                     assert abs(a - b) <= 1e-5 * (1 + abs(a)), (loss_name, "train loss per epoch", l1, l2)
-                werr = max(float((w1[k] - v).abs().max()) for k, v in m2.state_dict().items())
+                sd = {k: v.detach().cpu() for k, v in m2.state_dict().items()}
+                werr = max(float((w1[k] - v).abs().max()) for k, v in sd.items())
                 # two epochs of lr = 1e-3 Adam steps; entries whose gradient is below its round-off may take opposite signs
                 assert werr <= 6 * 2.1e-3, (loss_name, "weights", werr)
-                agree = np.mean([float(((w1[k] - v).abs() <= 2e-5).float().mean()) for k, v in m2.state_dict().items()])
+                agree = np.mean([float(((w1[k] - v).abs() <= 2e-5).float().mean()) for k, v in sd.items()])
                 assert agree >= 0.98, (loss_name, "fraction of weights that agree to 2e-5", agree)
-                for k in r1["val_metrics"]:
-                    assert abs(float(r1["val_metrics"][k]) - float(r2["val_metrics"][k])) <= 2e-3, (loss_name, k, r1["val_metrics"], r2["val_metrics"])
-        finally:
-            dist.barrier()
-            dist.destroy_process_group()
-    if rank == 0 and ok:
-        print("FIT_EQUIV_OK")
+                for k in v1:
+                    assert abs(v1[k] - float(r2["val_metrics"][k])) <= 2e-3, (loss_name, k, v1, r2["val_metrics"])
+        dist.barrier()
+        if rank == 0:
+            print("FIT_EQUIV_OK")
+    finally:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -99,14 +99,19 @@ def _run(B, L, F, H, act, seed, steps=3, optimizer="Adam", weight_decay=0.0, cli
                 worst["ograd"] = max(worst["ograd"], float(np.abs(g1 - g_or[k]).max()) / own)
             else:
                 worst["ograd"] = max(worst["ograd"], float(np.abs(g1 - g_or[k]).max()) / gm)
-        if optimizer == "Adam" and not weight_decay and not clip:
-            if st == 0:
-                adam = M.Adam({k: v.astype(np.float64) for k, v in params.items()}, lr=1e-3)
-            w_pred = {k: v.copy() for k, v in w_before.items()}
-            adam.step(w_pred, g_eng)
-            worst["w"] = max(worst["w"], max(float(np.abs(w_pred[k] - n1[k].detach().cpu().numpy()).max()) for k in keys))
-        elif cross and st == 0:                               # other update rules: against the flat-buffer kernel of the GEMM path
-            worst["w"] = max(worst["w"], max(float((n1[k].detach() - n2[k].detach()).abs().max()) for k in keys))
+        # the optimizer update (the reducing launch's fused Adam / AdamW, or -- with clipping -- clip + flat-buffer kernel) against an
+        # fp64 replica of torch.optim's rule driven by the ENGINE's gradients (a cross-path comparison of WEIGHTS is meaningless: the
+        # first Adam update is lr * sign(g), so entries whose gradient is below its round-off may take either sign)
+        if st == 0:
+            adam = M.Adam({k: v.astype(np.float64) for k, v in params.items()}, lr=1e-3, weight_decay=weight_decay,
+                          decoupled=(optimizer == "AdamW"))
+        g_use = g_eng
+        if clip:                                               # clip_grad_norm_ (train_utils.py:24-25): g * min(1, c / (||g|| + 1e-6))
+            tot = float(np.sqrt(sum(float((g ** 2).sum()) for g in g_eng.values())))
+            g_use = {k: g * min(1.0, clip / (tot + 1e-6)) for k, g in g_eng.items()}
+        w_pred = {k: v.copy() for k, v in w_before.items()}
+        adam.step(w_pred, g_use)
+        worst["w"] = max(worst["w"], max(float(np.abs(w_pred[k] - n1[k].detach().cpu().numpy()).max()) for k in keys))
     return worst
 
 

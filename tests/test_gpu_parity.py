@@ -679,9 +679,14 @@ def test_sharded_fit_with_uneven_last_batch_equals_one_rank():
     import sys
     script = os.path.join(ROOT, "tests", "dist_fit_worker.py")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), script]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        ref = os.path.join(tmp, "ref.pt")
+        out = subprocess.run([sys.executable, script, "--ref", ref], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "FIT_REF_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), script, "--cmp", ref]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     assert "FIT_EQUIV_OK" in out.stdout, out.stdout[-2000:]
 
