@@ -85,6 +85,7 @@ SIGNATURES = {
 
 _lib = None
 MAX_SLATE_LEN = 2048            # LTRX_MAX_SLATE_LEN (include/ltrx.h; checked against the header by tests/test_abi.py)
+MAX_LONG_SLATE_LEN = 16384      # LTRX_MAX_LONG_SLATE_LEN: listNet / listMLE / approxNDCG / lambdaLoss (work arrays in the workspace beyond LDS)
 MAX_METRIC_SLATE_LEN = 8192     # LTRX_MAX_METRIC_SLATE_LEN
 
 
@@ -136,9 +137,9 @@ def lib():
 def check(rc, what):
     if rc != 0:
         kinds = {-1: "invalid argument",
-                 -2: "unsupported shape (slate length above LTRX_MAX_SLATE_LEN = %d for a loss / LTRX_MAX_METRIC_SLATE_LEN = %d for a "
-                     "metric, or an alignment the kernel needs -- see include/ltrx.h; there is no fallback path)" %
-                     (MAX_SLATE_LEN, MAX_METRIC_SLATE_LEN)}
+                 -2: "unsupported shape (slate length above LTRX_MAX_SLATE_LEN = %d for a loss -- LTRX_MAX_LONG_SLATE_LEN = %d for listNet / "
+                     "listMLE / approxNDCGLoss / lambdaLoss -- or LTRX_MAX_METRIC_SLATE_LEN = %d for a metric, or an alignment the kernel "
+                     "needs -- see include/ltrx.h; there is no fallback path)" % (MAX_SLATE_LEN, MAX_LONG_SLATE_LEN, MAX_METRIC_SLATE_LEN)}
         msg = kinds.get(rc, "HIP error %d" % (-rc - 1000) if rc <= -1000 else "error")
         raise RuntimeError("libltrx %s failed: %s (code %d)" % (what, msg, rc))
 

@@ -28,16 +28,19 @@ __device__ __forceinline__ float sigmoid_neg_fast(float x) {
 }
 }  // namespace
 
+// GWS: the seven work arrays live in a global workspace (slates too long for LDS; ltrx_device.h)
+template <bool GWS>
 __global__ void __launch_bounds__(1024) ltrx_approxndcg_kernel(const float* __restrict__ y_pred,
                                                                const float* __restrict__ y_true, int L, float eps,
                                                                float pad, float alpha, float inv_div,
                                                                float* __restrict__ per_ws, float* __restrict__ per_out,
-                                                               float* __restrict__ grad) {
+                                                               float* __restrict__ grad, float* gws, size_t gws_stride) {
   extern __shared__ float lds[];
-  float* ss = lds;          // [L] scores
-  float* ys = lds + L;      // [L] labels (pad kept as pad)
-  float* ws = lds + 2 * L;  // [L] w_i
-  float* part = lds + 3 * L;   // [4][L] partial sums of the four partner quarters
+  float* base = GWS ? gws + (size_t)blockIdx.x * gws_stride : lds;
+  float* ss = base;          // [L] scores
+  float* ys = base + L;      // [L] labels (pad kept as pad)
+  float* ws = base + 2 * L;  // [L] w_i
+  float* part = base + 3 * L;   // [4][L] partial sums of the four partner quarters
   __shared__ float red[LTRX_MAX_WAVES];
   const int b = blockIdx.x;
   const float* sp = y_pred + (size_t)b * L;
@@ -127,17 +130,34 @@ __global__ void __launch_bounds__(1024) ltrx_approxndcg_kernel(const float* __re
   }
 }
 
-extern "C" size_t ltrx_approxndcg_workspace_bytes(int B, int L) { (void)L; return (size_t)(B > 0 ? B : 0) * sizeof(float); }
+static size_t approx_per_floats(int B) { return ((size_t)(B > 0 ? B : 0) + 3) & ~(size_t)3; }
+extern "C" size_t ltrx_approxndcg_workspace_bytes(int B, int L) {
+  return (approx_per_floats(B) + ltrx_array_ws_floats(7, 0, B > 0 ? B : 0, L > 0 ? L : 0)) * sizeof(float);
+}
 
 extern "C" int ltrx_approxndcg_fwd_bwd(const float* y_pred, const float* y_true, int B, int L, float eps,
                                        float pad_value, float alpha, float batch_divisor, float* loss_out,
                                        float* per_slate_out, float* grad_out, void* ws, ltrx_stream_t stream) {
   if (!y_pred || !y_true || !loss_out || !ws || B <= 0 || L <= 0 || !(batch_divisor > 0.f)) return LTRX_EINVAL;
-  if (L > LTRX_MAX_SLATE_LEN) return LTRX_EUNSUPPORTED;
+  if (L > LTRX_MAX_LONG_SLATE_LEN) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* per = (float*)ws;
-  hipLaunchKernelGGL(ltrx_approxndcg_kernel, dim3(B), dim3(1024), 7 * (size_t)L * sizeof(float), s, y_pred, y_true, L,
-                     eps, pad_value, alpha, 1.0f / batch_divisor, per, per_slate_out, grad_out);
+  if (ltrx_arrays_in_lds(7, 0, L)) {
+    const size_t lds = 7 * (size_t)L * sizeof(float);
+    if (lds > 48 * 1024) {
+      static std::atomic<uint64_t> attr_done{0};
+      const int arc = ltrx_once_per_device(attr_done, []() {
+        return hipFuncSetAttribute((const void*)ltrx_approxndcg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   LTRX_LDS_ARRAY_BUDGET_BYTES) == hipSuccess ? LTRX_OK : LTRX_EHIP;
+      });
+      if (arc != LTRX_OK) return arc;
+    }
+    hipLaunchKernelGGL(ltrx_approxndcg_kernel<false>, dim3(B), dim3(1024), lds, s, y_pred, y_true, L, eps, pad_value, alpha,
+                       1.0f / batch_divisor, per, per_slate_out, grad_out, (float*)nullptr, (size_t)0);
+  } else {
+    hipLaunchKernelGGL(ltrx_approxndcg_kernel<true>, dim3(B), dim3(1024), 0, s, y_pred, y_true, L, eps, pad_value, alpha,
+                       1.0f / batch_divisor, per, per_slate_out, grad_out, per + approx_per_floats(B), ltrx_array_ws_stride(7, 0, L));
+  }
   LTRX_LAUNCH_CHECK();
   return ltrx_launch_finalize_sum(per, B, -1.0f / batch_divisor, loss_out, s);
 }

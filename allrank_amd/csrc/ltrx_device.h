@@ -172,6 +172,25 @@ inline ltrx::DropSpec ltrx_make_drop(float p, uint32_t seed) {
 namespace ltrx {
 }  // namespace ltrx
 
+// Per-slate work arrays of the listwise loss kernels (`narr` floats per item): in LDS (extern __shared__) while they fit the CU's
+// 160 KB, otherwise in a global workspace that the SAME kernel body addresses through a generic pointer (template flag GWS): the
+// arrays of a slate stay in its CU's L1 / the XCD's L2, and __syncthreads() orders global accesses inside a workgroup exactly as it
+// orders LDS.  Slates up to LTRX_MAX_SLATE_LEN take the LDS form (the tuned path); up to LTRX_MAX_LONG_SLATE_LEN the global form --
+// the reference pads a validation set to its longest slate with no bound (allrank/data/dataset_loading.py:185-194).
+#define LTRX_LDS_ARRAY_BUDGET_BYTES (160 * 1024 - 1024)
+static inline bool ltrx_arrays_in_lds(int narr, int extra_floats, int L) {
+  return ((size_t)narr * (size_t)L + (size_t)extra_floats) * sizeof(float) <= (size_t)LTRX_LDS_ARRAY_BUDGET_BYTES;
+}
+// bytes of the global work arrays (0 when they fit in LDS), rounded so that the per-slate block keeps 16-byte alignment
+static inline size_t ltrx_array_ws_floats(int narr, int extra_floats, int B, int L) {
+  if (ltrx_arrays_in_lds(narr, extra_floats, L)) return 0;
+  const size_t per = (((size_t)narr * (size_t)L + (size_t)extra_floats) + 3) & ~(size_t)3;
+  return per * (size_t)B;
+}
+static inline size_t ltrx_array_ws_stride(int narr, int extra_floats, int L) {
+  return (((size_t)narr * (size_t)L + (size_t)extra_floats) + 3) & ~(size_t)3;
+}
+
 // Final cross-slate reduction: out[0] = scale * sum_b per[b]  (fixed order -> deterministic).  One block.
 // (host launcher lives in ltrx_common.hip; kernels are never launched across translation units)
 int ltrx_launch_finalize_sum(const float* per, int B, float scale, float* out, hipStream_t s);

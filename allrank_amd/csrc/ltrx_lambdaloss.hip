@@ -65,20 +65,23 @@ __device__ __forceinline__ void pair_terms(const PairCtx& c, float w, float sig,
 
 // 1024 threads per slate: thread (i, q) = (tid & 255 [+256 ...], tid >> 8) owns item i and a quarter of the partner range j;
 // the four partial sums per item are combined through LDS (16 waves per CU instead of 4 hide the exp/log latency).
+// GWS: the thirteen work arrays live in a global workspace (slates too long for LDS; ltrx_device.h)
+template <bool GWS>
 __global__ void __launch_bounds__(1024) ltrx_lambdaloss_kernel(const float* __restrict__ y_pred,
                                                               const float* __restrict__ y_true, int L, float eps,
                                                               float pad, int scheme, int k, float sigma, float mu,
                                                               int logbase, float* __restrict__ per_loss,
                                                               float* __restrict__ per_cnt, float* __restrict__ grad,
-                                                              int64_t* __restrict__ order_out) {
+                                                              int64_t* __restrict__ order_out, float* gws, size_t gws_stride) {
   extern __shared__ float lds[];
-  float* ss = lds;                    // [L] scores
-  float* ys = lds + L;                // [L] labels (pad kept)
-  float* Gs = lds + 2 * L;            // [L] gains / maxDCG
-  int* rk = (int*)(lds + 3 * L);      // [L] rank by score (valid items; padded get L)
-  float* invD = lds + 4 * L;          // [L+2]
-  float* part = lds + 5 * L + 2;      // [4][L] float partials
-  int* parti = (int*)(lds + 9 * L + 2);   // [4][L] int partials (score-rank and label-rank counts packed: rs | ry << 16)
+  float* base = GWS ? gws + (size_t)blockIdx.x * gws_stride : lds;
+  float* ss = base;                    // [L] scores
+  float* ys = base + L;                // [L] labels (pad kept)
+  float* Gs = base + 2 * L;            // [L] gains / maxDCG
+  int* rk = (int*)(base + 3 * L);      // [L] rank by score (valid items; padded get L)
+  float* invD = base + 4 * L;          // [L+2]
+  float* part = base + 5 * L + 2;      // [4][L] float partials
+  int* parti = (int*)(base + 9 * L + 2);   // [4][L] int partials (score-rank and label-rank counts packed: rs | ry << 16)
   __shared__ float red[LTRX_MAX_WAVES];
   __shared__ int redi[LTRX_MAX_WAVES];
   const int b = blockIdx.x;
@@ -110,7 +113,7 @@ __global__ void __launch_bounds__(1024) ltrx_lambdaloss_kernel(const float* __re
         rs += (sj > si) || (sj == si && j < i);
         ry += (yj > yi) || (yj == yi && j < i);
       }
-    parti[q * L + i] = rs | (ry << 16);            // L <= 2048: both counts fit 16 bits
+    parti[q * L + i] = rs | (ry << 16);            // a quarter of L <= LTRX_MAX_LONG_SLATE_LEN = 16384 partners: both counts fit 15 bits
   }
   __syncthreads();
   float dsum = 0.f;
@@ -228,9 +231,9 @@ __global__ void __launch_bounds__(256) ltrx_scale_by_device_scalar_kernel(float*
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= sc;
 }
 
+static size_t lambda_per_floats(int B) { return ((size_t)(2 * (B > 0 ? B : 0) + 4) + 3) & ~(size_t)3; }
 extern "C" size_t ltrx_lambdaloss_workspace_bytes(int B, int L) {
-  (void)L;
-  return (size_t)(2 * (B > 0 ? B : 0) + 4) * sizeof(float);
+  return (lambda_per_floats(B) + ltrx_array_ws_floats(13, 2, B > 0 ? B : 0, L > 0 ? L : 0)) * sizeof(float);
 }
 
 extern "C" int ltrx_lambdaloss_fwd_bwd(const float* y_pred, const float* y_true, int B, int L, float eps,
@@ -243,20 +246,25 @@ extern "C" int ltrx_lambdaloss_fwd_bwd(const float* y_pred, const float* y_true,
   if (reduction != LTRX_REDUCE_SUM && reduction != LTRX_REDUCE_MEAN) return LTRX_EINVAL;
   if (logbase != LTRX_LOG_BINARY && logbase != LTRX_LOG_NATURAL) return LTRX_EINVAL;
   if (!(eps > 0.f)) return LTRX_EINVAL;
-  if (L > LTRX_MAX_SLATE_LEN) return LTRX_EUNSUPPORTED;
+  if (L > LTRX_MAX_LONG_SLATE_LEN) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* per_loss = (float*)ws;
   float* per_cnt = per_loss + B;
   float* scale = per_cnt + B;
-  const size_t lds = (size_t)(13 * L + 2) * sizeof(float);
-  static std::atomic<uint64_t> attr_done{0};   // long slates need more than the default 64 KB of dynamic LDS
-  const int arc = ltrx_once_per_device(attr_done, []() {
-    return hipFuncSetAttribute((const void*)ltrx_lambdaloss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)((13 * LTRX_MAX_SLATE_LEN + 2) * sizeof(float))) == hipSuccess ? LTRX_OK : LTRX_EHIP;
-  });
-  if (arc != LTRX_OK) return arc;
-  hipLaunchKernelGGL(ltrx_lambdaloss_kernel, dim3(B), dim3(1024), lds, s, y_pred, y_true, L, eps, pad_value, scheme, k,
-                     sigma, mu, logbase, per_loss, per_cnt, grad_out, order_out);
+  if (ltrx_arrays_in_lds(13, 2, L)) {
+    const size_t lds = (size_t)(13 * L + 2) * sizeof(float);
+    static std::atomic<uint64_t> attr_done{0};   // long slates need more than the default 64 KB of dynamic LDS
+    const int arc = ltrx_once_per_device(attr_done, []() {
+      return hipFuncSetAttribute((const void*)ltrx_lambdaloss_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 LTRX_LDS_ARRAY_BUDGET_BYTES) == hipSuccess ? LTRX_OK : LTRX_EHIP;
+    });
+    if (arc != LTRX_OK) return arc;
+    hipLaunchKernelGGL(ltrx_lambdaloss_kernel<false>, dim3(B), dim3(1024), lds, s, y_pred, y_true, L, eps, pad_value, scheme, k, sigma, mu,
+                       logbase, per_loss, per_cnt, grad_out, order_out, (float*)nullptr, (size_t)0);
+  } else {
+    hipLaunchKernelGGL(ltrx_lambdaloss_kernel<true>, dim3(B), dim3(1024), 0, s, y_pred, y_true, L, eps, pad_value, scheme, k, sigma, mu,
+                       logbase, per_loss, per_cnt, grad_out, order_out, per_loss + lambda_per_floats(B), ltrx_array_ws_stride(13, 2, L));
+  }
   LTRX_LAUNCH_CHECK();
   hipLaunchKernelGGL(ltrx_lambdaloss_finalize_kernel, dim3(1), dim3(256), 0, s, per_loss, per_cnt, B, reduction,
                      ext_pair_count, loss_out, pair_count_out, scale);

@@ -16,19 +16,22 @@
 
 using namespace ltrx;
 
+// GWS: the six work arrays live in a global workspace (slates too long for LDS; ltrx_device.h)
+template <bool GWS>
 __global__ void __launch_bounds__(1024) ltrx_listmle_kernel(const float* __restrict__ y_pred,
                                                            const float* __restrict__ y_true,
                                                            const int64_t* __restrict__ perm, int L, float eps,
                                                            float pad, float inv_div, float* __restrict__ per_ws,
                                                            float* __restrict__ per_out, float* __restrict__ grad,
-                                                           int64_t* __restrict__ order_out) {
+                                                           int64_t* __restrict__ order_out, float* gws, size_t gws_stride) {
   extern __shared__ float lds[];
-  float* ys = lds;                  // [L] labels by original index
-  float* xs = lds + L;              // [L] preds in sorted order (-inf for padded)
-  float* es = lds + 2 * L;          // [L] exp(xm) -> suffix sums C
-  float* qs = lds + 3 * L;          // [L] 1/(C+eps) -> prefix sums
-  int* pos = (int*)(lds + 4 * L);   // [L] shuffled position of original item i (inverse of perm)
-  int* ord = (int*)(lds + 5 * L);   // [L] original item index at sorted position r
+  float* base = GWS ? gws + (size_t)blockIdx.x * gws_stride : lds;
+  float* ys = base;                  // [L] labels by original index
+  float* xs = base + L;              // [L] preds in sorted order (-inf for padded)
+  float* es = base + 2 * L;          // [L] exp(xm) -> suffix sums C
+  float* qs = base + 3 * L;          // [L] 1/(C+eps) -> prefix sums
+  int* pos = (int*)(base + 4 * L);   // [L] shuffled position of original item i (inverse of perm)
+  int* ord = (int*)(base + 5 * L);   // [L] original item index at sorted position r
   __shared__ float red[LTRX_MAX_WAVES];
   __shared__ int redi[LTRX_MAX_WAVES];
   const int b = blockIdx.x;
@@ -112,18 +115,36 @@ __global__ void __launch_bounds__(1024) ltrx_listmle_kernel(const float* __restr
   }
 }
 
-extern "C" size_t ltrx_listmle_workspace_bytes(int B, int L) { (void)L; return (size_t)(B > 0 ? B : 0) * sizeof(float); }
+static size_t listmle_per_floats(int B) { return ((size_t)(B > 0 ? B : 0) + 3) & ~(size_t)3; }
+extern "C" size_t ltrx_listmle_workspace_bytes(int B, int L) {
+  return (listmle_per_floats(B) + ltrx_array_ws_floats(6, 0, B > 0 ? B : 0, L > 0 ? L : 0)) * sizeof(float);
+}
 
 extern "C" int ltrx_listmle_fwd_bwd(const float* y_pred, const float* y_true, const int64_t* perm, int B, int L,
                                     float eps, float pad_value, float batch_divisor, float* loss_out,
                                     float* per_slate_out, float* grad_out, int64_t* order_out, void* ws,
                                     ltrx_stream_t stream) {
   if (!y_pred || !y_true || !perm || !loss_out || !ws || B <= 0 || L <= 0 || !(batch_divisor > 0.f)) return LTRX_EINVAL;
-  if (L > LTRX_MAX_SLATE_LEN) return LTRX_EUNSUPPORTED;
+  if (L > LTRX_MAX_LONG_SLATE_LEN) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* per = (float*)ws;
-  hipLaunchKernelGGL(ltrx_listmle_kernel, dim3(B), dim3(L > 512 ? 1024 : 256), 6 * (size_t)L * sizeof(float),   /* long slates: 16 waves */ s, y_pred, y_true, perm, L,
-                     eps, pad_value, 1.0f / batch_divisor, per, per_slate_out, grad_out, order_out);
+  const dim3 block(L > 512 ? 1024 : 256);                /* long slates: 16 waves */
+  if (ltrx_arrays_in_lds(6, 0, L)) {
+    const size_t lds = 6 * (size_t)L * sizeof(float);
+    if (lds > 48 * 1024) {
+      static std::atomic<uint64_t> attr_done{0};
+      const int arc = ltrx_once_per_device(attr_done, []() {
+        return hipFuncSetAttribute((const void*)ltrx_listmle_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   LTRX_LDS_ARRAY_BUDGET_BYTES) == hipSuccess ? LTRX_OK : LTRX_EHIP;
+      });
+      if (arc != LTRX_OK) return arc;
+    }
+    hipLaunchKernelGGL(ltrx_listmle_kernel<false>, dim3(B), block, lds, s, y_pred, y_true, perm, L, eps, pad_value, 1.0f / batch_divisor,
+                       per, per_slate_out, grad_out, order_out, (float*)nullptr, (size_t)0);
+  } else {
+    hipLaunchKernelGGL(ltrx_listmle_kernel<true>, dim3(B), block, 0, s, y_pred, y_true, perm, L, eps, pad_value, 1.0f / batch_divisor, per,
+                       per_slate_out, grad_out, order_out, per + listmle_per_floats(B), ltrx_array_ws_stride(6, 0, L));
+  }
   LTRX_LAUNCH_CHECK();
   return ltrx_launch_finalize_sum(per, B, 1.0f / batch_divisor, loss_out, s);
 }

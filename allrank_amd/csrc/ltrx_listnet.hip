@@ -11,13 +11,17 @@
 
 using namespace ltrx;
 
+// GWS: the two work arrays live in a global workspace (slates too long for LDS; ltrx_device.h)
+template <bool GWS>
 __global__ void __launch_bounds__(256) ltrx_listnet_kernel(const float* __restrict__ y_pred,
                                                            const float* __restrict__ y_true, int L, float eps,
                                                            float pad, float inv_div, float* __restrict__ per_ws,
-                                                           float* __restrict__ per_out, float* __restrict__ grad) {
+                                                           float* __restrict__ per_out, float* __restrict__ grad,
+                                                           float* gws, size_t gws_stride) {
   extern __shared__ float lds[];
-  float* ps = lds;       // [L] exp(s - max)  -> P
-  float* ts = lds + L;   // [L] exp(y - max)  -> T
+  float* base = GWS ? gws + (size_t)blockIdx.x * gws_stride : lds;
+  float* ps = base;      // [L] exp(s - max)  -> P
+  float* ts = base + L;  // [L] exp(y - max)  -> T
   __shared__ float red[LTRX_MAX_WAVES];
   const int b = blockIdx.x;
   const float* sp = y_pred + (size_t)b * L;
@@ -74,17 +78,34 @@ __global__ void __launch_bounds__(256) ltrx_listnet_kernel(const float* __restri
   }
 }
 
-extern "C" size_t ltrx_listnet_workspace_bytes(int B, int L) { (void)L; return (size_t)(B > 0 ? B : 0) * sizeof(float); }
+static size_t listnet_per_floats(int B) { return ((size_t)(B > 0 ? B : 0) + 3) & ~(size_t)3; }
+extern "C" size_t ltrx_listnet_workspace_bytes(int B, int L) {
+  return (listnet_per_floats(B) + ltrx_array_ws_floats(2, 0, B > 0 ? B : 0, L > 0 ? L : 0)) * sizeof(float);
+}
 
 extern "C" int ltrx_listnet_fwd_bwd(const float* y_pred, const float* y_true, int B, int L, float eps, float pad_value,
                                     float batch_divisor, float* loss_out, float* per_slate_out, float* grad_out,
                                     void* ws, ltrx_stream_t stream) {
   if (!y_pred || !y_true || !loss_out || !ws || B <= 0 || L <= 0 || !(batch_divisor > 0.f)) return LTRX_EINVAL;
-  if (L > LTRX_MAX_SLATE_LEN) return LTRX_EUNSUPPORTED;
+  if (L > LTRX_MAX_LONG_SLATE_LEN) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   float* per = (float*)ws;
-  hipLaunchKernelGGL(ltrx_listnet_kernel, dim3(B), dim3(256), 2 * (size_t)L * sizeof(float), s, y_pred, y_true, L, eps,
-                     pad_value, 1.0f / batch_divisor, per, per_slate_out, grad_out);
+  if (ltrx_arrays_in_lds(2, 0, L)) {
+    const size_t lds = 2 * (size_t)L * sizeof(float);
+    if (lds > 48 * 1024) {                               // more than the default dynamic-LDS allowance: once per device
+      static std::atomic<uint64_t> attr_done{0};
+      const int arc = ltrx_once_per_device(attr_done, []() {
+        return hipFuncSetAttribute((const void*)ltrx_listnet_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   LTRX_LDS_ARRAY_BUDGET_BYTES) == hipSuccess ? LTRX_OK : LTRX_EHIP;
+      });
+      if (arc != LTRX_OK) return arc;
+    }
+    hipLaunchKernelGGL(ltrx_listnet_kernel<false>, dim3(B), dim3(256), lds, s, y_pred, y_true, L, eps, pad_value, 1.0f / batch_divisor,
+                       per, per_slate_out, grad_out, (float*)nullptr, (size_t)0);
+  } else {
+    hipLaunchKernelGGL(ltrx_listnet_kernel<true>, dim3(B), dim3(256), 0, s, y_pred, y_true, L, eps, pad_value, 1.0f / batch_divisor, per,
+                       per_slate_out, grad_out, per + listnet_per_floats(B), ltrx_array_ws_stride(2, 0, L));
+  }
   LTRX_LAUNCH_CHECK();
   return ltrx_launch_finalize_sum(per, B, 1.0f / batch_divisor, loss_out, s);
 }

@@ -39,7 +39,12 @@ extern "C" {
 #define LTRX_EUNSUPPORTED (-2)
 #define LTRX_EHIP (-1000)
 
-#define LTRX_MAX_SLATE_LEN 2048        /* loss kernels stage a slate (and its per-item work arrays) in LDS */
+#define LTRX_MAX_SLATE_LEN 2048        /* the loss kernels' tuned form: a slate and its per-item work arrays in LDS.  Every loss takes slates
+                                          up to here; the four hot losses (listNet, listMLE, approxNDCG, lambdaLoss) go on: */
+#define LTRX_MAX_LONG_SLATE_LEN 16384  /* ... their work arrays stay in LDS while they fit the CU's 160 KB (listNet: every length, listMLE
+                                          6.7 k, approxNDCG 5.8 k, lambdaLoss 3.1 k items) and move to the call's workspace beyond that
+                                          (same kernels through a global pointer; *_workspace_bytes(B, L) grows accordingly) -- the
+                                          reference pads a validation set to its longest slate, allrank/data/dataset_loading.py:185-194 */
 #define LTRX_MHA_DS_BUDGET_BYTES (2147483648ull) /* ltrx_mha_bwd, modes 1 / 2: the dS hand-over workspace is B h LK^2 floats (LK = L rounded
                                                     up to 64); a call that would need more than this runs the exact-fp32 kernels
                                                     (workspace B L h floats) instead -- ltrx_mha_bwd_workspace_bytes says which */

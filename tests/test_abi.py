@@ -49,7 +49,8 @@ def test_slate_length_limits_are_stated_once_and_reported(libpath):
     fake = ctypes.c_void_p(4096)                       # never dereferenced: the shape check comes first
     ats = (ctypes.c_int * 1)(5)
     assert lib.ltrx_ndcg_at(fake, fake, 1, _lib.MAX_METRIC_SLATE_LEN + 1, ats, 1, -1.0, 1.0, fake, None, None, None, None) == -2
-    assert lib.ltrx_listnet_fwd_bwd(fake, fake, 1, _lib.MAX_SLATE_LEN + 1, 1e-10, -1.0, 1.0, fake, None, None, fake, None) == -2
+    assert int(re.search(r"#define LTRX_MAX_LONG_SLATE_LEN (\d+)", src).group(1)) == _lib.MAX_LONG_SLATE_LEN
+    assert lib.ltrx_listnet_fwd_bwd(fake, fake, 1, _lib.MAX_LONG_SLATE_LEN + 1, 1e-10, -1.0, 1.0, fake, None, None, fake, None) == -2
     with pytest.raises(RuntimeError, match="LTRX_MAX_METRIC_SLATE_LEN = %d" % _lib.MAX_METRIC_SLATE_LEN):
         _lib.check(-2, "ndcg_at")
 

@@ -175,7 +175,8 @@ def test_ndcg_and_sort_indices(losses_golden):
 def test_metrics_on_validation_slates_longer_than_the_loss_limit():
     """validation sets are padded to their longest slate with no bound (dataset_loading.py:185-194): ndcg / mrr take slates of
     up to LTRX_MAX_METRIC_SLATE_LEN = 8192 items (values and stable sort indices == the oracle), beyond that -- and for a loss
-    beyond LTRX_MAX_SLATE_LEN = 2048 -- the call raises and the message names the limit (no silent fallback)."""
+    beyond its limit (LTRX_MAX_SLATE_LEN = 2048; LTRX_MAX_LONG_SLATE_LEN = 16384 for the four hot listwise losses) -- the call raises and
+    the message names the limit (no silent fallback)."""
     from allrank_amd import metrics as EM, losses as E, _lib as LB
     from tests.golden.make_inputs import make_inputs
     for (B, L, seed) in [(3, 3000, 5), (2, 8192, 6)]:
@@ -193,6 +194,9 @@ def test_metrics_on_validation_slates_longer_than_the_loss_limit():
         EM.ndcg(_t(s), _t(y), ats=[5])
     s, y = make_inputs(1, LB.MAX_SLATE_LEN + 1, 8)
     with pytest.raises(RuntimeError, match="LTRX_MAX_SLATE_LEN"):
+        E.neuralNDCG(_t(s, True), _t(y))
+    s, y = make_inputs(1, LB.MAX_LONG_SLATE_LEN + 1, 8)
+    with pytest.raises(RuntimeError, match="LTRX_MAX_LONG_SLATE_LEN"):
         E.listNet(_t(s, True), _t(y))
 
 
@@ -1352,19 +1356,44 @@ def test_fused_trainer_gradient_clipping_matches_clip_grad_norm():
         assert float((sd1[k] - sd2[k]).abs().max().item()) <= 1.01e-2, k
 
 
-def test_listwise_losses_at_the_maximum_slate_length():
-    """L = LTRX_MAX_SLATE_LEN (2048): the per-slate LDS working sets (up to 106 KB for lambdaLoss) and the partner-range split
-    still agree with the oracle."""
-    rng = np.random.default_rng(2048)
-    s = rng.standard_normal((2, 2048)).astype(np.float32)
-    y = rng.integers(0, 5, (2, 2048)).astype(np.float32)
-    y[1, 1500:] = -1
-    for kind, kw in [("lambdaloss", dict(weighing_scheme="lambdaRank_scheme", k=None)), ("lambdaloss", dict(weighing_scheme="ndcgLoss2PP_scheme", k=100)),
-                     ("approxndcg", dict(alpha=1.0)), ("listnet", {})]:
+@pytest.mark.parametrize("L", [2048, 3000, 4096, 7000])
+def test_listwise_losses_at_and_beyond_the_lds_slate_length(L):
+    """The reference's losses take any slate length (validation sets are padded to their longest slate, dataset_loading.py:185-194;
+    approxNDCG.py:7-53, listMLE.py:7-38, lambdaLoss.py:7-81, listNet.py:8-30).  L = 2048 is LTRX_MAX_SLATE_LEN: the per-slate LDS
+    working sets (106 KB for lambdaLoss) and the partner-range split.  Beyond it the four hot losses keep their work arrays in LDS
+    while they fit the CU's 160 KB and in the call's workspace after that: 3000 = lambdaLoss's last LDS length,
+    4096 = lambdaLoss in the workspace, 7000 = approxNDCG and listMLE in the workspace too.  All against the oracle."""
+    rng = np.random.default_rng(L)
+    B = 2
+    s = rng.standard_normal((B, L)).astype(np.float32)
+    y = rng.integers(0, 5, (B, L)).astype(np.float32)
+    y[1, (3 * L) // 4:] = -1
+    perm = rng.permutation(L)
+    jobs = [("lambdaloss", dict(weighing_scheme="lambdaRank_scheme", k=None)), ("lambdaloss", dict(weighing_scheme="ndcgLoss2PP_scheme", k=100)),
+            ("approxndcg", dict(alpha=1.0)), ("listnet", {}), ("listmle", dict(perm=perm))]
+    for kind, kw in jobs:
         l, g = _engine_loss(kind, kw, s, y)
         lo, go = _oracle_loss(kind, kw, s, y)
-        assert close(l, lo, rtol=3e-5), (kind, l, lo)
-        assert grad_close(g, go, rtol=5e-4), (kind, float(np.abs(g - go).max()))
+        assert close(l, lo, rtol=3e-5), (L, kind, l, lo)
+        assert grad_close(g, go, rtol=5e-4), (L, kind, float(np.abs(g - go).max()))
+
+
+def test_long_slate_workspace_form_equals_lds_form_inside_the_fused_loss():
+    """FusedLoss (the explicit training step's loss launcher) sizes its workspace through *_workspace_bytes(B, L): at L = 4096 the
+    lambdaLoss arrays are in that workspace; value and gradient equal the plugin call's"""
+    from allrank_amd import losses as E
+    rng = np.random.default_rng(11)
+    B, L = 3, 4096
+    s = rng.standard_normal((B, L)).astype(np.float32)
+    y = rng.integers(0, 5, (B, L)).astype(np.float32)
+    y[2, 100:] = -1
+    for name, kw in (("lambdaLoss", dict(weighing_scheme="lambdaRank_scheme")), ("approxNDCGLoss", {}), ("listNet", {})):
+        fl = E.FusedLoss(name, B, L, "cuda:0", **kw)
+        loss, grad = fl.run(_t(s), _t(y), float(B))
+        sp = _t(s, True)
+        l2 = getattr(E, name)(sp, _t(y), **kw)
+        l2.backward()
+        assert torch.equal(loss.reshape(()), l2.detach().reshape(())) and torch.equal(grad, sp.grad), name
 
 
 # ---------------------------------------------------------------------------------------------------------------------
