@@ -78,6 +78,9 @@ SIGNATURES = {
     "ltrx_selftest_mfma32x32x2": (_i, [_vp, _vp, _vp, _vp]),
     "ltrx_fc_listnet_supported": (_i, [_i, _i, _i]),
     "ltrx_fc_listnet_workspace_bytes": (_sz, [_i, _i, _i, _i, _sz]),
+    "ltrx_fc_linear_listnet_workspace_bytes": (_sz, [_i, _i]),
+    "ltrx_fc_linear_listnet_step": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _sz, _sz, _sz, _sz, _f, _f, _f, _vp, _vp, _vp, _vp,
+                                         _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _vp, _vp]),
     "ltrx_fc_listnet_step": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _sz, _sz, _sz, _sz, _f, _f, _f, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _f, _f, _f, _f, _f, _i, _vp, _vp]),
     "ltrx_mha_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, ctypes.c_uint32, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -101,6 +101,58 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// ListNet (allrank/models/losses/listNet.py:8-30) of ONE slate held one row per lane by waves 0-3 (row r = threadIdx.x < 256): value
+// (added to loss_acc on wave 0) and d loss / d score of this lane's row.  Every wave of the workgroup must call (two LDS barriers
+// inside).  Softmax statistics are combined across the four waves as (max, sum of exp(. - max)) pairs: S = sum_w S_w exp(m_w - M) --
+// the factor is exactly 1 for the wave that holds the maximum; P = exp(s - M) / S as the reference computes it.  red: 24 floats of LDS.
+__device__ __forceinline__ float listnet_rows(float s, float yy, bool in_range, int wave, int lane, float* red, float pad, float eps,
+                                              float inv_div, float& loss_acc) {
+  float sv = -INFINITY, yv = -INFINITY, P = 0.f, T = 0.f, rr = 0.f;
+  bool val = false;
+  if (wave < 4) {
+    val = in_range && (yy != pad);
+    sv = val ? s : -INFINITY;
+    yv = val ? yy : -INFINITY;
+    const float mw = wave_max(sv), myw = wave_max(yv);
+    const float e = val ? expf(sv - mw) : 0.f, f = val ? expf(yv - myw) : 0.f;
+    const float sw = wave_sum(e), syw = wave_sum(f);
+    if (lane == 0) *reinterpret_cast<f32x4*>(&red[4 * wave]) = f32x4{mw, sw, myw, syw};
+  }
+  lds_barrier();
+  if (wave < 4) {
+    f32x4 st[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) st[w] = *reinterpret_cast<const f32x4*>(&red[4 * w]);
+    const float M = fmaxf(fmaxf(st[0][0], st[1][0]), fmaxf(st[2][0], st[3][0]));
+    const float MY = fmaxf(fmaxf(st[0][2], st[1][2]), fmaxf(st[2][2], st[3][2]));
+    float S = 0.f, SY = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (st[w][1] > 0.f) S += st[w][1] * expf(st[w][0] - M);
+      if (st[w][3] > 0.f) SY += st[w][3] * expf(st[w][2] - MY);
+    }
+    const float inv_s = S > 0.f ? 1.0f / S : 0.f;            // fully padded slate: contributes 0 (reference: NaN)
+    const float inv_y = SY > 0.f ? 1.0f / SY : 0.f;
+    P = val ? expf(sv - M) * inv_s : 0.f;
+    T = val ? expf(yv - MY) * inv_y : 0.f;
+    rr = (P > 0.f) ? P / (P + eps) : 0.f;
+    const float lt = (T > 0.f) ? T * logf(P + eps) : 0.f;
+    const float lw = wave_sum(lt), rw = wave_sum(T * rr);
+    if (lane == 0) {
+      red[16 + 2 * wave] = lw;
+      red[17 + 2 * wave] = rw;
+    }
+  }
+  lds_barrier();
+  float g = 0.f;
+  if (wave < 4) {
+    const float R = (red[17] + red[19]) + (red[21] + red[23]);
+    g = (P * R - T * rr) * inv_div;                          // padded / beyond L: P = T = 0 -> exactly 0
+    if (wave == 0) loss_acc -= (red[16] + red[18]) + (red[20] + red[22]);
+  }
+  return g;
+}
+
 struct FcArgs {
   const float* x;         // [B, L, F]
   const float* y;         // [B, L]
@@ -383,60 +435,21 @@ __global__ void __launch_bounds__(768) ltrx_fc_listnet_kernel(const FcArgs a) {
     lds_barrier();
     FC_STAMP(it_, 4);
 
-    // ---- scores + ListNet (listNet.py:8-30) by waves 0-3, one row per lane.  Softmax statistics are combined across the four
-    //      waves as (max, sum of exp(. - max)) pairs: S = sum_w S_w exp(m_w - M) -- the factor is exactly 1 for the wave that holds the
-    //      maximum; P = exp(s - M) / S as the reference computes it ----
+    // ---- scores + ListNet (listNet.py:8-30) by waves 0-3, one row per lane ----
     {
-      float* red = misc;                                          // [4][4]: m_w, S_w, my_w, Sy_w;   [16 .. 24): lsum_w, rsum_w
-      float sv = -INFINITY, yv = -INFINITY, P = 0.f, T = 0.f, rr = 0.f;
-      bool val = false;
+      float sc_ = 0.f, yy_ = a.pad;
       const int r = tid_;
       if (wave < 4) {
-        float s = bout;
-        for (int q = 0; q < nhb; ++q) s += s_part[q * FC_ROWS + r];
-        const float yy = ybuf[r];
-        val = (r < L_) && (yy != a.pad);
-        if (r < L_) a.scores[(size_t)b * L_ + r] = s;
-        sv = val ? s : -INFINITY;
-        yv = val ? yy : -INFINITY;
-        const float mw = wave_max(sv), myw = wave_max(yv);
-        const float e = val ? expf(sv - mw) : 0.f, f = val ? expf(yv - myw) : 0.f;
-        const float sw = wave_sum(e), syw = wave_sum(f);
-        if (lane == 0) *reinterpret_cast<f32x4*>(&red[4 * wave]) = f32x4{mw, sw, myw, syw};
+        sc_ = bout;
+        for (int q = 0; q < nhb; ++q) sc_ += s_part[q * FC_ROWS + r];
+        yy_ = ybuf[r];
+        if (r < L_) a.scores[(size_t)b * L_ + r] = sc_;
       }
-      lds_barrier();
+      const float g = listnet_rows(sc_, yy_, r < L_, wave, lane, misc, a.pad, a.eps, a.inv_div, loss_acc);
       if (wave < 4) {
-        f32x4 st[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) st[w] = *reinterpret_cast<const f32x4*>(&red[4 * w]);
-        const float M = fmaxf(fmaxf(st[0][0], st[1][0]), fmaxf(st[2][0], st[3][0]));
-        const float MY = fmaxf(fmaxf(st[0][2], st[1][2]), fmaxf(st[2][2], st[3][2]));
-        float S = 0.f, SY = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          if (st[w][1] > 0.f) S += st[w][1] * expf(st[w][0] - M);
-          if (st[w][3] > 0.f) SY += st[w][3] * expf(st[w][2] - MY);
-        }
-        const float inv_s = S > 0.f ? 1.0f / S : 0.f;            // fully padded slate: contributes 0 (reference: NaN)
-        const float inv_y = SY > 0.f ? 1.0f / SY : 0.f;
-        P = val ? expf(sv - M) * inv_s : 0.f;
-        T = val ? expf(yv - MY) * inv_y : 0.f;
-        rr = (P > 0.f) ? P / (P + a.eps) : 0.f;
-        const float lt = (T > 0.f) ? T * logf(P + a.eps) : 0.f;
-        const float lw = wave_sum(lt), rw = wave_sum(T * rr);
-        if (lane == 0) {
-          red[16 + 2 * wave] = lw;
-          red[17 + 2 * wave] = rw;
-        }
-      }
-      lds_barrier();
-      if (wave < 4) {
-        const float R = (red[17] + red[19]) + (red[21] + red[23]);
-        const float g = (P * R - T * rr) * a.inv_div;             // padded / beyond L: P = T = 0 -> exactly 0
         dbuf[r] = g;
         if (a.dscores && r < L_) a.dscores[(size_t)b * L_ + r] = g;
         dbo += g;
-        if (wave == 0) loss_acc -= (red[16] + red[18]) + (red[20] + red[22]);
       }
     }
     FC_STAMP(it_, 5);
@@ -593,6 +606,268 @@ __global__ void __launch_bounds__(1024) ltrx_fc_reduce_kernel(const float* __res
   *reinterpret_cast<f32x4*>(ad.v + 4 * c4) = vv;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Linear scorer (FC activation None): score = w_out . (W1 x + b1) + b_out = x . v + c with v = W1^T w_out, c = w_out . b1 + b_out --
+// two consecutive linear maps are one, exactly.  The gradients keep that structure:
+//   u = sum_{slates, l} dscore_l x_l,  D = sum dscore_l   =>   dW1 = w_out (x) u,  db1 = D w_out,  dw_out = W1 u + D b1,  db_out = D,
+// so a slate needs two matrix-VECTOR products (fp32 FMAs, no split, no matrix cores) and a workgroup's partial gradient is F + 2
+// floats.  The slate never touches LDS: thread (c4, r0) keeps the float4 column group c4 of rows r0, r0 + RPT, ... (RPT = 768 / (F/4)
+// rows per pass) in registers -- 44 VGPRs at 240 x 136 -- next to the SAME registers of the next slate, whose loads are issued before
+// the current slate is processed: the kernel streams x at the rate one CU can pull from HBM.  Row sums go through a small LDS table
+// in a fixed order (deterministic); ListNet is the four-wave routine of the MFMA kernel.
+// This is an opt-in specialisation (FusedTrainer(fc_step="collapse")): the default for an FCModel + listNet job is the MFMA kernel
+// above, which evaluates the two layers as the reference does and also covers ReLU.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int FL_KMAX = 13;                  // rows per thread at the largest shape (256 rows, 36 column groups, 21 rows per pass)
+constexpr int FL_PSTRIDE = 37;               // row stride of the partial-dot table (floats): odd -> conflict-free row sums
+constexpr size_t FL_SMEM = (size_t)(FC_ROWS * FL_PSTRIDE + 3 * FC_ROWS + 64 + FC_MAXF) * sizeof(float) + 48 * 36 * sizeof(f32x4);
+
+struct FlArgs {
+  const float* x;
+  const float* y;
+  const float* w1;
+  const float* b1;
+  const float* wout;
+  const float* bout;
+  float* scores;
+  float* dscores;
+  float* slab;          // [gridDim.x][F + 4 + H4]: u[F], D, loss, 0, 0, (W1 u + D b1)[H4]
+  float* wout_snapshot; // [H]: w_out as this step read it
+  float* step_count;
+  int B, L, F, H;
+  float eps, pad, inv_div;
+};
+
+// KMAX: rows per thread (ceil(L / RPT)): 11 covers the WEB30K shape (240 rows, 34 column groups), FL_KMAX every supported one
+template <int KMAX>
+__global__ void __launch_bounds__(768) ltrx_fc_linear_listnet_kernel(const FlArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* part = reinterpret_cast<float*>(smem);                 // [256][37] partial dots
+  float* ybuf = part + FC_ROWS * FL_PSTRIDE;
+  float* dbuf = ybuf + FC_ROWS;
+  float* sbuf = dbuf + FC_ROWS;
+  float* misc = sbuf + FC_ROWS;                                 // 64 floats: softmax statistics, final combines
+  float* vbuf = misc + 64;                                      // [F] v = W1^T w_out
+  f32x4* ured = reinterpret_cast<f32x4*>(vbuf + FC_MAXF);       // [rpt][nc4] at the end
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int L = a.L, F = a.F, H = a.H, nc4 = F >> 2;
+  const int rpt = 768 / nc4;                                    // rows per pass
+  const int c4 = tid % nc4, r0 = tid / nc4;
+  const bool active = r0 < rpt;
+  if (a.step_count && blockIdx.x == 0 && tid == 0) a.step_count[0] += 1.0f;
+
+  f32x4 xa[KMAX], xb[KMAX];
+  float ya = a.pad, yb = a.pad;                                 // label of row `tid` of the slate in xa / xb (requested with it: a load
+                                                                // issued later would make its wait cover the whole prefetch, vmcnt is in order)
+  auto load = [&](f32x4 (&xr)[KMAX], float& yr, int bb) {
+    int r0_ = r0, L_ = L;                                       // (opaque copies: keep the per-row predicates / addresses out of scratch)
+    asm volatile("" : "+v"(r0_), "+s"(L_));
+    const float* xs = a.x + (size_t)bb * L * F + 4 * c4;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int r = r0_ + rpt * k;
+      xr[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (active && bb < a.B && r < L_) xr[k] = *reinterpret_cast<const f32x4*>(xs + (size_t)r * F);
+    }
+    yr = a.pad;
+    if (bb < a.B && tid < L_) yr = a.y[(size_t)bb * L + tid];
+  };
+  load(xa, ya, blockIdx.x);
+  // v = W1^T w_out, c = w_out . b1 + b_out: 768 / F groups of F threads, each group a slice of the hidden units with all its loads in
+  // flight at once (one thread per feature looping over H dependent loads cost 40 us per launch), combined in a fixed order
+  {
+    float* wo_s = part;                                         // [H] w_out, [H] b1 (the partial-dot table is free before the first slate)
+    float* b1_s = part + FC_MAXH;
+    float* vpart = part + 2 * FC_MAXH;                          // [ngrp][F]
+    for (int n = tid; n < H; n += 768) {
+      wo_s[n] = a.wout[n];
+      b1_s[n] = a.b1[n];
+      if (blockIdx.x == 0) a.wout_snapshot[n] = wo_s[n];         // (the finishing launch updates w_out while other workgroups still need it)
+    }
+    __syncthreads();
+    const int ngrp = 768 / F, grp = tid / F, f = tid - grp * F;
+    const int chunk = (H + ngrp - 1) / ngrp;
+    if (grp < ngrp) {
+      float acc = 0.f;
+      const int n0 = grp * chunk, n1 = min(H, n0 + chunk);
+#pragma unroll 8
+      for (int n = n0; n < n1; ++n) acc += wo_s[n] * a.w1[(size_t)n * F + f];
+      vpart[grp * F + f] = acc;
+    }
+    __syncthreads();
+    for (int ff = tid; ff < F; ff += 768) {
+      float acc = vpart[ff];
+      for (int g = 1; g < ngrp; ++g) acc += vpart[g * F + ff];
+      vbuf[ff] = acc;
+    }
+  }
+  float cc = a.bout[0];
+  for (int n = 0; n < H; ++n) cc += part[n] * part[FC_MAXH + n];        // (LDS broadcast reads: every thread the same sum, same order)
+  __syncthreads();
+  const f32x4 v4 = active ? *reinterpret_cast<const f32x4*>(vbuf + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 u4 = {0.f, 0.f, 0.f, 0.f};
+  float dsum = 0.f, loss_acc = 0.f;
+
+  auto slate = [&](const f32x4 (&xr)[KMAX], float yr, int b) {
+    if (tid < FC_ROWS) ybuf[tid] = yr;
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        const int r = r0 + rpt * k;
+        if (r < L) part[r * FL_PSTRIDE + c4] = (xr[k][0] * v4[0] + xr[k][1] * v4[1]) + (xr[k][2] * v4[2] + xr[k][3] * v4[3]);
+      }
+    }
+    lds_barrier();
+    float sc = 0.f, yy = a.pad;
+    if (wave < 4) {
+      const int r = tid;
+      sc = cc;
+      if (r < L)
+        for (int q = 0; q < nc4; ++q) sc += part[r * FL_PSTRIDE + q];
+      yy = ybuf[r];
+      if (r < L) a.scores[(size_t)b * L + r] = sc;
+    }
+    const float g = listnet_rows(sc, yy, tid < L, wave, lane, misc, a.pad, a.eps, a.inv_div, loss_acc);
+    if (wave < 4) {
+      dbuf[tid] = g;
+      if (a.dscores && tid < L) a.dscores[(size_t)b * L + tid] = g;
+      dsum += g;
+    }
+    lds_barrier();
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        const int r = r0 + rpt * k;
+        if (r < L) {
+          const float d = dbuf[r];
+          u4[0] += d * xr[k][0]; u4[1] += d * xr[k][1]; u4[2] += d * xr[k][2]; u4[3] += d * xr[k][3];
+        }
+      }
+    }
+    lds_barrier();                                              // part / dbuf / ybuf are free for the next slate
+  };
+
+  for (int b = blockIdx.x; b < a.B; b += 2 * gridDim.x) {
+    load(xb, yb, b + gridDim.x);                                // next slate in flight while this one is processed
+    slate(xa, ya, b);
+    if (b + (int)gridDim.x < a.B) {
+      load(xa, ya, b + 2 * gridDim.x);
+      slate(xb, yb, b + gridDim.x);
+    }
+  }
+
+  // ---- one partial per workgroup: u summed over the row groups in a fixed order, D, the loss ----
+  if (active) ured[r0 * nc4 + c4] = u4;
+  if (wave < 4) {
+    const float t = wave_sum(dsum);
+    if (lane == 0) misc[32 + wave] = t;
+  }
+  __syncthreads();
+  const int H4 = (H + 3) & ~3, sstride = F + 4 + H4;
+  float* slab = a.slab + (size_t)blockIdx.x * sstride;
+  if (tid < nc4) {
+    f32x4 t = ured[tid];
+    for (int q = 1; q < rpt; ++q) t += ured[q * nc4 + tid];
+    *reinterpret_cast<f32x4*>(slab + 4 * tid) = t;
+    *reinterpret_cast<f32x4*>(vbuf + 4 * tid) = t;              // (v is dead: the workgroup's u for the product below)
+  }
+  const float Dw = (misc[32] + misc[33]) + (misc[34] + misc[35]);
+  if (tid == 0) {
+    slab[F] = Dw;
+    slab[F + 1] = loss_acc;
+    slab[F + 2] = 0.f;
+    slab[F + 3] = 0.f;
+  }
+  __syncthreads();
+  // this workgroup's share of dw_out = W1 u + D b1 (linear in (u, D), so the shares add up): 8 threads per hidden unit, 1 / 8 of the
+  // features each, combined in a fixed order -- the W1 loads of all units are in flight at once
+  {
+    float* rpart = part;                                        // [8][H]
+    const int n = tid % FC_MAXH, sl = tid / FC_MAXH;            // 768 = 8 x 96
+    if (n < H) {
+      const int fchunk = (F + 7) / 8, f0 = sl * fchunk, f1 = min(F, f0 + fchunk);
+      float acc = 0.f;
+#pragma unroll 6
+      for (int f = f0; f < f1; ++f) acc += a.w1[(size_t)n * F + f] * vbuf[f];
+      rpart[sl * FC_MAXH + n] = acc;
+    }
+    __syncthreads();
+    if (tid < H4) {
+      float acc = 0.f;
+      if (tid < H) {
+        acc = rpart[tid];
+        for (int q = 1; q < 8; ++q) acc += rpart[q * FC_MAXH + tid];
+        acc += a.b1[tid] * Dw;
+      }
+      slab[F + 4 + tid] = acc;
+    }
+  }
+}
+
+// partials -> (u, D, loss, W1 u + D b1) -> the four gradients of the flat layout (dW1 = w_out (x) u, db1 = D w_out, dw_out, db_out = D).
+// Every workgroup re-reduces the (tiny) partials in a fixed order.
+__global__ void __launch_bounds__(1024) ltrx_fc_linear_finish_kernel(const float* __restrict__ slab, int nwg, int F, int H, int off_b1,
+                                                                      int off_wout, int off_bout, int nflat, float* __restrict__ grads,
+                                                                      float* __restrict__ loss_out, float inv_div, const FcAdam ad,
+                                                                      const float* __restrict__ wo) {
+  // every workgroup re-reduces the (tiny) partials -- nwg x (F + 4 + H4) floats -- in a fixed order, forms the gradients of its
+  // 1024 flat entries (w_out from the step's snapshot, never from `params`, which other workgroups are updating) and applies the
+  // optimizer to them in the same pass
+  __shared__ __attribute__((aligned(16))) float tot[FC_MAXF + 4 + FC_MAXH];
+  __shared__ f32x4 psum[16][(FC_MAXF + 4 + FC_MAXH) / 4];
+  const int tid = threadIdx.x;
+  const int H4 = (H + 3) & ~3, sstride = F + 4 + H4;
+  {
+    const int nc = sstride >> 2, col = tid % nc, gq = tid / nc;
+    const int ng = (1024 / nc) < 16 ? (1024 / nc) : 16;        // complete groups of nc threads (nc <= 61): all loads in flight at once
+    if (gq < ng) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+      for (int g = gq; g < nwg; g += ng) acc += *reinterpret_cast<const f32x4*>(slab + (size_t)g * sstride + 4 * col);
+      psum[gq][col] = acc;
+    }
+    __syncthreads();
+    if (tid < nc) {
+      f32x4 t = psum[0][tid];
+      for (int q = 1; q < ng; ++q) t += psum[q][tid];          // fixed order
+      *reinterpret_cast<f32x4*>(&tot[4 * tid]) = t;
+    }
+    __syncthreads();
+  }
+  const float D = tot[F];
+  if (blockIdx.x == 0 && tid == 0) loss_out[0] = tot[F + 1] * inv_div;
+  const int i = blockIdx.x * 1024 + tid;
+  if (i >= nflat) return;
+  float g;
+  if (i < off_b1) {
+    const int n = i / F, f = i - n * F;
+    g = wo[n] * tot[f];
+  } else if (i < off_wout) {
+    const int n = i - off_b1;
+    g = (n < H) ? wo[n] * D : 0.f;
+  } else if (i < off_bout) {
+    const int n = i - off_wout;
+    g = (n < H) ? tot[F + 4 + n] : 0.f;
+  } else {
+    g = (i == off_bout) ? D : 0.f;
+  }
+  grads[i] = g;
+  if (!ad.p) return;
+  const float l2 = ad.decoupled ? 0.f : ad.wd, shrink = ad.decoupled ? 1.0f - ad.lr * ad.wd : 1.0f;
+  const float ts = ad.step[0];
+  const float bc1 = 1.0f - powf(ad.b1, ts);
+  const float bc2s = sqrtf(1.0f - powf(ad.b2, ts));
+  const float step_size = ad.lr / bc1;
+  const float pp = ad.p[i];
+  const float gr = g * 1.0f + l2 * pp;
+  const float mm = ad.b1 * ad.m[i] + (1.0f - ad.b1) * gr;
+  const float vv = ad.b2 * ad.v[i] + (1.0f - ad.b2) * gr * gr;
+  ad.m[i] = mm;
+  ad.v[i] = vv;
+  ad.p[i] = pp * shrink - step_size * (mm / (sqrtf(vv) / bc2s + ad.eps));
+}
+
+std::atomic<uint64_t> g_fl_attr{0};
 std::atomic<uint64_t> g_fc_attr{0};
 
 int fc_workgroups(int B) {
@@ -700,6 +975,76 @@ extern "C" int ltrx_fc_listnet_step(const float* x, const float* y, int B, int L
   const int n4 = (int)(nflat >> 2) + 1;
   hipLaunchKernelGGL(ltrx_fc_reduce_kernel, dim3((n4 + 15) / 16), dim3(1024), 0, s, (const float*)ws, nwg, a.stride, (int)nflat, grads,
                      loss_out, 1.0f / batch_divisor, ad);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+extern "C" size_t ltrx_fc_linear_listnet_workspace_bytes(int B, int F) {
+  if (B <= 0 || F <= 0) return 0;
+  const size_t nwg = (size_t)(B < 1024 ? B : 1024);
+  return (nwg * (size_t)(F + 4 + FC_MAXH) + FC_MAXH) * sizeof(float);
+}
+
+extern "C" int ltrx_fc_linear_listnet_step(const float* x, const float* y, int B, int L, int F, int H, float* params, size_t off_w1,
+                                           size_t off_b1, size_t off_wout, size_t off_bout, size_t nflat, float eps, float pad_value,
+                                           float batch_divisor, float* scores, float* dscores, float* loss_out, float* grads,
+                                           float* exp_avg, float* exp_avg_sq, float* step_count, float lr, float beta1, float beta2,
+                                           float adam_eps, float weight_decay, int decoupled, void* ws, ltrx_stream_t stream) {
+  if (!x || !y || !params || !scores || !loss_out || !grads || !ws || B <= 0 || !(batch_divisor > 0.f)) return LTRX_EINVAL;
+  if (!ltrx_fc_listnet_supported(L, F, H)) return LTRX_EUNSUPPORTED;
+  const size_t H4 = ((size_t)H + 3) & ~(size_t)3;
+  if (off_w1 != 0 || off_b1 != (size_t)H * F || off_wout != off_b1 + H4 || off_bout != off_wout + H4 || nflat != off_bout + 4)
+    return LTRX_EINVAL;
+  if ((((uintptr_t)x | (uintptr_t)params | (uintptr_t)grads | (uintptr_t)ws) & 15)) return LTRX_EINVAL;
+  if (exp_avg && (!exp_avg_sq || !step_count)) return LTRX_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = ltrx_once_per_device(g_fl_attr, []() -> int {
+    if (hipFuncSetAttribute((const void*)ltrx_fc_linear_listnet_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL_SMEM) != hipSuccess)
+      return LTRX_EHIP;
+    return hipFuncSetAttribute((const void*)ltrx_fc_linear_listnet_kernel<FL_KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FL_SMEM) ==
+                   hipSuccess ? LTRX_OK : LTRX_EHIP;
+  });
+  if (rc != LTRX_OK) return rc;
+  FlArgs a;
+  a.x = x;
+  a.y = y;
+  a.w1 = params + off_w1;
+  a.b1 = params + off_b1;
+  a.wout = params + off_wout;
+  a.bout = params + off_bout;
+  a.scores = scores;
+  a.dscores = dscores;
+  a.slab = (float*)ws;
+  a.wout_snapshot = (float*)ws + (size_t)fc_workgroups(B) * (size_t)(F + 4 + (((size_t)H + 3) & ~(size_t)3));
+  a.step_count = exp_avg ? step_count : nullptr;
+  a.B = B;
+  a.L = L;
+  a.F = F;
+  a.H = H;
+  a.eps = eps;
+  a.pad = pad_value;
+  a.inv_div = 1.0f / batch_divisor;
+  const int nwg = fc_workgroups(B);
+  const int rpt = 768 / (F >> 2);
+  if ((L + rpt - 1) / rpt <= 11)
+    hipLaunchKernelGGL(ltrx_fc_linear_listnet_kernel<11>, dim3(nwg), dim3(768), FL_SMEM, s, a);
+  else
+    hipLaunchKernelGGL(ltrx_fc_linear_listnet_kernel<FL_KMAX>, dim3(nwg), dim3(768), FL_SMEM, s, a);
+  LTRX_LAUNCH_CHECK();
+  FcAdam ad;
+  ad.p = exp_avg ? params : nullptr;
+  ad.m = exp_avg;
+  ad.v = exp_avg_sq;
+  ad.step = step_count;
+  ad.lr = lr;
+  ad.b1 = beta1;
+  ad.b2 = beta2;
+  ad.eps = adam_eps;
+  ad.wd = weight_decay;
+  ad.decoupled = decoupled;
+  hipLaunchKernelGGL(ltrx_fc_linear_finish_kernel, dim3((unsigned)((nflat + 1023) / 1024)), dim3(1024), 0, s, (const float*)ws, nwg, F, H,
+                     (int)off_b1, (int)off_wout, (int)off_bout, (int)nflat, grads, loss_out, 1.0f / batch_divisor, ad,
+                     (const float*)a.wout_snapshot);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }

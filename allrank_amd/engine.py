@@ -106,7 +106,9 @@ class FusedTrainer(object):
         fc_step=True: a model that is FCModel([H]) -> OutputLayer(H, 1) with the listNet loss (BASELINE configs[1]) trains through
         the slate-resident step of ltrx_fc_listnet_step -- forward, loss, backward and Adam in two launches that read the batch
         from HBM once, straight from the caller's tensors (no staging copy, no hipGraph needed); False keeps the GEMM launch
-        sequence for A/B runs.  ``self.fcstep`` tells which one is active."""
+        sequence for A/B runs; "collapse" (opt-in, FC activation None only): the linear scorer's two layers evaluated as ONE
+        matrix-vector product per slate with the exact rank-1 gradients (ltrx_fc_linear_listnet_step: fp32 FMAs, the slate in registers,
+        HBM-bound).  ``self.fcstep`` tells which one is active (False / True / "collapse")."""
         import torch.nn as nn
         from . import _lib as LB
         from .losses import FusedLoss
@@ -400,6 +402,8 @@ class FusedTrainer(object):
             and self.p_fc == 0.0 and self.n_out == 1 and self.out_act == 0 and loss_name == "listNet" and not compact
             and gemm == "split_bf16" and optimizer in ("Adam", "AdamW")
             and self.lib.ltrx_fc_listnet_supported(L, self.fc_sizes[0], self.fc_sizes[1]))
+        if self.fcstep and fc_step == "collapse" and self.fc_act == 0:
+            self.fcstep = "collapse"
         if self.fcstep:
             F_, H_ = self.fc_sizes[0], self.fc_sizes[1]
             H4 = (H_ + 3) // 4 * 4
@@ -409,6 +413,9 @@ class FusedTrainer(object):
             P = LB.ptr
             self._fc_a = (B, L, F_, H_, self.fc_act, P(self.flat_p), offs_fc[0], offs_fc[1], offs_fc[2], offs_fc[3], self.nflat,
                           float(self.loss.eps), float(self.loss.pad))
+            if self.fcstep == "collapse":
+                self._fc_ws = torch.empty(max(self.lib.ltrx_fc_linear_listnet_workspace_bytes(B, F_), 64), dtype=torch.uint8, device=dev)
+                self._fc_a = self._fc_a[:4] + self._fc_a[5:]          # (no activation argument)
             self._fc_b = (P(self.scores_raw), P(self.loss.grad))
 
     # ---- thin launch helpers -----------------------------------------------------------------------------------
@@ -929,9 +936,13 @@ class FusedTrainer(object):
                    float(self.eps), self.weight_decay, 1 if self.optimizer == "AdamW" else 0)
         else:
             opt = (None, None, None, 0.0, 0.0, 0.0, 0.0, 0.0, 0)
-        LB.check(self.lib.ltrx_fc_listnet_step(P(xb), P(yb), *self._fc_a, div, self._fc_b[0], self._fc_b[1] if self.keep_loss_grad else None,
-                                               hid, P(self.loss.loss), P(self.flat_g), *opt,
-                                               P(self._fc_ws), self._st()), "fc_listnet_step")
+        dsc = self._fc_b[1] if self.keep_loss_grad else None
+        if self.fcstep == "collapse":
+            LB.check(self.lib.ltrx_fc_linear_listnet_step(P(xb), P(yb), *self._fc_a, div, self._fc_b[0], dsc, P(self.loss.loss), P(self.flat_g),
+                                                          *opt, P(self._fc_ws), self._st()), "fc_linear_listnet_step")
+        else:
+            LB.check(self.lib.ltrx_fc_listnet_step(P(xb), P(yb), *self._fc_a, div, self._fc_b[0], dsc, hid, P(self.loss.loss), P(self.flat_g),
+                                                   *opt, P(self._fc_ws), self._st()), "fc_listnet_step")
         if not fused_adam:
             if self.world > 1 and self.comm_enabled:
                 import torch.distributed as dist

@@ -571,6 +571,35 @@ def main():
                 del tl, ml, xl, yl, il
             except Exception as e:
                 out["large_batch_2048_slates"] = "failed: %r" % (e,)
+            if w.get("fc_activation") is None:
+                # opt-in specialisation for a LINEAR scorer (FC activation None, as this workload is specified): the two linear layers
+                # evaluated as one matrix-vector product per slate with the exact rank-1 gradients (ltrx_fc_linear_listnet_step) --
+                # fp32 FMAs, slate in registers, HBM-bound.  Reported beside `value`, never as `value`.
+                try:
+                    rec = {}
+                    for Bc in (B, 2048):
+                        xc, yc, ic = synth_batch(2 * Bc, L, w["n_features"], 777, device)
+                        mc = build_model(w, device, args.dropout)
+                        tc = FusedTrainer(mc, w["loss"], w.get("loss_args", {}), Bc, L, lr=1e-3, world_size=1, use_graph=False, gemm=args.gemm,
+                                          fc_step="collapse")
+                        assert tc.fcstep == "collapse"
+                        for i in range(6):
+                            tc.step(xc[(i % 2) * Bc:(i % 2 + 1) * Bc], yc[(i % 2) * Bc:(i % 2 + 1) * Bc], ic[(i % 2) * Bc:(i % 2 + 1) * Bc])
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for i in range(40):
+                            tc.step(xc[(i % 2) * Bc:(i % 2 + 1) * Bc], yc[(i % 2) * Bc:(i % 2 + 1) * Bc], ic[(i % 2) * Bc:(i % 2 + 1) * Bc])
+                        torch.cuda.synchronize()
+                        tsec = (time.perf_counter() - t0) / 40
+                        byc = float(4 * w["n_features"] + 8) * Bc * L
+                        rec["slates_%d" % Bc] = {"value": round(Bc * L / tsec, 1), "us_per_step": round(tsec * 1e6, 1),
+                                                 "achieved_gbps": round(byc / tsec / 1e9, 1), "hbm_roofline_frac": round(byc / tsec / 1e9 / PEAK_HBM_GBPS, 4)}
+                        del tc, mc, xc, yc, ic
+                    rec["what"] = ("FusedTrainer(fc_step='collapse'): score = x . (W1^T w_out) + c, dW1 = w_out (x) u -- exact algebra of a linear "
+                                   "scorer, fp32 FMAs, no matrix cores; parity: tests/test_gpu_fcstep.py::test_fc_linear_listnet_step_*")
+                    out["linear_scorer_collapse"] = rec
+                except Exception as e:
+                    out["linear_scorer_collapse"] = "failed: %r" % (e,)
             try:           # A/B: the same workload through the GEMM launch sequence (FusedTrainer(fc_step=False), hipGraph)
                 mg = build_model(w, device, args.dropout)
                 tg = FusedTrainer(mg, w["loss"], w.get("loss_args", {}), B, L, lr=1e-3, world_size=1, use_graph=True, gemm=args.gemm, fc_step=False)

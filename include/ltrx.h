@@ -372,6 +372,19 @@ int ltrx_fc_listnet_step(const float* x, const float* y, int B, int L, int F, in
                          float* exp_avg, float* exp_avg_sq, float* step_count, float lr, float beta1, float beta2, float adam_eps,
                          float weight_decay, int decoupled, void* ws, ltrx_stream_t stream);
 
+/* The same step for a LINEAR scorer (FC activation None), opt-in: score = w_out . (W1 x + b1) + b_out = x . v + c with v = W1^T w_out --
+ * two consecutive linear maps evaluated as one, exactly -- and dW1 = w_out (x) u, db1 = D w_out, dw_out = W1 u + D b1, db_out = D with
+ * u = sum dscore_l x_l, D = sum dscore_l.  Per slate two matrix-vector products in fp32 FMAs (no matrix cores, no operand split); the
+ * slate is held in registers, the next one is in flight while it is processed; a workgroup's partial gradient is F + 2 floats.  Same
+ * arguments, layout of `params` / `grads`, outputs and optimizer semantics as ltrx_fc_listnet_step (without `act` / hidden_out).
+ * Two launches (slates; partials -> gradients + optimizer).  allrank_amd/csrc/ltrx_fcstep.hip. */
+size_t ltrx_fc_linear_listnet_workspace_bytes(int B, int F);
+int ltrx_fc_linear_listnet_step(const float* x, const float* y, int B, int L, int F, int H, float* params, size_t off_w1, size_t off_b1,
+                                size_t off_wout, size_t off_bout, size_t nflat, float eps, float pad_value, float batch_divisor,
+                                float* scores, float* dscores, float* loss_out, float* grads, float* exp_avg, float* exp_avg_sq,
+                                float* step_count, float lr, float beta1, float beta2, float adam_eps, float weight_decay,
+                                int decoupled, void* ws, ltrx_stream_t stream);
+
 /* On-device batch assembly for a CSR training set resident in HBM (allrank_amd/csrc/ltrx_data.hip):
  *   ltrx_fixlength_positions: FixLength (dataset_loading.py:32-93) for the B slates `slates` of a batch: positions[b][l] = the
  *       position inside slate b that fills slot l, -1 = padding.  Short slates are padded (:81-93); slates of >= L items are

@@ -41,7 +41,7 @@ def _batch(rng, B, L, F, ragged):
     return x, y
 
 
-def _run(B, L, F, H, act, seed, steps=3, optimizer="Adam", weight_decay=0.0, clip=None, global_batch=None):
+def _run(B, L, F, H, act, seed, steps=3, optimizer="Adam", weight_decay=0.0, clip=None, global_batch=None, fc_step=True):
     from allrank_amd.engine import FusedTrainer
     cfg = dict(n_features=F, fc_sizes=[H], fc_activation=act, fc_input_norm=False, N=0, d_ff=0, h=1, output_activation=None)
     m1, params = _build(cfg, seed)
@@ -51,10 +51,10 @@ def _run(B, L, F, H, act, seed, steps=3, optimizer="Adam", weight_decay=0.0, cli
     mask = y == -1
     xt, yt = torch.tensor(x, device=DEV), torch.tensor(y, device=DEV)
     kw = dict(lr=1e-3, use_graph=False, optimizer=optimizer, weight_decay=weight_decay, gradient_clipping_norm=clip)
-    f1 = FusedTrainer(m1, "listNet", {}, B, L, fc_step=True, **kw)
+    f1 = FusedTrainer(m1, "listNet", {}, B, L, fc_step=fc_step, **kw)
     cross = (H % 4 == 0)                       # (the GEMM launch sequence needs H % 4 == 0)
     f2 = FusedTrainer(m2, "listNet", {}, B, L, fc_step=False, **kw) if cross else None
-    assert f1.fcstep and (f2 is None or not f2.fcstep)
+    assert f1.fcstep == fc_step and (f2 is None or not f2.fcstep)
     f1.keep_fc_out = f1.keep_loss_grad = True
     keys = list(params)
     n1, n2 = dict(m1.named_parameters()), dict(m2.named_parameters())
@@ -77,7 +77,7 @@ def _run(B, L, F, H, act, seed, steps=3, optimizer="Adam", weight_decay=0.0, cli
         lo = float(lo_rows) * ok_rows.sum() / div
         gfull = np.zeros_like(so)
         gfull[ok_rows] = np.asarray(gs, dtype=np.float64) * ok_rows.sum() / div
-        fc_pats = [(f1.fc_out[0] > 0).view(B, L, -1).cpu().numpy()] if act == "ReLU" else None
+        fc_pats = [(f1.fc_out[0] > 0).view(B, L, -1).cpu().numpy()] if act == "ReLU" else None      # (collapse: act is None)
         g_or = M.backward(w_before, cfg, cache, gfull, relu_masks=[], fc_relu_masks=fc_pats)
         worst["oloss"] = max(worst["oloss"], abs(l1 - lo) / (1 + abs(lo)))
         worst["oscore"] = max(worst["oscore"], float(np.abs(s1 - so)[~mask].max()) / sc)
@@ -131,6 +131,26 @@ CASES = [(6, 16, 20, 16, None), (6, 100, 64, 48, "ReLU"), (7, 240, 136, 96, None
 @pytest.mark.parametrize("B,L,F,H,act", CASES)
 def test_fc_listnet_step_matches_fp64_oracle_and_gemm_path(B, L, F, H, act):
     _assert(_run(B, L, F, H, act, seed=100 + L + F), (B, L, F, H, act))
+
+
+@pytest.mark.parametrize("B,L,F,H", [(6, 16, 20, 16), (7, 240, 136, 96), (6, 256, 144, 96), (9, 37, 136, 80), (6, 129, 128, 33), (6, 17, 8, 96),
+                                     (300, 240, 136, 96), (700, 240, 136, 96)])
+def test_fc_linear_listnet_step_matches_fp64_oracle_and_gemm_path(B, L, F, H):
+    """the opt-in linear-scorer form (FC activation None; ltrx_fc_linear_listnet_step): one matrix-vector product per slate and the exact
+    rank-1 gradients -- same bars as the two-layer evaluation, incl. the fused optimizer update and B > 256 (several slates per
+    workgroup, register double-buffering)"""
+    _assert(_run(B, L, F, H, None, seed=300 + L + F, fc_step="collapse"), (B, L, F, H, "collapse"))
+    if B == 7:
+        _assert(_run(B, L, F, H, None, seed=41, fc_step="collapse", optimizer="AdamW", weight_decay=0.01), "collapse AdamW")
+        _assert(_run(B, L, F, H, None, seed=42, fc_step="collapse", clip=0.05, global_batch=20), "collapse clip + divisor")
+
+
+def test_fc_linear_collapse_is_only_taken_for_a_linear_scorer():
+    from allrank_amd.engine import FusedTrainer
+    cfg = dict(n_features=136, fc_sizes=[96], fc_activation="ReLU", fc_input_norm=False, N=0, d_ff=0, h=1, output_activation=None)
+    m, _p = _build(cfg, 3)
+    ft = FusedTrainer(m, "listNet", {}, 4, 240, lr=1e-3, use_graph=False, fc_step="collapse")
+    assert ft.fcstep is True                                   # ReLU: the two-layer MFMA kernel
 
 
 @pytest.mark.parametrize("B,act", [(300, None), (700, "ReLU")])

@@ -111,7 +111,10 @@ def timing(B, L=240, F=136, H=96, act=None, steps=200):
     x, y = batch(rng, nb * B, L, F, [])
     xt, yt = torch.tensor(x, device=DEV), torch.tensor(y, device=DEV)
     out = {}
-    for name, kw in (("fcstep", dict(fc_step=True, use_graph=False)), ("gemm+graph", dict(fc_step=False, use_graph=True))):
+    for name, kw in (("fcstep", dict(fc_step=True, use_graph=False)), ("collapse", dict(fc_step="collapse", use_graph=False)),
+                     ("gemm+graph", dict(fc_step=False, use_graph=True))):
+        if name == "collapse" and act is not None:
+            continue
         m, _ = build(cfg, 3)
         ft = FusedTrainer(m, "listNet", {}, B, L, lr=1e-3, **kw)
         for i in range(10):
