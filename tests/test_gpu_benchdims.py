@@ -244,6 +244,16 @@ def test_fused_step_at_config3_dimensions_matches_fp64_oracle(gemm):
     _check(rows, "cfg3/" + gemm)
 
 
+def test_fused_step_at_config3_bench_batch_matches_fp64_oracle():
+    """config (3) at the batch the headline is timed on: 256 slates x 240 items = 61440 rows -- 480 / 1920 large
+    tiles, the hipGraph replay on the second step."""
+    B, L = 256, 240
+    rows = _run(CFG3, B, L, "split_bf16", "approxNDCGLoss", lambda s, t: O.approxndcg(s, t, dtype=np.float64), steps=3,
+                ragged=[(1, 200), (3, 17), (50, 1), (200, 100)], seed=29)
+    _log("cfg3_b256_split_bf16", rows)
+    _check(rows, "cfg3/b256")
+
+
 def test_fused_step_at_config5_dimensions_matches_fp64_oracle():
     """BASELINE configs[4]: F=1024, slate length 1024, ListMLE (explicit permutation = the oracle's)."""
     B, L = 2, 1024
