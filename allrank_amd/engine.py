@@ -826,10 +826,12 @@ class FusedTrainer(object):
             idx = torch.nonzero(valid.reshape(-1)).reshape(-1)    # (host sync: the row count sizes every launch)
             n = int(idx.numel())
             self.idx[:n] = idx
-        if n == 0:
+        if n == 0 and self.world <= 1:
             raise ValueError("FusedTrainer(compact=True): the batch has no valid item")
+        # (sharded: a rank whose block of a short last batch is empty -- 1 slate on 2 ranks -- still runs the step on 32 all-zero
+        #  alignment rows: zero loss, zero gradient, and every collective of the step is entered by every rank)
         self.n_valid = n
-        self.rows = min(self.M, (n + 31) // 32 * 32)              # alignment rows (zero input, zero gradient) keep M % 32 == 0
+        self.rows = max(32, min(self.M, (n + 31) // 32 * 32))     # alignment rows (zero input, zero gradient) keep M % 32 == 0
         F = self.x_in.shape[1]
         self.LB.check(self.lib.ltrx_gather_rows(self.LB.ptr(xb), F, self.LB.ptr(self.idx), n, self.rows, F, self.LB.ptr(self.x_in), F,
                                                 self._st()), "gather_rows")

@@ -691,6 +691,9 @@ def test_sharded_fit_with_uneven_last_batch_equals_one_rank():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), script, "--cmp", ref]
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "dist_fit_worker.log"), "w") as fh:
+        fh.write(out.stdout + "\n---- stderr ----\n" + out.stderr)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     assert "FIT_EQUIV_OK" in out.stdout, out.stdout[-2000:]
 
