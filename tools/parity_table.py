@@ -1,11 +1,11 @@
-"""profiles/r03_parity_benchdims.md from the summaries tests/test_gpu_benchdims.py leaves in gpurun_out/ (run after the GPU tests)."""
+"""profiles/r04_parity_benchdims.md from the summaries tests/test_gpu_benchdims.py leaves in gpurun_out/ (run after the GPU tests)."""
 import glob, json, os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(R, "profiles", "r03_parity_benchdims.md")
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(R, "profiles", "r04_parity_benchdims.md")
 hdr = ["run", "step", "loss err", "score err / scale", "loss-grad kernel err (same scores)", "loss-grad shift from the score err (oracle)",
        "grad max err / own max", "/ model max", "grad rms / own max", "ReLU units on other branch", "max abs pre-act of those",
        "NDCG@5 batch-mean delta", "max delta well-cond.", "ill", "top-5 differs (well-cond.)", "full valid order identical"]
-lines = ["# Round 3: parity of the benchmarked arithmetic at benchmark dimensions (tests/test_gpu_benchdims.py, MI355X)", "",
+lines = ["# Round 4: parity of the benchmarked arithmetic at benchmark dimensions (tests/test_gpu_benchdims.py, MI355X)", "",
          "fp64 oracle evaluated at the engine's weights at every step; gradients on the engine's ReLU branch (units on the other branch counted);",
          "NDCG@5 of the engine's scores vs the oracle's.  `ill` = slates with two of their six best items (different labels) closer than twice the score error.",
          "`loss-grad kernel err` = the loss kernel's d loss / d scores against the oracle's AT THE ENGINE'S OWN SCORES; `shift` = how far the oracle's own",
