@@ -46,6 +46,25 @@ def main():
         assert gerr < 1e-4, (loss_name, "grad", gerr)
         werr = (ft.flat_p - f1.flat_p).abs().max().item()
         assert werr <= 2.1e-3, (loss_name, "weights", werr)   # one Adam step of lr=1e-3; ~0-gradient params may flip sign
+    # the slate-resident FC + ListNet step (csrc/ltrx_fcstep.hip), sharded: gradients only in the kernels, all-reduce(SUM) of the flat
+    # buffer, then the flat-buffer Adam -- both forms (two-layer MFMA evaluation with ReLU, linear-scorer collapse) against one rank
+    def build_fc(act):
+        torch.manual_seed(11)
+        return make_model(dict(sizes=[48], input_norm=False, activation=act, dropout=0.0), None, dict(d_output=1, output_activation=None), 20).to("cuda:0")
+    lo, hi = parallel.shard_slates(G, rank, world)
+    for act, mode in (("ReLU", True), (None, True), (None, "collapse")):
+        m_sh, m_1 = build_fc(act), build_fc(act)
+        ft = FusedTrainer(m_sh, "listNet", {}, hi - lo, L, lr=1e-3, world_size=world, use_graph=False, fc_step=mode)
+        f1 = FusedTrainer(m_1, "listNet", {}, G, L, lr=1e-3, world_size=1, use_graph=False, fc_step=mode)
+        assert ft.fcstep == mode and f1.fcstep == mode
+        share = ft.step(x[lo:hi], y[lo:hi], global_batch=G).clone()
+        dist.all_reduce(share)
+        full = f1.step(x, y)
+        assert abs(share.item() - full.item()) <= 1e-5 * (1 + abs(full.item())), ("fcstep", act, mode, share.item(), full.item())
+        gerr = (ft.flat_g - f1.flat_g).abs().max().item() / max(f1.flat_g.abs().max().item(), 1e-12)
+        assert gerr < 1e-4, ("fcstep", act, mode, "grad", gerr)
+        werr = (ft.flat_p - f1.flat_p).abs().max().item()
+        assert werr <= 2.1e-3, ("fcstep", act, mode, "weights", werr)
     # the CAPTURED sharded step (hipGraph segments with the collectives between them, engine.FusedTrainer._capture) == the
     # eager sharded step, bit for bit, step after step (same kernels, same order, same collectives), and == the one-rank step
     # on the gathered batch; five steps = two eager warm-ups, the capture step, two replays
