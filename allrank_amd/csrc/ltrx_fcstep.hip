@@ -23,6 +23,11 @@
 // HBM traffic per item: 4 F (features, once) + 4 (label) + 4 (score) [+ 4 d loss / d score when asked for] -- SURVEY.md 8(d)'s
 // algorithmic bytes; plus one partial gradient (4 (H F + 2 H + 8) B) per WORKGROUP.
 //
+// Register budget (168 per thread at 12 waves): dW1 tile 36 + h tiles 32 + the forward's W1 fragments 40 (re-read per slate) or the
+// backward's working set ~45, + 24 for the half-slate prefetch.  Requesting the WHOLE next slate a slate ahead (48 registers through
+// the backward; forward reordered K-step-outer so that the W1 fragments stream) was built in round 4 and spills 120-330 registers --
+// the second half of a slate's loads stays exposed at the top of its iteration.
+//
 // LDS image of one plane (hi or lo): two panels [256 rows][64 cols] bf16 (128-byte rows; 16-byte chunk c of row r at position
 // c ^ s(r), s(r) = 2 ((r >> 1) & 3): conflict-free for the row-wise b128 reads of a 16x16x32 A fragment AND for the [8 rows][16 cols]
 // footprint of a half-wave's transposed read) and a tail panel [256][16] for columns 128..143 (32-byte rows, no swizzle needed).
