@@ -209,6 +209,16 @@ class FusedTrainer(object):
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.ws_clip = torch.empty(max(self.lib.ltrx_clip_workspace_bytes(n), 64), dtype=torch.uint8, device=dev)
         self.drop_step = torch.zeros(1, dtype=torch.int32, device=dev)       # u32 word folded into every dropout seed
+        # slate-resident FC + ListNet step (csrc/ltrx_fcstep.hip): eligibility.  It reads the padded batch in place and masks padded
+        # items itself, so a request for variable-length execution is moot for such a job (and would only route it to the slower
+        # GEMM launch sequence): compact is dropped.
+        fc_ok = bool(
+            fc_step and self.N == 0 and self.nfc == 1 and self.in_norm is None and self.pos is None and self.fc_act in (0, 1)
+            and self.p_fc == 0.0 and self.n_out == 1 and self.out_act == 0 and loss_name == "listNet"
+            and gemm == "split_bf16" and optimizer in ("Adam", "AdamW")
+            and self.lib.ltrx_fc_listnet_supported(L, self.fc_sizes[0], self.fc_sizes[1]))
+        if fc_ok:
+            compact = False
         self.compact = bool(compact)
         self.rows = B * L                                                     # rows the row-wise kernels run over
         self.n_valid = B * L
@@ -394,14 +404,9 @@ class FusedTrainer(object):
         self._wver = [p._version for p in self._order]
         self._images_stale = False
         self.y_cur = self.y_in                                # labels of the last step() (the caller's tensor in the fcstep path)
-        # ---- slate-resident FC + ListNet step (csrc/ltrx_fcstep.hip): eligibility ----
         self.keep_fc_out = False                              # tests: also write the FC activations to fc_out[0]
         self.keep_loss_grad = False                           # tests: also write d loss / d scores to self.loss.grad (4 B per item)
-        self.fcstep = bool(
-            fc_step and self.N == 0 and self.nfc == 1 and self.in_norm is None and self.pos is None and self.fc_act in (0, 1)
-            and self.p_fc == 0.0 and self.n_out == 1 and self.out_act == 0 and loss_name == "listNet" and not compact
-            and gemm == "split_bf16" and optimizer in ("Adam", "AdamW")
-            and self.lib.ltrx_fc_listnet_supported(L, self.fc_sizes[0], self.fc_sizes[1]))
+        self.fcstep = fc_ok
         if self.fcstep and fc_step == "collapse" and self.fc_act == 0:
             self.fcstep = "collapse"
         if self.fcstep:
@@ -923,8 +928,10 @@ class FusedTrainer(object):
         then the all-reduce / clip and the flat-buffer Adam as in the general step."""
         LB, P = self.LB, self.LB.ptr
         xb = xb.reshape(self.M, -1)
-        if xb.dtype != torch.float32 or not xb.is_contiguous() or (xb.data_ptr() & 15):
-            xb = xb.float().contiguous().clone()
+        if xb.dtype != torch.float32 or not xb.is_contiguous():
+            xb = xb.float().contiguous()
+        if xb.data_ptr() & 15:                                # (the kernel reads 16-byte pieces: a misaligned view is copied once)
+            xb = xb.clone()
         yb = yb.reshape(self.B, self.L)
         if yb.dtype != torch.float32 or not yb.is_contiguous():
             yb = yb.float().contiguous()

@@ -262,7 +262,8 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
     if trainer is None:
         trainer = Trainer(model, loss_func, optimizer, gradient_clipping_norm, world, None)
     last_run.clear()
-    last_run.update(engine="fused" if fused else "autograd", compact=bool(compact) if fused else False, reason=reason)
+    last_run.update(engine="fused" if fused else "autograd", compact=bool(trainer.compact) if fused else False, reason=reason,
+                    fcstep=getattr(trainer, "fcstep", False))
     log.info("allrank_amd.fit: %s step%s", last_run["engine"], (" (" + reason + ")") if reason else "")
 
     epoch, train_metrics, val_metrics = -1, {}, {}

@@ -112,13 +112,18 @@ def _main_sequence(cfg, tmp_path):
     return EF, model, w0, flat, out_dir
 
 
-@pytest.mark.parametrize("job", ["run_example", "fc_listnet"])
+@pytest.mark.parametrize("job", ["run_example", "fc_listnet", "fc_listnet_padded_240"])
 def test_main_call_sequence_trains_on_the_fused_step(tmp_path, job):
     cfg = json.loads(json.dumps(CONFIG))
-    if job == "fc_listnet":                                            # BASELINE configs[0] / SURVEY 8(d) config (1): transformer null
+    if job.startswith("fc_listnet"):                                   # BASELINE configs[0] / SURVEY 8(d) config (1): transformer null
         cfg["model"]["transformer"] = None
+    if job == "fc_listnet_padded_240":                                 # run_example pads its 20-document slates to slate_length 240
+        cfg["data"]["slate_length"] = 240                              # (92 % padding)
     EF, model, w0, flat, out_dir = _main_sequence(cfg, tmp_path)
     assert EF.last_run["engine"] == "fused", EF.last_run
+    if job.startswith("fc_listnet"):
+        # the slate-resident step reads the padded batch in place: it is taken even where fit() would ask for variable-length execution
+        assert EF.last_run["fcstep"] is True and EF.last_run["compact"] is False, EF.last_run
     assert flat["epochs"] == cfg["training"]["epochs"] - 1
     assert 0.3 <= flat["val_metrics/ndcg_5"] <= 1.0 and np.isfinite(flat["train_metrics/ndcg_5"])
     assert flat["num_params"] == sum(p.numel() for p in model.parameters())
