@@ -544,10 +544,23 @@ __device__ __forceinline__ int swz_t(int row, int k) {
   return (row ^ ((row >> 4) & 1)) * 32 + c * 8 + (k & 7);
 }
 
+// Up to LTRX_TN_GROUP weight gradients over the SAME rows (the four projections of an encoder layer: dW = dY^T X with their own dY, X
+// and output shape) in ONE launch: the tiles of all problems form one grid, so the chip is filled with total_tiles x splits workgroups
+// instead of tiles x splits per problem -- 4x fewer splits, i.e. 4x fewer partial slabs to write and to reduce (round 4: the slabs were
+// 550 MB per step whatever the batch; ltrx_gemm_tn_group).
+#define LTRX_TN_GROUP 4
+struct TnGroup {
+  const float* A[LTRX_TN_GROUP];
+  const float* B[LTRX_TN_GROUP];
+  float* slabs[LTRX_TN_GROUP];
+  float* bias_slabs[LTRX_TN_GROUP];
+  int lda[LTRX_TN_GROUP], ldb[LTRX_TN_GROUP], NP[LTRX_TN_GROUP], KP[LTRX_TN_GROUP], tiles_k[LTRX_TN_GROUP];
+  int tile_start[LTRX_TN_GROUP + 1];
+  int nprob;
+};
+
 template <int NT>
-__global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
-                                                              int ldb, float* __restrict__ slabs, float* __restrict__ bias_slabs,
-                                                              int M, int NP, int KP, int tiles_k, int m_per_split) {
+__global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const TnGroup grp, int M, int m_per_split) {
   constexpr int BK_ = 32;
   constexpr int L1 = NT - 1;
   typedef SmemNT<256, NT> SmemT;
@@ -560,7 +573,15 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const float* __res
   // kernel is bound by its staging path, not by HBM), the freed bandwidth is what the overlapped all-reduce needs.
   const int n_tiles = gridDim.x;
   const int wg = xcd_remap(blockIdx.x + n_tiles * blockIdx.y, n_tiles * gridDim.y);
-  const int tile = wg % n_tiles, split = wg / n_tiles;
+  const int gtile = wg % n_tiles, split = wg / n_tiles;
+  int pi = 0;                                                          // (workgroup-uniform)
+  while (pi + 1 < grp.nprob && gtile >= grp.tile_start[pi + 1]) ++pi;
+  const float* __restrict__ A = grp.A[pi];
+  const float* __restrict__ B = grp.B[pi];
+  float* __restrict__ slabs = grp.slabs[pi];
+  float* __restrict__ bias_slabs = grp.bias_slabs[pi];
+  const int lda = grp.lda[pi], ldb = grp.ldb[pi], NP = grp.NP[pi], KP = grp.KP[pi], tiles_k = grp.tiles_k[pi];
+  const int tile = gtile - grp.tile_start[pi];
   const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 256;
   const int wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
   const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
@@ -965,12 +986,23 @@ extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, fl
     });
     if (arc != LTRX_OK) return arc;
     float* bslabs = bias_out ? (float*)ws + (size_t)splits * NP * KP : nullptr;
+    TnGroup g = {};
+    g.A[0] = A;
+    g.B[0] = B;
+    g.slabs[0] = (float*)ws;
+    g.bias_slabs[0] = bslabs;
+    g.lda[0] = lda;
+    g.ldb[0] = ldb;
+    g.NP[0] = NP;
+    g.KP[0] = KP;
+    g.tiles_k[0] = KP / 256;
+    g.tile_start[0] = 0;
+    g.tile_start[1] = (NP / 256) * (KP / 256);
+    g.nprob = 1;
     if (plain)
-      hipLaunchKernelGGL(ltrx_gemm_tn256_kernel<1>, dim3((NP / 256) * (KP / 256), splits), dim3(512), 2 * sizeof(SmemNT<256, 1>), s, A,
-                         lda, B, ldb, (float*)ws, bslabs, M, NP, KP, KP / 256, mps);
+      hipLaunchKernelGGL(ltrx_gemm_tn256_kernel<1>, dim3((NP / 256) * (KP / 256), splits), dim3(512), 2 * sizeof(SmemNT<256, 1>), s, g, M, mps);
     else
-      hipLaunchKernelGGL(ltrx_gemm_tn256_kernel<2>, dim3((NP / 256) * (KP / 256), splits), dim3(512), 2 * sizeof(SmemNT<256, 2>), s, A,
-                         lda, B, ldb, (float*)ws, bslabs, M, NP, KP, KP / 256, mps);
+      hipLaunchKernelGGL(ltrx_gemm_tn256_kernel<2>, dim3((NP / 256) * (KP / 256), splits), dim3(512), 2 * sizeof(SmemNT<256, 2>), s, g, M, mps);
     LTRX_LAUNCH_CHECK();
     launch_slab_reduce((const float*)ws, splits, (size_t)NP * KP, C, bslabs, splits, (size_t)NP, bias_out, s);
     LTRX_LAUNCH_CHECK();
@@ -993,5 +1025,113 @@ extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, fl
   LTRX_LAUNCH_CHECK();
   launch_slab_reduce((const float*)ws, splits, (size_t)NP * KP, C, bslabs, 2 * splits, (size_t)NP, bias_out, s);
   LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+// ---- grouped weight gradients (see TnGroup) ----
+static void tn_group_plan(int nprob, int M, const int* NP, const int* KP, int* total_tiles, int* splits, int* mps) {
+  int t = 0;
+  for (int p = 0; p < nprob; ++p) t += (NP[p] / 256) * (KP[p] / 256);
+  int sp = t > 0 ? 256 / t : 1;                       // one workgroup per CU and ONE round
+  if (sp > M / 128) sp = M / 128;                     // at least 4 K-steps per split
+  if (sp < 1) sp = 1;
+  const int m = ((M + sp - 1) / sp + 31) / 32 * 32;
+  *total_tiles = t;
+  *mps = m;
+  *splits = (M + m - 1) / m;
+}
+static bool tn_group_ok(int nprob, int M, const int* NP, const int* KP, const int* lda, const int* ldb, int strict) {
+  if (nprob < 1 || nprob > LTRX_TN_GROUP || strict == 1) return false;
+  int t = 0;
+  for (int p = 0; p < nprob; ++p) {
+    if (!tn256_ok(M, NP[p], KP[p]) || (lda && ((lda[p] & 3) || lda[p] < NP[p])) || (ldb && ((ldb[p] & 3) || ldb[p] < KP[p]))) return false;
+    t += (NP[p] / 256) * (KP[p] / 256);
+  }
+  return t <= 256;
+}
+
+// bytes for ltrx_gemm_tn_group: an upper bound over every row count m <= M (variable-length batches): per problem at most
+// min(256 / total_tiles, m / 128) + 1 slabs of NP x KP (+ NP for the bias), and never less than the single-problem calls need (the
+// group call falls back to them when a shape does not qualify)
+extern "C" size_t ltrx_gemm_tn_group_workspace_bytes(int nprob, int M, const int* NP, const int* KP) {
+  if (nprob < 1 || nprob > LTRX_TN_GROUP || M <= 0 || !NP || !KP) return 0;
+  size_t single = 0;
+  int t = 0;
+  for (int p = 0; p < nprob; ++p) {
+    const size_t b = ltrx_gemm_tn_workspace_bytes(M, NP[p], KP[p]);
+    if (b > single) single = b;
+    t += ((NP[p] + 255) / 256) * ((KP[p] + 255) / 256);
+  }
+  size_t sp = t > 0 ? (size_t)(256 / t) : 1;
+  if (sp < 1) sp = 1;
+  sp += 1;
+  size_t grouped = 0;
+  for (int p = 0; p < nprob; ++p) grouped += (sp * NP[p] * KP[p] + sp * NP[p] + 4) * sizeof(float);
+  return grouped > single ? grouped : single;
+}
+
+extern "C" int ltrx_gemm_tn_group(int nprob, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
+                                  float* const* bias_out, int M, const int* NP, const int* KP, int strict, void* ws, size_t ws_bytes,
+                                  ltrx_stream_t stream) {
+  if (nprob < 1 || nprob > LTRX_TN_GROUP || !A || !lda || !B || !ldb || !C || !bias_out || !NP || !KP || !ws || M <= 0) return LTRX_EINVAL;
+  for (int p = 0; p < nprob; ++p)
+    if (!A[p] || !B[p] || !C[p] || NP[p] <= 0 || KP[p] <= 0) return LTRX_EINVAL;
+  const bool plain = strict == 2;
+  int total = 0, splits = 1, mps = M;
+  bool grouped = tn_group_ok(nprob, M, NP, KP, lda, ldb, strict);
+  size_t need = 0;
+  if (grouped) {
+    tn_group_plan(nprob, M, NP, KP, &total, &splits, &mps);
+    for (int p = 0; p < nprob; ++p) need += ((size_t)splits * NP[p] * KP[p] + (size_t)splits * NP[p] + 4) * sizeof(float);
+    if (need > ws_bytes) grouped = false;
+  }
+  if (!grouped) {                                     // shapes outside the large-tile kernel: one call per problem
+    for (int p = 0; p < nprob; ++p) {
+      if (ltrx_gemm_tn_workspace_bytes(M, NP[p], KP[p]) > ws_bytes) return LTRX_EINVAL;
+      const int rc = ltrx_gemm_tn(A[p], lda[p], B[p], ldb[p], C[p], bias_out[p], M, NP[p], KP[p], strict, 0, ws, stream);
+      if (rc != LTRX_OK) return rc;
+    }
+    return LTRX_OK;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  static std::atomic<uint64_t> attr_done{0};
+  const int arc = ltrx_once_per_device(attr_done, []() {
+    if (hipFuncSetAttribute((const void*)ltrx_gemm_tn256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(2 * sizeof(SmemNT<256, 2>))) != hipSuccess ||
+        hipFuncSetAttribute((const void*)ltrx_gemm_tn256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(2 * sizeof(SmemNT<256, 1>))) != hipSuccess)
+      return LTRX_EHIP;
+    return LTRX_OK;
+  });
+  if (arc != LTRX_OK) return arc;
+  TnGroup g = {};
+  g.nprob = nprob;
+  float* w = (float*)ws;
+  int t0 = 0;
+  for (int p = 0; p < nprob; ++p) {
+    g.A[p] = A[p];
+    g.B[p] = B[p];
+    g.lda[p] = lda[p];
+    g.ldb[p] = ldb[p];
+    g.NP[p] = NP[p];
+    g.KP[p] = KP[p];
+    g.tiles_k[p] = KP[p] / 256;
+    g.tile_start[p] = t0;
+    t0 += (NP[p] / 256) * (KP[p] / 256);
+    g.slabs[p] = w;
+    w += (size_t)splits * NP[p] * KP[p];
+    g.bias_slabs[p] = bias_out[p] ? w : nullptr;
+    w += ((size_t)splits * NP[p] + 3) & ~(size_t)3;
+  }
+  g.tile_start[nprob] = t0;
+  if (plain)
+    hipLaunchKernelGGL(ltrx_gemm_tn256_kernel<1>, dim3(total, splits), dim3(512), 2 * sizeof(SmemNT<256, 1>), s, g, M, mps);
+  else
+    hipLaunchKernelGGL(ltrx_gemm_tn256_kernel<2>, dim3(total, splits), dim3(512), 2 * sizeof(SmemNT<256, 2>), s, g, M, mps);
+  LTRX_LAUNCH_CHECK();
+  for (int p = 0; p < nprob; ++p) {
+    launch_slab_reduce(g.slabs[p], splits, (size_t)NP[p] * KP[p], C[p], g.bias_slabs[p], splits, (size_t)NP[p], bias_out[p], s);
+    LTRX_LAUNCH_CHECK();
+  }
   return LTRX_OK;
 }

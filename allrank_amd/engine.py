@@ -86,7 +86,7 @@ class FusedTrainer(object):
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
                  optimizer="Adam", weight_decay=0.0, momentum=0.0, nesterov=False,
                  use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None, compact=False,
-                 weight_images=True, fc_step=True):
+                 weight_images=True, fc_step=True, group_wgrad=True):
         """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
         products), "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs), or "bf16" -- the THROUGHPUT mode: one bf16
         product per contraction in the dense projections AND in attention (fp32 storage, accumulation, LayerNorm, softmax,
@@ -108,7 +108,9 @@ class FusedTrainer(object):
         from HBM once, straight from the caller's tensors (no staging copy, no hipGraph needed); False keeps the GEMM launch
         sequence for A/B runs; "collapse" (opt-in, FC activation None only): the linear scorer's two layers evaluated as ONE
         matrix-vector product per slate with the exact rank-1 gradients (ltrx_fc_linear_listnet_step: fp32 FMAs, the slate in registers,
-        HBM-bound).  ``self.fcstep`` tells which one is active (False / True / "collapse")."""
+        HBM-bound).  ``self.fcstep`` tells which one is active (False / True / "collapse").
+        group_wgrad=True: the four weight gradients of an encoder layer run as one ltrx_gemm_tn_group launch (4x fewer partial slabs
+        to write and reduce); False = one ltrx_gemm_tn per projection (A/B runs)."""
         import torch.nn as nn
         from . import _lib as LB
         from .losses import FusedLoss
@@ -119,6 +121,8 @@ class FusedTrainer(object):
             raise ValueError("gemm must be split_bf16, split_bf16_strict, hipblaslt or bf16")
         self.gemm = gemm
         self.weight_images = bool(weight_images)
+        self.group_wgrad = bool(group_wgrad) and gemm != "split_bf16_strict"     # (the strict arithmetic has no large-tile kernel)
+        self._wg_pending = []
         self._prec = {"split_bf16_strict": 1, "bf16": 2}.get(gemm, 0)        # precision code of ltrx_gemm_nt / ltrx_gemm_tn
         # attention arithmetic of THIS trainer, passed with every ltrx_mha_fwd / ltrx_mha_bwd call (the library keeps no mode):
         # 1 = three bf16 products (fp32-class, parity), 2 = one product (the "bf16" throughput mode)
@@ -348,6 +352,11 @@ class FusedTrainer(object):
                 shapes += [(self.n_out, d)]
             for (npp, kpp) in shapes:
                 nb = max(nb, self.lib.ltrx_gemm_tn_workspace_bytes(M, npp, kpp))
+            if self.N and self.group_wgrad:                       # the four projections of a layer in one launch (_wgrad_flush)
+                import ctypes
+                npa = (ctypes.c_int * 4)(3 * d, d, self.dff, d)
+                kpa = (ctypes.c_int * 4)(d, d, d, self.dff)
+                nb = max(nb, self.lib.ltrx_gemm_tn_group_workspace_bytes(4, M, npa, kpa))
             self.ws_tn = torch.empty(max(nb, 64), dtype=torch.uint8, device=dev)
             # transposed weight copies for the input-gradient GEMMs (refreshed after every optimizer step by ONE batched
             # transpose launch): all copies live in one flat buffer, the descriptor table is built once
@@ -572,16 +581,40 @@ class FusedTrainer(object):
                                             relu_of.stride(0) if relu_of is not None else 0, float(p), seed, P(self.drop_step),
                                             self._prec, 0, self._st()), "gemm_nt(dgrad)")
 
-    def _lin_wgrad(self, dy, x, gw, gb):
-        """gw = dy^T x, gb = column sums of dy   (weight and bias gradients of nn.Linear)"""
+    def _lin_wgrad(self, dy, x, gw, gb, defer=False):
+        """gw = dy^T x, gb = column sums of dy   (weight and bias gradients of nn.Linear).  ``defer``: an encoder-layer projection
+        -- queued for the layer's one grouped launch (_wgrad_flush); dy and x must stay untouched until then."""
         if self.gemm == "hipblaslt":
             torch.mm(dy[:self.rows].t(), x[:self.rows], out=gw)
             self._colsum(dy, gb)
+            return
+        if defer and self.group_wgrad:
+            self._wg_pending.append((dy, x, gw, gb))
             return
         P = self.LB.ptr
         self.LB.check(self.lib.ltrx_gemm_tn(P(dy), dy.stride(0), P(x), x.stride(0), P(gw), P(gb), self.rows, dy.shape[1],
                                             x.shape[1], self._prec, 0, P(self.ws_tn), self._st()),
                       "gemm_tn(wgrad)")
+
+    def _wgrad_flush(self):
+        """the queued weight gradients of a layer as ONE ltrx_gemm_tn_group launch (+ one fixed-order slab reduce each)"""
+        q = self._wg_pending
+        if not q:
+            return
+        import ctypes
+        n = len(q)
+        vp, ci = ctypes.c_void_p * n, ctypes.c_int * n
+        A = vp(*[t[0].data_ptr() for t in q])
+        Bm = vp(*[t[1].data_ptr() for t in q])
+        C = vp(*[t[2].data_ptr() for t in q])
+        bo = vp(*[t[3].data_ptr() for t in q])
+        lda = ci(*[t[0].stride(0) for t in q])
+        ldb = ci(*[t[1].stride(0) for t in q])
+        NP = ci(*[t[0].shape[1] for t in q])
+        KP = ci(*[t[1].shape[1] for t in q])
+        self.LB.check(self.lib.ltrx_gemm_tn_group(n, A, lda, Bm, ldb, C, bo, self.rows, NP, KP, self._prec, self.LB.ptr(self.ws_tn),
+                                                  self.ws_tn.numel(), self._st()), "gemm_tn_group(wgrad)")
+        q.clear()
 
     # ---- the step body (capturable) ----------------------------------------------------------------------------
     def _forward(self, train=True):
@@ -700,16 +733,20 @@ class FusedTrainer(object):
                 ff = lay.feed_forward
                 # FFN branch
                 db = self._branch_grad(ds, st["p_s1"], st["s_s1"])
-                self._lin_wgrad(db, st["r"], G(ff.w_2.weight), G(ff.w_2.bias))
+                # (the four weight gradients of the layer are queued and run as one grouped launch before the first kernel that
+                #  overwrites one of their operands: the LN0 backward below, or the second use of the dropout buffer d_br)
+                self._lin_wgrad(db, st["r"], G(ff.w_2.weight), G(ff.w_2.bias), defer=True)
                 self._lin_dgrad(db, W(ff.w_2.weight), self._wT.get(id(ff.w_2.weight)), self.d_r, relu_of=st["r"], p=st["p_ff"])
-                self._lin_wgrad(self.d_r, st["xn1"], G(ff.w_1.weight), G(ff.w_1.bias))
+                self._lin_wgrad(self.d_r, st["xn1"], G(ff.w_1.weight), G(ff.w_1.bias), defer=True)
                 self._lin_dgrad(self.d_r, W(ff.w_1.weight), self._wT.get(id(ff.w_1.weight)), self.tmp_d)
                 self._ln_bwd(self.tmp_d, st["x1"], W(n1.a_2), st["mean1"], st["rstd1"], ds, other, G(n1.a_2), G(n1.b_2))
                 ds, other = other, ds                              # ds = d loss / d x1
                 # attention branch
                 lo = lay.self_attn.linears[3]
+                if st["p_s0"] and st["p_s1"]:                      # d_br still holds the FFN branch's dY
+                    self._wgrad_flush()
                 db = self._branch_grad(ds, st["p_s0"], st["s_s0"])
-                self._lin_wgrad(db, st["o"], G(lo.weight), G(lo.bias))
+                self._lin_wgrad(db, st["o"], G(lo.weight), G(lo.bias), defer=True)
                 self._lin_dgrad(db, W(lo.weight), self._wT.get(id(lo.weight)), self.d_o)
                 qkv, dq = st["qkv"], self.dqkv
                 self.LB.check(lib.ltrx_mha_bwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(kpm), P(st["o"]),
@@ -719,8 +756,9 @@ class FusedTrainer(object):
                               "mha_bwd")
                 if self.compact and M > self.n_valid:              # alignment rows belong to no slate: no gradient
                     dq[self.n_valid:M].zero_()
-                self._lin_wgrad(dq, st["xn0"], st["gwqkv"], st["gbqkv"])
+                self._lin_wgrad(dq, st["xn0"], st["gwqkv"], st["gbqkv"], defer=True)
                 self._lin_dgrad(dq, st["wqkv"], st.get("wqkvT"), self.tmp_d)
+                self._wgrad_flush()
                 self._ln_bwd(self.tmp_d, st["xin"], W(n0.a_2), st["mean0"], st["rstd0"], ds, other, G(n0.a_2), G(n0.b_2))
                 ds, other = other, ds                              # ds = d loss / d (layer input)
                 self._bucket_done(self.N - 1 - i)

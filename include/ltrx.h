@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTRX_VERSION 120 /* 0.2.0: slate-resident FC + ListNet step (round 4) */
+#define LTRX_VERSION 121 /* 0.2.0: slate-resident FC + ListNet step (round 4) */
 
 #define LTRX_OK 0
 #define LTRX_EINVAL (-1)
@@ -329,6 +329,19 @@ size_t ltrx_gemm_tn_workspace_bytes(int M, int NP, int KP);
 int ltrx_gemm_tn_splits(int M, int NP, int KP);
 int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, float* bias_out, int M, int NP, int KP, int strict,
                  int tile, void* ws, ltrx_stream_t stream);
+/* Up to LTRX_GEMM_TN_GROUP_MAX weight gradients over the SAME M rows in one launch (the four nn.Linear projections of an encoder
+ * layer: allrank/models/transformer.py:174, 217-218 -- loss.backward() computes each dW = dY^T X separately, allrank/training/
+ * train_utils.py:23): C[p][NP[p], KP[p]] = A[p][M, NP[p]]^T * B[p][M, KP[p]], bias_out[p] (may be NULL per problem) = column
+ * sums of A[p].  The tiles of all problems share one grid, so the row split is chosen for the SUM of the tiles: 4x fewer partial
+ * slabs than four ltrx_gemm_tn calls.  Each result is BIT-IDENTICAL run to run (fixed split and reduction order) but not to the
+ * single-problem call's (different split count).  Shapes outside the 256x256-tile kernel fall back to one ltrx_gemm_tn per problem.
+ * The pointer / int tables are HOST arrays, read before the call returns.  ws: ltrx_gemm_tn_group_workspace_bytes (sufficient for
+ * every row count <= M). */
+#define LTRX_GEMM_TN_GROUP_MAX 4
+size_t ltrx_gemm_tn_group_workspace_bytes(int nprob, int M, const int* NP, const int* KP);
+int ltrx_gemm_tn_group(int nprob, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
+                       float* const* bias_out, int M, const int* NP, const int* KP, int strict, void* ws, size_t ws_bytes,
+                       ltrx_stream_t stream);
 
 /* Model options around the encoder on the explicit step (allrank_amd/csrc/ltrx_extras.hip):
  *   ltrx_layernorm_torch_fwd: FCModel.input_norm = nn.LayerNorm(n_features) (model.py:27,39): biased variance, eps inside the

@@ -1272,6 +1272,93 @@ def test_large_tile_wgrad_gemm_matches_fp64_and_the_small_tile_kernel():
         pass
 
 
+def test_grouped_wgrad_launch_matches_fp64_is_deterministic_and_falls_back():
+    """ltrx_gemm_tn_group: the four weight gradients of an encoder layer in one launch -- every result vs fp64 (same bound as the
+    single-problem kernel), bit-identical run to run, bias sums present or absent per problem, strided operands (the fused QKV
+    buffer), a ragged row count, and the per-problem fallback for shapes the large tile does not take."""
+    import ctypes
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    rng = np.random.default_rng(21)
+    cases = [(15360, [(1536, 512), (512, 512), (2048, 512), (512, 2048)]),      # the bench layer at 64 slates of 240
+             (6176, [(768, 256), (256, 256), (512, 256), (256, 512)]),          # ragged rows
+             (4096, [(256, 256)]),
+             (2048, [(96, 136), (256, 256)])]                                   # first shape not a large-tile shape: fallback
+    for (Mm, probs) in cases:
+        n = len(probs)
+        As = [rng.standard_normal((Mm, a + 8)).astype(np.float32) for a, _ in probs]        # lda = NP + 8
+        Bs = [rng.standard_normal((Mm, b)).astype(np.float32) for _, b in probs]
+        At, Bt = [_t(a) for a in As], [_t(b) for b in Bs]
+        NP = (ctypes.c_int * n)(*[a for a, _ in probs])
+        KP = (ctypes.c_int * n)(*[b for _, b in probs])
+        lda = (ctypes.c_int * n)(*[a + 8 for a, _ in probs])
+        ldb = (ctypes.c_int * n)(*[b for _, b in probs])
+        nb = lib.ltrx_gemm_tn_group_workspace_bytes(n, Mm, NP, KP)
+        assert nb >= max(lib.ltrx_gemm_tn_workspace_bytes(Mm, a, b) for a, b in probs)
+        ws = torch.empty(max(nb, 64), dtype=torch.uint8, device=DEV)
+        runs = []
+        for rep in range(2):
+            Cs = [torch.full((a, b), float("nan"), device=DEV) for a, b in probs]
+            gbs = [torch.full((a,), float("nan"), device=DEV) if (i % 2 == 0) else None for i, (a, _) in enumerate(probs)]
+            vp = ctypes.c_void_p * n
+            LB.check(lib.ltrx_gemm_tn_group(n, vp(*[t.data_ptr() for t in At]), lda, vp(*[t.data_ptr() for t in Bt]), ldb,
+                                            vp(*[t.data_ptr() for t in Cs]), vp(*[(g.data_ptr() if g is not None else None) for g in gbs]),
+                                            Mm, NP, KP, 0, LB.ptr(ws), ws.numel(), None), "gemm_tn_group")
+            runs.append((Cs, gbs))
+        for i, (a, b) in enumerate(probs):
+            A64 = As[i][:, :a].astype(np.float64)
+            ref = A64.T @ Bs[i].astype(np.float64)
+            scale = (np.abs(A64).T @ np.abs(Bs[i]).astype(np.float64)).max()
+            got = runs[0][0][i]
+            assert float(np.abs(got.cpu().numpy() - ref).max() / scale) < 4e-6, (Mm, a, b)
+            assert torch.equal(got, runs[1][0][i]), ("run-to-run", Mm, a, b)
+            if runs[0][1][i] is not None:
+                bref = A64.sum(0)
+                assert float(np.abs(runs[0][1][i].cpu().numpy() - bref).max()) < 1e-5 * max(1.0, np.abs(A64).sum(0).max())
+                assert torch.equal(runs[0][1][i], runs[1][1][i])
+    # argument validation: more problems than the table holds, a workspace too small for even one problem
+    NP5, KP5 = (ctypes.c_int * 5)(*[256] * 5), (ctypes.c_int * 5)(*[256] * 5)
+    assert lib.ltrx_gemm_tn_group_workspace_bytes(5, 1024, NP5, KP5) == 0
+    vp1 = ctypes.c_void_p * 1
+    a1, b1, c1 = torch.zeros((1024, 256), device=DEV), torch.zeros((1024, 256), device=DEV), torch.zeros((256, 256), device=DEV)
+    one = (ctypes.c_int * 1)(256)
+    assert lib.ltrx_gemm_tn_group(1, vp1(a1.data_ptr()), one, vp1(b1.data_ptr()), one, vp1(c1.data_ptr()), vp1(None), 1024, one, one, 0,
+                                  LB.ptr(ws), 16, None) != 0
+
+
+def test_grouped_wgrad_step_equals_the_per_projection_step():
+    """FusedTrainer(group_wgrad=True) (default) vs group_wgrad=False: same loss bit for bit (the forward is untouched), every
+    gradient equal to the per-projection launch's to split-order round-off, with and without sublayer dropout (the flush points
+    differ: the dropout buffer is reused inside a layer)."""
+    import copy
+    from allrank_amd.model import make_model
+    from allrank_amd.engine import FusedTrainer
+    rng = np.random.default_rng(5)
+    B, L, F = 16, 64, 136
+    x = _t(rng.standard_normal((B, L, F)).astype(np.float32))
+    y = rng.integers(0, 5, (B, L)).astype(np.float32)
+    y[2, 40:] = -1
+    yt = _t(y)
+    for pdrop in (0.0, 0.1):
+        torch.manual_seed(3)
+        base = make_model(dict(sizes=[256], input_norm=False, activation=None, dropout=0.0),
+                          dict(N=2, d_ff=512, h=2, positional_encoding=None, dropout=pdrop),
+                          dict(d_output=1, output_activation=None), F).to(DEV)
+        grads = {}
+        for grouped in (True, False):
+            m = copy.deepcopy(base)
+            ft = FusedTrainer(m, "listNet", {}, B, L, lr=1e-3, use_graph=False, seed=11, group_wgrad=grouped)
+            assert ft.group_wgrad == grouped
+            loss = ft.step(x, yt).item()
+            grads[grouped] = (loss, {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+            assert not ft._wg_pending
+        assert grads[True][0] == grads[False][0]
+        for k, g in grads[True][1].items():
+            ref = grads[False][1][k]
+            tol = 2e-5 * max(1e-6, float(ref.abs().max()))
+            assert float((g - ref).abs().max()) <= tol, (pdrop, k, float((g - ref).abs().max()), tol)
+
+
 def test_row4_losses_edge_shapes():
     """single-item slates, a fully padded slate, the maximum slate length and a single slate: engine == oracle (NaN where
     the reference's own arithmetic is 0/0)."""

@@ -1,0 +1,46 @@
+"""Same-box A/B of the grouped weight-gradient launch (FusedTrainer(group_wgrad=True) vs False) on the bench workload:
+   python tools/wgrad_group_ab.py [slates ...]   -> ms/step of both, interleaved, per batch size."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def main():
+    from allrank_amd.model import make_model
+    from allrank_amd.engine import FusedTrainer
+    sizes = [int(a) for a in sys.argv[1:]] or [64, 256]
+    dev = "cuda:0"
+    L, F = 240, 136
+    for B in sizes:
+        rng = np.random.default_rng(0)
+        x = torch.tensor(rng.standard_normal((B, L, F)).astype(np.float32), device=dev)
+        y = torch.tensor(rng.integers(0, 5, (B, L)).astype(np.float32), device=dev)
+        trs = {}
+        for grouped in (True, False):
+            torch.manual_seed(0)
+            m = make_model(dict(sizes=[512], input_norm=False, activation=None, dropout=0.0),
+                           dict(N=2, d_ff=2048, h=8, positional_encoding=None, dropout=0.0),
+                           dict(d_output=1, output_activation=None), F).to(dev)
+            trs[grouped] = FusedTrainer(m, "approxNDCGLoss", {}, B, L, lr=1e-3, group_wgrad=grouped)
+            for _ in range(5):
+                trs[grouped].step(x, y)
+        res = {True: [], False: []}
+        for rep in range(5):
+            for grouped in (True, False):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    trs[grouped].step(x, y)
+                torch.cuda.synchronize()
+                res[grouped].append((time.perf_counter() - t0) / 20 * 1e3)
+        g, s = min(res[True]), min(res[False])
+        print("slates %4d: grouped %.3f ms/step (%.2f M items/s)   per-projection %.3f ms/step (%.2f M items/s)   gain %.1f %%"
+              % (B, g, B * L / g / 1e3, s, B * L / s / 1e3, (s / g - 1) * 100), flush=True)
+
+
+if __name__ == "__main__":
+    main()
