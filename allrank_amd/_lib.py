@@ -42,6 +42,7 @@ SIGNATURES = {
     "ltrx_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, ctypes.c_uint32, _vp, _vp]),
     "ltrx_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_layernorm_bwd_partial": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "ltrx_mha_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _f, ctypes.c_uint32, _vp, _vp, _vp, _i, _vp]),
     "ltrx_mha_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ltrx_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _f, _vp, _vp]),
@@ -67,7 +68,8 @@ SIGNATURES = {
     "ltrx_gemm_tn_splits": (_i, [_i, _i, _i]),
     "ltrx_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ltrx_gemm_tn_group_workspace_bytes": (_sz, [_i, _i, _vp, _vp]),
-    "ltrx_gemm_tn_group": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
+    "ltrx_gemm_tn_group": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "ltrx_reduce_group": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_layernorm_torch_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "ltrx_posenc_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "ltrx_posenc_table_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

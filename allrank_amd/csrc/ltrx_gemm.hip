@@ -704,42 +704,39 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const TnGroup grp,
   }
 }
 
-// C[i] = sum_s slabs[s][i] in a fixed order.  One launch serves the weight gradient (workgroups 0 .. main_blocks-1) and,
-// when given, the bias gradient's column-sum slabs (the remaining workgroups).
-__global__ void __launch_bounds__(256) ltrx_gemm_slab_reduce_kernel(const float* __restrict__ slabs, int splits,
-                                                                    size_t n, float* __restrict__ C, int main_blocks,
-                                                                    const float* __restrict__ slabs2, int splits2, size_t n2,
-                                                                    float* __restrict__ C2) {
-  if ((int)blockIdx.x >= main_blocks) {
-    // bias slabs: 64 columns per workgroup, its 4 waves take every 4th slab with 8 loads in flight, partials combined through LDS
-    // in a fixed order (one thread per column looping over all slabs was up to 128 dependent-latency iterations in a handful of
-    // workgroups: the critical path of this launch)
-    __shared__ float sh[4][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const size_t c = (size_t)(blockIdx.x - main_blocks) * 64 + cl;
-    float a = 0.f;
-    if (c < n2) {
-      int sidx = rg;
-      for (; sidx + 28 < splits2; sidx += 32) {
-        float v[8];
+// Fixed-order sums of partial slabs, as device functions shared by the per-GEMM launch and the grouped launch (same order of
+// additions in both: a result does not depend on which launch produced it).
+// columns kind: out[c] = sum_s src[s * row_stride + c] for 64 columns per workgroup; its 4 waves take every 4th slab with 8 loads in
+// flight, partials combined through LDS in a fixed order (one thread per column looping over all slabs was up to 128
+// dependent-latency iterations in a handful of workgroups: the critical path of the launch)
+__device__ __forceinline__ void reduce_cols(const float* __restrict__ src, int splits, size_t n, size_t row_stride,
+                                            float* __restrict__ out, int lb, float (*sh)[64]) {
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const size_t c = (size_t)lb * 64 + cl;
+  float a = 0.f;
+  if (c < n) {
+    int sidx = rg;
+    for (; sidx + 28 < splits; sidx += 32) {
+      float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = slabs2[(size_t)(sidx + 4 * u) * n2 + c];
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(sidx + 4 * u) * row_stride + c];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a += v[u];
-      }
-      for (; sidx < splits2; sidx += 4) a += slabs2[(size_t)sidx * n2 + c];
+      for (int u = 0; u < 8; ++u) a += v[u];
     }
-    sh[rg][cl] = a;
-    __syncthreads();
-    if (rg == 0 && c < n2) C2[c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
-    return;
+    for (; sidx < splits; sidx += 4) a += src[(size_t)sidx * row_stride + c];
   }
-  const size_t stride = (size_t)main_blocks * blockDim.x;
+  sh[rg][cl] = a;
+  __syncthreads();
+  if (rg == 0 && c < n) out[c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+}
+// wide kind: C[i] = sum_s slabs[s * n + i], grid-stride over `nb` workgroups (this one is `lb`)
+__device__ __forceinline__ void reduce_wide(const float* __restrict__ slabs, int splits, size_t n, float* __restrict__ C, int lb, int nb) {
+  const size_t stride = (size_t)nb * blockDim.x;
   if ((n & 3) == 0 && (((uintptr_t)slabs | (uintptr_t)C) & 15) == 0) {
     // 16-byte accesses, eight slabs in flight per thread; the additions keep the slab order (same bits as the scalar loop)
     const size_t n4 = n >> 2;
     const f32x4* s4 = reinterpret_cast<const f32x4*>(slabs);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    for (size_t i = (size_t)lb * blockDim.x + threadIdx.x; i < n4; i += stride) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
       int sidx = 0;
       for (; sidx + 8 <= splits; sidx += 8) {
@@ -754,20 +751,90 @@ __global__ void __launch_bounds__(256) ltrx_gemm_slab_reduce_kernel(const float*
     }
     return;
   }
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  for (size_t i = (size_t)lb * blockDim.x + threadIdx.x; i < n; i += stride) {
     float a = 0.f;
     for (int sidx = 0; sidx < splits; ++sidx) a += slabs[(size_t)sidx * n + i];
     C[i] = a;
   }
 }
 
+// One launch serves the weight gradient (workgroups 0 .. main_blocks-1) and, when given, the bias gradient's column-sum slabs
+// (the remaining workgroups).
+__global__ void __launch_bounds__(256) ltrx_gemm_slab_reduce_kernel(const float* __restrict__ slabs, int splits,
+                                                                    size_t n, float* __restrict__ C, int main_blocks,
+                                                                    const float* __restrict__ slabs2, int splits2, size_t n2,
+                                                                    float* __restrict__ C2) {
+  __shared__ float sh[4][64];
+  if ((int)blockIdx.x >= main_blocks) {
+    reduce_cols(slabs2, splits2, n2, n2, C2, (int)blockIdx.x - main_blocks, sh);
+    return;
+  }
+  reduce_wide(slabs, splits, n, C, (int)blockIdx.x, main_blocks);
+}
+
+static size_t slab_reduce_blocks(size_t n) {
+  size_t blocks = ((n & 3) == 0 ? n / 4 : n) / 256 + 1;
+  return blocks > 2048 ? 2048 : blocks;
+}
 static void launch_slab_reduce(const float* slabs, int splits, size_t n, float* C, const float* bslabs, int bsplits, size_t nb,
                                float* bias_out, hipStream_t s) {
-  size_t blocks = ((n & 3) == 0 ? n / 4 : n) / 256 + 1;
-  if (blocks > 2048) blocks = 2048;
+  const size_t blocks = slab_reduce_blocks(n);
   const size_t bblocks = bias_out ? (nb + 63) / 64 : 0;
   hipLaunchKernelGGL(ltrx_gemm_slab_reduce_kernel, dim3((unsigned)(blocks + bblocks)), dim3(256), 0, s, slabs, splits, n, C,
                      (int)blocks, bslabs, bsplits, nb, bias_out);
+}
+
+// Several independent fixed-order reductions in ONE launch (ltrx_reduce_group): the partial slabs of a grouped weight-gradient GEMM,
+// their bias column sums, and the parameter-gradient partials of the LayerNorm backward kernels of the same encoder layer -- eleven
+// launches of 5-12 us per layer become one.  Entry e owns workgroups blk_start[e] .. blk_start[e+1]-1.
+#define LTRX_REDUCE_GROUP 16
+struct RedGroup {
+  const float* src[LTRX_REDUCE_GROUP];
+  float* dst[LTRX_REDUCE_GROUP];
+  unsigned long long n[LTRX_REDUCE_GROUP];
+  unsigned long long row_stride[LTRX_REDUCE_GROUP];
+  int splits[LTRX_REDUCE_GROUP];
+  int wide[LTRX_REDUCE_GROUP];
+  int blk_start[LTRX_REDUCE_GROUP + 1];
+  int nent;
+};
+__global__ void __launch_bounds__(256) ltrx_reduce_group_kernel(const RedGroup g) {
+  __shared__ float sh[4][64];
+  int e = 0;                                                            // (workgroup-uniform)
+  while (e + 1 < g.nent && (int)blockIdx.x >= g.blk_start[e + 1]) ++e;
+  const int lb = (int)blockIdx.x - g.blk_start[e];
+  if (g.wide[e])
+    reduce_wide(g.src[e], g.splits[e], (size_t)g.n[e], g.dst[e], lb, g.blk_start[e + 1] - g.blk_start[e]);
+  else
+    reduce_cols(g.src[e], g.splits[e], (size_t)g.n[e], (size_t)g.row_stride[e], g.dst[e], lb, sh);
+}
+
+// dst[i][c] = sum_{s < splits[i]} src[i][s * row_stride[i] + c]  for c < cols[i], i < n: every sum in a fixed order (deterministic;
+// an entry gives the same bits as ltrx_gemm_tn's own reduction of the same slabs).  Entries with splits[i] <= 0 are skipped.
+extern "C" int ltrx_reduce_group(int n, const float* const* src, const int* splits, const size_t* row_stride, const size_t* cols,
+                                 float* const* dst, ltrx_stream_t stream) {
+  if (n < 0 || n > LTRX_REDUCE_GROUP || (n > 0 && (!src || !splits || !row_stride || !cols || !dst))) return LTRX_EINVAL;
+  RedGroup g = {};
+  int ne = 0, blk = 0;
+  for (int i = 0; i < n; ++i) {
+    if (splits[i] <= 0 || cols[i] == 0) continue;
+    if (!src[i] || !dst[i] || row_stride[i] < cols[i]) return LTRX_EINVAL;
+    g.src[ne] = src[i];
+    g.dst[ne] = dst[i];
+    g.n[ne] = cols[i];
+    g.row_stride[ne] = row_stride[i];
+    g.splits[ne] = splits[i];
+    g.wide[ne] = (row_stride[i] == cols[i] && cols[i] >= 16384) ? 1 : 0;
+    g.blk_start[ne] = blk;
+    blk += (int)(g.wide[ne] ? slab_reduce_blocks(cols[i]) : (cols[i] + 63) / 64);
+    ++ne;
+  }
+  g.blk_start[ne] = blk;
+  g.nent = ne;
+  if (ne == 0) return LTRX_OK;
+  hipLaunchKernelGGL(ltrx_reduce_group_kernel, dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, g);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
 }
 
 // pre-split operand image: every 4 consecutive floats of src become the 16 bytes {hi0..hi3, lo0..lo3} (bf16) of dst -- the same
@@ -1072,7 +1139,10 @@ extern "C" size_t ltrx_gemm_tn_group_workspace_bytes(int nprob, int M, const int
 
 extern "C" int ltrx_gemm_tn_group(int nprob, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
                                   float* const* bias_out, int M, const int* NP, const int* KP, int strict, void* ws, size_t ws_bytes,
-                                  ltrx_stream_t stream) {
+                                  const float** slabs_out, const float** bias_slabs_out, int* splits_out, ltrx_stream_t stream) {
+  const bool defer = slabs_out && bias_slabs_out && splits_out;   // the caller sums the slabs (ltrx_reduce_group)
+  if ((slabs_out || bias_slabs_out || splits_out) && !defer) return LTRX_EINVAL;
+  if (defer) *splits_out = 0;
   if (nprob < 1 || nprob > LTRX_TN_GROUP || !A || !lda || !B || !ldb || !C || !bias_out || !NP || !KP || !ws || M <= 0) return LTRX_EINVAL;
   for (int p = 0; p < nprob; ++p)
     if (!A[p] || !B[p] || !C[p] || NP[p] <= 0 || KP[p] <= 0) return LTRX_EINVAL;
@@ -1129,6 +1199,14 @@ extern "C" int ltrx_gemm_tn_group(int nprob, const float* const* A, const int* l
   else
     hipLaunchKernelGGL(ltrx_gemm_tn256_kernel<2>, dim3(total, splits), dim3(512), 2 * sizeof(SmemNT<256, 2>), s, g, M, mps);
   LTRX_LAUNCH_CHECK();
+  if (defer) {
+    for (int p = 0; p < nprob; ++p) {
+      slabs_out[p] = g.slabs[p];
+      bias_slabs_out[p] = g.bias_slabs[p];
+    }
+    *splits_out = splits;
+    return LTRX_OK;
+  }
   for (int p = 0; p < nprob; ++p) {
     launch_slab_reduce(g.slabs[p], splits, (size_t)NP[p] * KP[p], C[p], g.bias_slabs[p], splits, (size_t)NP[p], bias_out[p], s);
     LTRX_LAUNCH_CHECK();

@@ -334,12 +334,12 @@ extern "C" size_t ltrx_layernorm_bwd_workspace_bytes(int rows, int D) {
   return (size_t)(LTRX_LN_BWD_G16 > 320 ? LTRX_LN_BWD_G16 : 320) * 2 * D * sizeof(float);
 }
 
-extern "C" int ltrx_layernorm_bwd(const float* dy, const float* xsum, const float* a, const float* mean,
-                                  const float* rstd, const float* dres_in, int rows, int D, float eps, float* dx_out,
-                                  float* da_out, float* db_out, void* ws, ltrx_stream_t stream) {
-  if (!dy || !xsum || !a || !mean || !rstd || !dx_out || !da_out || !db_out || !ws || rows <= 0 || D < 2) return LTRX_EINVAL;
+// the streaming kernel of the backward: dx, and per-workgroup column partials [grid][2][D] of (da, db) in ws; returns the partial
+// row count through *grid_out
+static int ln_bwd_main(const float* dy, const float* xsum, const float* a, const float* mean, const float* rstd, const float* dres_in,
+                       int rows, int D, float eps, float* dx_out, void* ws, int* grid_out, hipStream_t s) {
+  if (!dy || !xsum || !a || !mean || !rstd || !dx_out || !ws || rows <= 0 || D < 2) return LTRX_EINVAL;
   if ((size_t)4 * 2 * D * sizeof(float) > 64 * 1024) return LTRX_EUNSUPPORTED;   // D <= 2048
-  hipStream_t s = (hipStream_t)stream;
   int grid = ln_bwd_grid(rows);
   if (ln_vec_ok(D, dy, xsum, dx_out) && ln_vec_ok(D, a, dres_in, ws)) {
 #define LTRX_LN_BWD(NV, WPB) \
@@ -361,8 +361,30 @@ extern "C" int ltrx_layernorm_bwd(const float* dy, const float* xsum, const floa
                        mean, rstd, dres_in, rows, D, eps, dx_out, (float*)ws);
   }
   LTRX_LAUNCH_CHECK();
+  *grid_out = grid;
+  return LTRX_OK;
+}
+
+extern "C" int ltrx_layernorm_bwd(const float* dy, const float* xsum, const float* a, const float* mean,
+                                  const float* rstd, const float* dres_in, int rows, int D, float eps, float* dx_out,
+                                  float* da_out, float* db_out, void* ws, ltrx_stream_t stream) {
+  if (!da_out || !db_out) return LTRX_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = 0;
+  const int rc = ln_bwd_main(dy, xsum, a, mean, rstd, dres_in, rows, D, eps, dx_out, ws, &grid, s);
+  if (rc != LTRX_OK) return rc;
   hipLaunchKernelGGL(ltrx_layernorm_bwd_reduce_kernel, dim3((D + 63) / 64), dim3(1024), 0, s, (const float*)ws, grid, D,
                      da_out, db_out);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
+}
+
+// the same backward WITHOUT the parameter-gradient reduction: dx is final, ws holds *partial_rows_out rows of [da(D) | db(D)] partials
+// for the caller to sum -- ltrx_reduce_group sums the partials of several LayerNorms and the weight-gradient slabs of
+// ltrx_gemm_tn_group in one launch (da = column sums of ws[:, 0:D], db = of ws[:, D:2D]; row stride 2 D).
+extern "C" int ltrx_layernorm_bwd_partial(const float* dy, const float* xsum, const float* a, const float* mean, const float* rstd,
+                                          const float* dres_in, int rows, int D, float eps, float* dx_out, void* ws,
+                                          int* partial_rows_out, ltrx_stream_t stream) {
+  if (!partial_rows_out) return LTRX_EINVAL;
+  return ln_bwd_main(dy, xsum, a, mean, rstd, dres_in, rows, D, eps, dx_out, ws, partial_rows_out, (hipStream_t)stream);
 }

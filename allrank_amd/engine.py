@@ -123,6 +123,8 @@ class FusedTrainer(object):
         self.weight_images = bool(weight_images)
         self.group_wgrad = bool(group_wgrad) and gemm != "split_bf16_strict"     # (the strict arithmetic has no large-tile kernel)
         self._wg_pending = []
+        self._red_pending = []                # (src ptr, partial rows, row stride, columns, dst ptr) entries of the next _reduce_flush
+        self._ln_slot = 0
         self._prec = {"split_bf16_strict": 1, "bf16": 2}.get(gemm, 0)        # precision code of ltrx_gemm_nt / ltrx_gemm_tn
         # attention arithmetic of THIS trainer, passed with every ltrx_mha_fwd / ltrx_mha_bwd call (the library keeps no mode):
         # 1 = three bf16 products (fp32-class, parity), 2 = one product (the "bf16" throughput mode)
@@ -324,6 +326,8 @@ class FusedTrainer(object):
             self.tmp_d = torch.zeros((M, d), **f32)
             self.d_br = torch.zeros((M, d), **f32)            # gradient of a dropped residual branch (ds * keep)
             self.ws_ln = torch.empty(max(self.lib.ltrx_layernorm_bwd_workspace_bytes(M, d), 64), dtype=torch.uint8, device=dev)
+            # deferred parameter-gradient partials of up to three LayerNorm backwards per encoder layer (_reduce_flush)
+            self.ws_ln_g = [self.ws_ln] + [torch.empty_like(self.ws_ln) for _ in range(2)]
             self.ws_mha = torch.empty(max(self.lib.ltrx_mha_bwd_workspace_bytes(B, L, self.h, self.d // self.h, self._mha_mode), 64), dtype=torch.uint8, device=dev)
         no = self.n_out
         self.scores_raw = torch.zeros((B, L) if no == 1 else (B, L, no), **f32)      # what the loss sees (model.forward)
@@ -471,6 +475,18 @@ class FusedTrainer(object):
 
     def _ln_bwd(self, dy, xsum, a, mean, rstd, dres, dx, da, db):
         P = self.LB.ptr
+        if self.group_wgrad and self.gemm != "hipblaslt" and self._ln_slot < len(self.ws_ln_g):
+            # dx now; the (da, db) partials join the layer's one reducing launch (_reduce_flush)
+            import ctypes
+            buf = self.ws_ln_g[self._ln_slot]
+            self._ln_slot += 1
+            rows_out = ctypes.c_int(0)
+            self.LB.check(self.lib.ltrx_layernorm_bwd_partial(P(dy), P(xsum), P(a), P(mean), P(rstd), P(dres), self.rows, self.d,
+                                                              float(self.ln_eps), P(dx), P(buf), ctypes.byref(rows_out), self._st()),
+                          "layernorm_bwd_partial")
+            self._red_pending.append((buf.data_ptr(), rows_out.value, 2 * self.d, self.d, da.data_ptr()))
+            self._red_pending.append((buf.data_ptr() + 4 * self.d, rows_out.value, 2 * self.d, self.d, db.data_ptr()))
+            return
         self.LB.check(self.lib.ltrx_layernorm_bwd(P(dy), P(xsum), P(a), P(mean), P(rstd), P(dres), self.rows, self.d,
                                                   float(self.ln_eps), P(dx), P(da), P(db), P(self.ws_ln), self._st()),
                       "layernorm_bwd")
@@ -596,8 +612,10 @@ class FusedTrainer(object):
                                             x.shape[1], self._prec, 0, P(self.ws_tn), self._st()),
                       "gemm_tn(wgrad)")
 
-    def _wgrad_flush(self):
-        """the queued weight gradients of a layer as ONE ltrx_gemm_tn_group launch (+ one fixed-order slab reduce each)"""
+    def _wgrad_flush(self, defer_reduce=False):
+        """the queued weight gradients of a layer as ONE ltrx_gemm_tn_group launch; their partial slabs are summed by the call
+        (one launch per projection) or, with ``defer_reduce``, by the layer's _reduce_flush (the workspace must stay untouched
+        until then)"""
         q = self._wg_pending
         if not q:
             return
@@ -612,8 +630,34 @@ class FusedTrainer(object):
         ldb = ci(*[t[1].stride(0) for t in q])
         NP = ci(*[t[0].shape[1] for t in q])
         KP = ci(*[t[1].shape[1] for t in q])
+        if defer_reduce:
+            so, bso, sp = vp(), vp(), ctypes.c_int(0)
+            outs = (so, bso, ctypes.byref(sp))
+        else:
+            outs = (None, None, None)
         self.LB.check(self.lib.ltrx_gemm_tn_group(n, A, lda, Bm, ldb, C, bo, self.rows, NP, KP, self._prec, self.LB.ptr(self.ws_tn),
-                                                  self.ws_tn.numel(), self._st()), "gemm_tn_group(wgrad)")
+                                                  self.ws_tn.numel(), *outs, self._st()), "gemm_tn_group(wgrad)")
+        if defer_reduce and sp.value > 0:
+            for i, t in enumerate(q):
+                nw = t[0].shape[1] * t[1].shape[1]
+                self._red_pending.append((so[i], sp.value, nw, nw, t[2].data_ptr()))
+                if bso[i]:
+                    self._red_pending.append((bso[i], sp.value, t[0].shape[1], t[0].shape[1], t[3].data_ptr()))
+        q.clear()
+
+    def _reduce_flush(self):
+        """every pending fixed-order reduction of the layer (weight-gradient slabs, bias column sums, LayerNorm parameter-gradient
+        partials) in ONE launch (ltrx_reduce_group)"""
+        q = self._red_pending
+        self._ln_slot = 0
+        if not q:
+            return
+        import ctypes
+        n = len(q)
+        vp = ctypes.c_void_p * n
+        self.LB.check(self.lib.ltrx_reduce_group(n, vp(*[t[0] for t in q]), (ctypes.c_int * n)(*[t[1] for t in q]),
+                                                 (ctypes.c_size_t * n)(*[t[2] for t in q]), (ctypes.c_size_t * n)(*[t[3] for t in q]),
+                                                 vp(*[t[4] for t in q]), self._st()), "reduce_group")
         q.clear()
 
     # ---- the step body (capturable) ----------------------------------------------------------------------------
@@ -758,9 +802,10 @@ class FusedTrainer(object):
                     dq[self.n_valid:M].zero_()
                 self._lin_wgrad(dq, st["xn0"], st["gwqkv"], st["gbqkv"], defer=True)
                 self._lin_dgrad(dq, st["wqkv"], st.get("wqkvT"), self.tmp_d)
-                self._wgrad_flush()
+                self._wgrad_flush(defer_reduce=True)
                 self._ln_bwd(self.tmp_d, st["xin"], W(n0.a_2), st["mean0"], st["rstd0"], ds, other, G(n0.a_2), G(n0.b_2))
                 ds, other = other, ds                              # ds = d loss / d (layer input)
+                self._reduce_flush()                               # the layer's parameter gradients are final from here
                 self._bucket_done(self.N - 1 - i)
         else:
             ds, other = ga, gb

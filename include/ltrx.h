@@ -191,6 +191,11 @@ size_t ltrx_layernorm_bwd_workspace_bytes(int rows, int D);
 int ltrx_layernorm_bwd(const float* dy, const float* xsum, const float* a, const float* mean, const float* rstd,
                        const float* dres_in, int rows, int D, float eps, float* dx_out, float* da_out, float* db_out,
                        void* ws, ltrx_stream_t stream);
+/* ltrx_layernorm_bwd without the parameter-gradient reduction: dx_out is final; ws holds *partial_rows_out rows of [da(D) | db(D)]
+ * partials (row stride 2 D) that the caller sums, e.g. as two entries of ltrx_reduce_group. */
+int ltrx_layernorm_bwd_partial(const float* dy, const float* xsum, const float* a, const float* mean, const float* rstd,
+                               const float* dres_in, int rows, int D, float eps, float* dx_out, void* ws, int* partial_rows_out,
+                               ltrx_stream_t stream);
 
 /* transformer.py:137-156 attention() as used by MultiHeadedAttention.forward (:178-203), fused flash-style:
  * q,k,v,o are [B, L, h, d_k] views of the projection outputs (element (b,l,head,c) at ((b*L+l)*h+head)*d_k + c
@@ -339,9 +344,21 @@ int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, flo
  * every row count <= M). */
 #define LTRX_GEMM_TN_GROUP_MAX 4
 size_t ltrx_gemm_tn_group_workspace_bytes(int nprob, int M, const int* NP, const int* KP);
+/* slabs_out / bias_slabs_out / splits_out: all NULL = the call reduces its partial slabs itself (one launch per problem); all given =
+ * the reduction is left to the caller: problem p's dW is the fixed-order sum of *splits_out slabs of NP[p]*KP[p] floats at slabs_out[p],
+ * its bias gradient the column sums of *splits_out rows of NP[p] floats at bias_slabs_out[p] (NULL where bias_out[p] is NULL) -- entries
+ * for ltrx_reduce_group, which sums them together with other partials of the same layer in one launch.  *splits_out == 0: the call took
+ * the per-problem path and C / bias_out are already final. */
 int ltrx_gemm_tn_group(int nprob, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
                        float* const* bias_out, int M, const int* NP, const int* KP, int strict, void* ws, size_t ws_bytes,
-                       ltrx_stream_t stream);
+                       const float** slabs_out, const float** bias_slabs_out, int* splits_out, ltrx_stream_t stream);
+/* n <= LTRX_REDUCE_GROUP_MAX independent reductions in one launch: dst[i][c] = sum_{s < splits[i]} src[i][s * row_stride[i] + c] for
+ * c < cols[i], each in a fixed order (deterministic).  Entries with splits[i] <= 0 are skipped.  (The engine sums the weight-gradient
+ * slabs of an encoder layer and the parameter-gradient partials of its LayerNorms with it: 11 launches -> 1; autograd's per-tensor
+ * accumulation in loss.backward(), allrank/training/train_utils.py:23.) */
+#define LTRX_REDUCE_GROUP_MAX 16
+int ltrx_reduce_group(int n, const float* const* src, const int* splits, const size_t* row_stride, const size_t* cols, float* const* dst,
+                      ltrx_stream_t stream);
 
 /* Model options around the encoder on the explicit step (allrank_amd/csrc/ltrx_extras.hip):
  *   ltrx_layernorm_torch_fwd: FCModel.input_norm = nn.LayerNorm(n_features) (model.py:27,39): biased variance, eps inside the

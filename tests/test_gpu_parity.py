@@ -1303,8 +1303,39 @@ def test_grouped_wgrad_launch_matches_fp64_is_deterministic_and_falls_back():
             vp = ctypes.c_void_p * n
             LB.check(lib.ltrx_gemm_tn_group(n, vp(*[t.data_ptr() for t in At]), lda, vp(*[t.data_ptr() for t in Bt]), ldb,
                                             vp(*[t.data_ptr() for t in Cs]), vp(*[(g.data_ptr() if g is not None else None) for g in gbs]),
-                                            Mm, NP, KP, 0, LB.ptr(ws), ws.numel(), None), "gemm_tn_group")
+                                            Mm, NP, KP, 0, LB.ptr(ws), ws.numel(), None, None, None, None), "gemm_tn_group")
             runs.append((Cs, gbs))
+        # deferred form: the call leaves the slabs, ltrx_reduce_group sums them (all problems + an unrelated strided entry in one
+        # launch) -- bit-identical to the call's own reduction
+        Cs = [torch.full((a, b), float("nan"), device=DEV) for a, b in probs]
+        gbs = [torch.full((a,), float("nan"), device=DEV) if (i % 2 == 0) else None for i, (a, _) in enumerate(probs)]
+        so, bso, sp = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), ctypes.c_int(-1)
+        LB.check(lib.ltrx_gemm_tn_group(n, vp(*[t.data_ptr() for t in At]), lda, vp(*[t.data_ptr() for t in Bt]), ldb,
+                                        vp(*[t.data_ptr() for t in Cs]), vp(*[(g.data_ptr() if g is not None else None) for g in gbs]),
+                                        Mm, NP, KP, 0, LB.ptr(ws), ws.numel(), so, bso, ctypes.byref(sp), None), "gemm_tn_group(deferred)")
+        part = _t(rng.standard_normal((37, 2 * 200)).astype(np.float32))                 # [rows][da(200) | db(200)] partials
+        da, db = torch.empty(200, device=DEV), torch.empty(200, device=DEV)
+        ent = [(part.data_ptr(), 37, 400, 200, da.data_ptr()), (part.data_ptr() + 800, 37, 400, 200, db.data_ptr())]
+        if sp.value > 0:
+            for i, (a, b) in enumerate(probs):
+                ent.append((so[i], sp.value, a * b, a * b, Cs[i].data_ptr()))
+                if gbs[i] is not None:
+                    assert bso[i]
+                    ent.append((bso[i], sp.value, a, a, gbs[i].data_ptr()))
+                else:
+                    assert not bso[i]
+        else:
+            assert any(a % 256 or b % 256 for a, b in probs)                              # only the fallback case leaves nothing to sum
+        ne = len(ent)
+        LB.check(lib.ltrx_reduce_group(ne, (ctypes.c_void_p * ne)(*[e[0] for e in ent]), (ctypes.c_int * ne)(*[e[1] for e in ent]),
+                                       (ctypes.c_size_t * ne)(*[e[2] for e in ent]), (ctypes.c_size_t * ne)(*[e[3] for e in ent]),
+                                       (ctypes.c_void_p * ne)(*[e[4] for e in ent]), None), "reduce_group")
+        for i in range(n):
+            assert torch.equal(Cs[i], runs[0][0][i]), ("deferred", Mm, probs[i])
+            if gbs[i] is not None:
+                assert torch.equal(gbs[i], runs[0][1][i])
+        p64 = part.cpu().numpy().astype(np.float64)
+        assert np.abs(da.cpu().numpy() - p64[:, :200].sum(0)).max() < 1e-5 and np.abs(db.cpu().numpy() - p64[:, 200:].sum(0)).max() < 1e-5
         for i, (a, b) in enumerate(probs):
             A64 = As[i][:, :a].astype(np.float64)
             ref = A64.T @ Bs[i].astype(np.float64)
@@ -1323,7 +1354,9 @@ def test_grouped_wgrad_launch_matches_fp64_is_deterministic_and_falls_back():
     a1, b1, c1 = torch.zeros((1024, 256), device=DEV), torch.zeros((1024, 256), device=DEV), torch.zeros((256, 256), device=DEV)
     one = (ctypes.c_int * 1)(256)
     assert lib.ltrx_gemm_tn_group(1, vp1(a1.data_ptr()), one, vp1(b1.data_ptr()), one, vp1(c1.data_ptr()), vp1(None), 1024, one, one, 0,
-                                  LB.ptr(ws), 16, None) != 0
+                                  LB.ptr(ws), 16, None, None, None, None) != 0
+    assert lib.ltrx_reduce_group(17, None, None, None, None, None, None) != 0
+    assert lib.ltrx_reduce_group(0, None, None, None, None, None, None) == 0
 
 
 def test_grouped_wgrad_step_equals_the_per_projection_step():
@@ -1353,9 +1386,12 @@ def test_grouped_wgrad_step_equals_the_per_projection_step():
             grads[grouped] = (loss, {k: p.grad.detach().clone() for k, p in m.named_parameters()})
             assert not ft._wg_pending
         assert grads[True][0] == grads[False][0]
+        # (a tensor whose gradient is pure cancellation noise -- the final norm's b_2 under listNet, whose d loss / d scores sum to 0
+        #  per slate -- is compared on the scale of the step's gradients, not on its own)
+        floor = 1e-2 * max(float(r.abs().max()) for r in grads[False][1].values())
         for k, g in grads[True][1].items():
             ref = grads[False][1][k]
-            tol = 2e-5 * max(1e-6, float(ref.abs().max()))
+            tol = 2e-5 * max(floor, float(ref.abs().max()))
             assert float((g - ref).abs().max()) <= tol, (pdrop, k, float((g - ref).abs().max()), tol)
 
 
