@@ -172,6 +172,25 @@ inline ltrx::DropSpec ltrx_make_drop(float p, uint32_t seed) {
 namespace ltrx {
 }  // namespace ltrx
 
+// 4 floats -> the 16 bytes {hi0..hi3, lo0..lo3} (bf16) of a pre-split operand image: hi = bf16(x), lo = bf16(x - hi), the same
+// expressions the GEMM kernels apply while staging (ltrx_gemm.hip split4), so an image written anywhere is bit-identical to the
+// on-the-fly split
+typedef __bf16 ltrx_bf16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ltrx_split_image4(const float4 v) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  ltrx_bf16x4_t hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 h = (__bf16)x[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(x[e] - (float)h);
+  }
+  float4 o;
+  *reinterpret_cast<ltrx_bf16x4_t*>(&o.x) = hi;
+  *reinterpret_cast<ltrx_bf16x4_t*>(&o.z) = lo;
+  return o;
+}
+
 // Per-slate work arrays of the listwise loss kernels (`narr` floats per item): in LDS (extern __shared__) while they fit the CU's
 // 160 KB, otherwise in a global workspace that the SAME kernel body addresses through a generic pointer (template flag GWS): the
 // arrays of a slate stay in its CU's L1 / the XCD's L2, and __syncthreads() orders global accesses inside a workgroup exactly as it

@@ -441,6 +441,101 @@ extern "C" int ltrx_transpose_batch(const float* src_base, float* dst_base, cons
   return LTRX_OK;
 }
 
+// The whole per-step weight-image refresh in ONE launch (it was a transpose launch and two image launches, the second re-reading
+// the transposed copies): workgroups 0 .. total_tiles-1 transpose their 32 x 32 tile and write BOTH the fp32 transposed copy and its
+// pre-split bf16 hi/lo image (each thread owns 4 consecutive elements of a transposed row = one 16-byte image group); the remaining
+// workgroups split the untransposed flat parameter buffer.  Needs every transposed matrix to have rows % 4 == 0 (the image groups
+// of 4 must not straddle a transposed row) -- the host checks and otherwise keeps the three-launch form.
+__global__ void __launch_bounds__(256) ltrx_weight_images_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
+                                                                 float4* __restrict__ dst_image, const int64_t* __restrict__ desc,
+                                                                 const int32_t* __restrict__ tile_start, int n, int total_tiles,
+                                                                 float4* __restrict__ src_image, size_t nflat4) {
+  if ((int)blockIdx.x >= total_tiles) {
+    const size_t nb = gridDim.x - total_tiles;
+    for (size_t i = (size_t)(blockIdx.x - total_tiles) * blockDim.x + threadIdx.x; i < nflat4; i += nb * blockDim.x)
+      src_image[i] = ltrx_split_image4(reinterpret_cast<const float4*>(src_base)[i]);
+    return;
+  }
+  __shared__ float tile[32][33];
+  int m = 0;
+  while (m + 1 < n && (int)blockIdx.x >= tile_start[m + 1]) ++m;
+  const int64_t so = desc[4 * m + 0], dof = desc[4 * m + 1];
+  const int rows = (int)desc[4 * m + 2], cols = (int)desc[4 * m + 3];
+  const int t = blockIdx.x - tile_start[m];
+  const int tiles_c = (cols + 31) / 32;
+  const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  const float* src = src_base + so;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    tile[ty + 8 * k][tx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  const int cl = threadIdx.x >> 3, r4 = (threadIdx.x & 7) * 4;  // transposed row c0 + cl, its elements r0 + r4 .. + 3
+  const int c = c0 + cl, r = r0 + r4;
+  if (c < cols && r < rows) {                                   // (rows % 4 == 0: a group is inside the matrix or outside)
+    const float4 v = make_float4(tile[r4][cl], tile[r4 + 1][cl], tile[r4 + 2][cl], tile[r4 + 3][cl]);
+    const size_t o = (size_t)dof + (size_t)c * rows + r;        // multiple of 4: dof and rows are
+    *reinterpret_cast<float4*>(dst_base + o) = v;
+    dst_image[o >> 2] = ltrx_split_image4(v);
+  }
+}
+
+extern "C" int ltrx_weight_images(const float* src_base, size_t nflat, void* src_image, float* dst_base, void* dst_image,
+                                  const int64_t* desc, const int32_t* tile_start, int n, int total_tiles, ltrx_stream_t stream) {
+  if (!src_base || !src_image || (nflat & 3) || (((uintptr_t)src_base | (uintptr_t)src_image) & 15)) return LTRX_EINVAL;
+  if (n < 0 || total_tiles < 0 || (n > 0 && (!dst_base || !dst_image || !desc || !tile_start || total_tiles <= 0))) return LTRX_EINVAL;
+  if (n > 0 && (((uintptr_t)dst_base | (uintptr_t)dst_image) & 15)) return LTRX_EINVAL;
+  if (n == 0) total_tiles = 0;
+  size_t blocks = (nflat / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks == 0 && total_tiles == 0) return LTRX_OK;
+  hipLaunchKernelGGL(ltrx_weight_images_kernel, dim3((unsigned)(total_tiles + blocks)), dim3(256), 0, (hipStream_t)stream, src_base,
+                     dst_base, reinterpret_cast<float4*>(dst_image), desc, tile_start, n, total_tiles,
+                     reinterpret_cast<float4*>(src_image), nflat / 4);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
+// One launch that takes a batch into the step's static input buffers (they are what a captured hipGraph reads): x and y copied,
+// the padding mask y == pad_value written next to them (it was four launches: two copies, a compare, a bool copy).
+__global__ void __launch_bounds__(256) ltrx_ingest_batch_kernel(const float* __restrict__ x, const float* __restrict__ y, size_t nx,
+                                                                size_t ny, float pad_value, float* __restrict__ x_dst,
+                                                                float* __restrict__ y_dst, unsigned char* __restrict__ mask_dst,
+                                                                int x_blocks, int vec) {
+  if ((int)blockIdx.x >= x_blocks) {
+    const size_t i = (size_t)(blockIdx.x - x_blocks) * blockDim.x + threadIdx.x;
+    if (i < ny) {
+      const float v = y[i];
+      y_dst[i] = v;
+      mask_dst[i] = (v == pad_value) ? 1 : 0;
+    }
+    return;
+  }
+  const size_t stride = (size_t)x_blocks * blockDim.x;
+  if (vec) {
+    const size_t n4 = nx >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+      reinterpret_cast<float4*>(x_dst)[i] = reinterpret_cast<const float4*>(x)[i];
+  } else {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += stride) x_dst[i] = x[i];
+  }
+}
+
+extern "C" int ltrx_ingest_batch(const float* x, const float* y, size_t nx, size_t ny, float pad_value, float* x_dst, float* y_dst,
+                                 unsigned char* mask_dst, ltrx_stream_t stream) {
+  if (!y || !y_dst || !mask_dst || ny == 0 || (nx > 0 && (!x || !x_dst))) return LTRX_EINVAL;
+  const int vec = ((nx & 3) == 0 && (((uintptr_t)x | (uintptr_t)x_dst) & 15) == 0) ? 1 : 0;
+  size_t xb = ((vec ? nx / 4 : nx) + 255) / 256;
+  if (xb > 4096) xb = 4096;
+  const size_t yb = (ny + 255) / 256;
+  hipLaunchKernelGGL(ltrx_ingest_batch_kernel, dim3((unsigned)(xb + yb)), dim3(256), 0, (hipStream_t)stream, x, y, nx, ny, pad_value,
+                     x_dst, y_dst, mask_dst, (int)xb, vec);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Row gather / scatter for compacted (variable-length) batches: the valid items of a padded [B, L] batch are packed into
 // consecutive rows before the row-wise part of the step (dataset.py:28-38 pads every slate to the batch's slate length;

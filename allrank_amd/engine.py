@@ -315,6 +315,8 @@ class FusedTrainer(object):
                 p_s1=float(lay.sublayer[1].dropout.p) if dropout else 0.0,
                 s_att=self._site(4 * i), s_ff=self._site(4 * i + 1), s_s0=self._site(4 * i + 2), s_s1=self._site(4 * i + 3))
             self.layers.append(st)
+        # (no active dropout site -> no mask counter to advance: one launch less per step)
+        self._any_dropout = bool(self.p_fc or any(st[k] for st in self.layers for k in ("p_att", "p_ff", "p_s0", "p_s1")))
         if self.N:
             self.xsum_f = torch.zeros((M, d), **f32)
             self.xf = torch.zeros((M, d), **f32)
@@ -347,6 +349,7 @@ class FusedTrainer(object):
         self.ws_head = torch.empty(max(self.lib.ltrx_score_head_bwd_workspace_bytes(M, d), 64), dtype=torch.uint8, device=dev)
         self.fc_dgrad = [torch.zeros((M, s), **f32) for s in self.fc_sizes[1:-1]]
         big = max([(3 * d) * d, (self.dff * d) if self.N else 0] + [a * b for a, b in zip(self.fc_sizes[:-1], self.fc_sizes[1:])])
+        self._fused_images = False
         if self.gemm != "hipblaslt":
             nb = 0
             shapes = [(s1, s0) for s0, s1 in zip(self.fc_sizes[:-1], self.fc_sizes[1:])]
@@ -390,7 +393,9 @@ class FusedTrainer(object):
             # pre-split bf16 hi / lo IMAGES of the weights and of their transposes (same offsets as flat_p / flat_t): what the
             # large-tile NT GEMMs stage as operand B without splitting it again in every tile (ltrx_split_image, include/ltrx.h)
             self.flat_pi = torch.empty_like(self.flat_p)
-            self.flat_ti = torch.empty_like(self.flat_t)
+            self.flat_ti = torch.zeros_like(self.flat_t)
+            # one-launch refresh (ltrx_weight_images) when every transposed matrix keeps image groups of 4 inside a row
+            self._fused_images = self.nflat % 4 == 0 and all(r % 4 == 0 for _, r, _, _ in srcs)
             self._refresh_transposes()
         self.loss = FusedLoss(loss_name, B, L, dev, **(loss_args or {}))
         if (self.n_out > 1) != (loss_name == "ordinal") or (loss_name == "ordinal" and int(loss_args["n"]) != self.n_out):
@@ -506,6 +511,11 @@ class FusedTrainer(object):
         if self.gemm == "hipblaslt":
             return
         P = self.LB.ptr
+        if self._fused_images:
+            self.LB.check(self.lib.ltrx_weight_images(P(self.flat_p), self.nflat, P(self.flat_pi), P(self.flat_t), P(self.flat_ti),
+                                                      P(self._tdesc), P(self._tstart), self._tn, self._ttiles if self._tn else 0,
+                                                      self._st()), "weight_images")
+            return
         if self._tn:
             self.LB.check(self.lib.ltrx_transpose_batch(P(self.flat_p), P(self.flat_t), P(self._tdesc), P(self._tstart), self._tn,
                                                         self._ttiles, self._st()), "transpose_batch")
@@ -867,7 +877,8 @@ class FusedTrainer(object):
                       "adam_step")
 
     def _full(self):
-        self.LB.check(self.lib.ltrx_bump_u32(self.LB.ptr(self.drop_step), self._st()), "bump_u32")   # fresh masks every step
+        if self._any_dropout:
+            self.LB.check(self.lib.ltrx_bump_u32(self.LB.ptr(self.drop_step), self._st()), "bump_u32")   # fresh masks every step
         loss = self._body()
         self._wait_buckets()
         self._adam()
@@ -946,11 +957,20 @@ class FusedTrainer(object):
             # permutation lives in a persistent device buffer, so the refresh is safe under hipGraph replay
             self.loss.perm.copy_(torch.randperm(self.L, device=self.dev, generator=self._perm_gen))
         self._divisor = float(global_batch if global_batch is not None else self.B * self.world)
-        self.y_in.copy_(yb)
-        self.mask.copy_(yb == PADDED_Y_VALUE)
+        direct = (yb.dtype == torch.float32 and yb.is_contiguous() and yb.is_cuda and yb.numel() == self.M
+                  and (self.compact or (xb.dtype == torch.float32 and xb.is_contiguous() and xb.is_cuda
+                                        and xb.numel() == self.x_in.numel())))
+        if direct:                                                # x, y and the padding mask in one launch
+            P = self.LB.ptr
+            self.LB.check(self.lib.ltrx_ingest_batch(None if self.compact else P(xb), P(yb), 0 if self.compact else xb.numel(), self.M,
+                                                     float(PADDED_Y_VALUE), None if self.compact else P(self.x_in), P(self.y_in),
+                                                     P(self.mask), self._st()), "ingest_batch")
+        else:
+            self.y_in.copy_(yb)
+            self.mask.copy_(yb == PADDED_Y_VALUE)
         if self.compact:
             self._pack(xb.reshape(self.M, -1).contiguous(), lengths)
-        else:
+        elif not direct:
             self.x_in.copy_(xb.reshape(self.M, -1))
         if self.pos is not None:
             if indices is None:

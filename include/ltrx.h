@@ -323,6 +323,17 @@ int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, const void* B
  * is for: nn.Linear weights (model.py:35-44, transformer.py:193-227) change once per optimizer step but are staged by every tile of
  * every GEMM of the step.  ltrx_split_image: n floats (multiple of 4), src and dst 16-byte aligned. */
 int ltrx_split_image(const float* src, void* dst, size_t n, ltrx_stream_t stream);
+/* The engine's whole per-step weight refresh in one launch: the image of the flat parameter buffer (src_base[0..nflat) -> src_image,
+ * as ltrx_split_image) and, for the n matrices of desc / tile_start (as ltrx_transpose_batch), the transposed fp32 copy in dst_base
+ * AND its image in dst_image (same offsets).  Requires nflat % 4 == 0, 16-byte aligned buffers, 4-float aligned dst offsets and
+ * rows % 4 == 0 for every matrix.  Bit-identical to ltrx_transpose_batch + 2 x ltrx_split_image. */
+int ltrx_weight_images(const float* src_base, size_t nflat, void* src_image, float* dst_base, void* dst_image, const int64_t* desc,
+                       const int32_t* tile_start, int n, int total_tiles, ltrx_stream_t stream);
+/* A batch into the step's static input buffers in one launch: x_dst = x (nx floats; nx may be 0), y_dst = y (ny floats),
+ * mask_dst[i] = (y[i] == pad_value) -- the padding mask the reference derives per batch (allrank/training/train_utils.py:19,
+ * allrank/data/dataset_loading.py:15 PADDED_Y_VALUE). */
+int ltrx_ingest_batch(const float* x, const float* y, size_t nx, size_t ny, float pad_value, float* x_dst, float* y_dst,
+                      unsigned char* mask_dst, ltrx_stream_t stream);
 /* `tile` (both GEMMs) is a per-call tuning argument: 0 = automatic choice per shape (what every product call passes);
  * ltrx_gemm_nt: 1 128x128x32, 2 128x128x64, 3 256x128x32, 4 256x128x64, 6 256x256x32, 7 128x256x32 (the large-tile forms
  * need N % 256 == 0, K % 32 == 0); ltrx_gemm_tn: 1 = the 128x128 kernel even where the 256x256 one applies.  Results do not

@@ -1395,6 +1395,59 @@ def test_grouped_wgrad_step_equals_the_per_projection_step():
             assert float((g - ref).abs().max()) <= tol, (pdrop, k, float((g - ref).abs().max()), tol)
 
 
+def test_one_launch_weight_refresh_and_batch_ingest_are_bit_identical_to_the_separate_launches():
+    """ltrx_weight_images == ltrx_transpose_batch + ltrx_split_image x 2 (bits); ltrx_ingest_batch == copy + (y == pad) (bits),
+    with and without x, vector and scalar x paths."""
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    rng = np.random.default_rng(31)
+    mats = [(512, 136), (1536, 512), (96, 40), (2048, 512)]                      # [rows, cols] inside the flat buffer
+    offs, o = [], 0
+    for r, c in mats:
+        offs.append(o)
+        o += (r * c + 3) // 4 * 4
+    nflat = o + 8
+    flat = _t(rng.standard_normal(nflat).astype(np.float32))
+    desc, tstart, od = [], [0], 0
+    for (r, c), so in zip(mats, offs):
+        desc += [so, od, r, c]
+        tstart.append(tstart[-1] + ((r + 31) // 32) * ((c + 31) // 32))
+        od += (r * c + 3) // 4 * 4
+    tdesc = torch.tensor(desc, dtype=torch.int64, device=DEV)
+    tst = torch.tensor(tstart, dtype=torch.int32, device=DEV)
+    ft_a, ft_b = torch.zeros(od, device=DEV), torch.zeros(od, device=DEV)
+    ia_p, ib_p = torch.zeros(nflat, device=DEV), torch.zeros(nflat, device=DEV)
+    ia_t, ib_t = torch.zeros(od, device=DEV), torch.zeros(od, device=DEV)
+    LB.check(lib.ltrx_transpose_batch(LB.ptr(flat), LB.ptr(ft_a), LB.ptr(tdesc), LB.ptr(tst), len(mats), tstart[-1], None), "transpose_batch")
+    LB.check(lib.ltrx_split_image(LB.ptr(ft_a), LB.ptr(ia_t), od, None), "split_image")
+    LB.check(lib.ltrx_split_image(LB.ptr(flat), LB.ptr(ia_p), nflat, None), "split_image")
+    LB.check(lib.ltrx_weight_images(LB.ptr(flat), nflat, LB.ptr(ib_p), LB.ptr(ft_b), LB.ptr(ib_t), LB.ptr(tdesc), LB.ptr(tst), len(mats),
+                                    tstart[-1], None), "weight_images")
+    assert torch.equal(ft_a, ft_b)
+    assert torch.equal(ia_p.view(torch.int32), ib_p.view(torch.int32))
+    assert torch.equal(ia_t.view(torch.int32), ib_t.view(torch.int32))
+    for (r, c), so, k in zip(mats, offs, range(len(mats))):
+        assert torch.equal(ft_b[desc[4 * k + 1]:desc[4 * k + 1] + r * c].view(c, r), flat[so:so + r * c].view(r, c).t())
+    ib_p.zero_()
+    LB.check(lib.ltrx_weight_images(LB.ptr(flat), nflat, LB.ptr(ib_p), None, None, None, None, 0, 0, None), "weight_images(no transposes)")
+    assert torch.equal(ia_p.view(torch.int32), ib_p.view(torch.int32))
+    assert lib.ltrx_weight_images(LB.ptr(flat), nflat + 1, LB.ptr(ib_p), None, None, None, None, 0, 0, None) != 0
+    for (B, L, F) in [(8, 240, 136), (3, 7, 5)]:
+        x = _t(rng.standard_normal((B, L, F)).astype(np.float32))
+        yv = rng.integers(0, 5, (B, L)).astype(np.float32)
+        yv[1, L // 2:] = -1
+        y = _t(yv)
+        xd, yd = torch.full((B * L, F), 7.0, device=DEV), torch.full((B, L), 7.0, device=DEV)
+        md = torch.full((B, L), 9, dtype=torch.uint8, device=DEV)
+        LB.check(lib.ltrx_ingest_batch(LB.ptr(x), LB.ptr(y), x.numel(), y.numel(), -1.0, LB.ptr(xd), LB.ptr(yd), LB.ptr(md), None), "ingest")
+        assert torch.equal(xd.view(-1), x.view(-1)) and torch.equal(yd, y) and torch.equal(md.bool(), y == -1)
+        md.fill_(9)
+        yd.fill_(7.0)
+        LB.check(lib.ltrx_ingest_batch(None, LB.ptr(y), 0, y.numel(), -1.0, None, LB.ptr(yd), LB.ptr(md), None), "ingest(y only)")
+        assert torch.equal(yd, y) and torch.equal(md.bool(), y == -1)
+    assert lib.ltrx_ingest_batch(None, LB.ptr(y), 5, y.numel(), -1.0, None, LB.ptr(yd), LB.ptr(md), None) != 0
+
+
 def test_row4_losses_edge_shapes():
     """single-item slates, a fully padded slate, the maximum slate length and a single slate: engine == oracle (NaN where
     the reference's own arithmetic is 0/0)."""

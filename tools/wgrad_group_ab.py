@@ -38,6 +38,7 @@ def main():
                 torch.cuda.synchronize()
                 res[grouped].append((time.perf_counter() - t0) / 20 * 1e3)
         g, s = min(res[True]), min(res[False])
+        print("   loss after the timed steps: grouped %.6f  per-projection %.6f" % (trs[True].step(x, y).item(), trs[False].step(x, y).item()))
         print("slates %4d: grouped %.3f ms/step (%.2f M items/s)   per-projection %.3f ms/step (%.2f M items/s)   gain %.1f %%"
               % (B, g, B * L / g / 1e3, s, B * L / s / 1e3, (s / g - 1) * 100), flush=True)
 
