@@ -223,6 +223,21 @@ def cpu_baseline(w, L, seconds_budget=20.0):
                                               points=ref["points"])
     except Exception:
         pass
+    # round 4: ONE metered run with the reference staged in an ignored scratch directory on the GPU box (never committed; removed
+    # after the run): its own loss_batch on that box's host cores, and on the MI355X itself through stock PyTorch-ROCm.  Static
+    # figures with their provenance (profiles/r04_reference_on_gpu_box.md), printed beside the live numbers of this run.
+    try:
+        if w["N"] == 2 and w["d_ff"] == 2048 and w["n_features"] == 136 and L == 240 and w["loss"] == "approxNDCGLoss":
+            rc = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_cpu_timing_gpubox.json")))
+            out["reference_gpu_box_cpu"] = dict(value=rc["value"], unit=rc["unit"], host_cores=rc["cores"], cpu=rc.get("cpu"),
+                                                kind="reference (allrank loss_batch on CPU torch %s, GPU box host, round-4 staged run)" % rc.get("torch"),
+                                                points=rc["points"])
+            rg = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_gpu_timing_gpubox.json")))
+            out["reference_on_this_gpu"] = dict(value=rg["value"], unit=rg["unit"],
+                                                kind="reference (unmodified allrank loss_batch, stock PyTorch-ROCm %s on the MI355X, round-4 staged run)" % rg.get("torch"),
+                                                points=rg["points"])
+    except Exception:
+        pass
     return out
 
 
