@@ -373,6 +373,15 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
   const int q = lane & 3;
   const bool b0 = q & 1, b1 = q & 2;
   const int cq = l31 & ~3;
+  // act 4 / 5: the ReLU(+dropout) mask as ONE BIT per element instead of the saved fp32 activation.  The lane that produces an
+  // element in the forward launch (act 4) is the lane that needs its mask in the input-gradient launch (act 5: same M, N, tiling),
+  // so the 128 bits of a lane's 32 row-quads travel as one private 16-byte word per (tile, thread): 1/32 of the bytes act 2 reads.
+  unsigned int mbits[4] = {0u, 0u, 0u, 0u};
+  uint4* const mask_words = reinterpret_cast<uint4*>(const_cast<float*>(aux)) + (size_t)id * 512 + threadIdx.x;
+  if (act == 5) {
+    const uint4 w = *mask_words;
+    mbits[0] = w.x; mbits[1] = w.y; mbits[2] = w.z; mbits[3] = w.w;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wc * 64 + j * 32 + cq;
@@ -403,10 +412,16 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
         const int row = m0 + wr * (BM / 2) + i * 32 + 8 * g + 4 * half + q;
         if (TAIL && row >= M) continue;
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        if (act == 1) {
+        if (act == 1 || act == 4) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        if (act == 2) {
+        if (act == 5) {
+          const unsigned int nb_ = mbits[((j * RI + i) * 4 + g) >> 3] >> ((((j * RI + i) * 4 + g) & 7) * 4);
+          v.x = (nb_ & 1u) ? v.x * drop.inv_keep : 0.f;
+          v.y = (nb_ & 2u) ? v.y * drop.inv_keep : 0.f;
+          v.z = (nb_ & 4u) ? v.z * drop.inv_keep : 0.f;
+          v.w = (nb_ & 8u) ? v.w * drop.inv_keep : 0.f;
+        } else if (act == 2) {
           v.x = (ax[g].x > 0.f) ? v.x * drop.inv_keep : 0.f;
           v.y = (ax[g].y > 0.f) ? v.y * drop.inv_keep : 0.f;
           v.z = (ax[g].z > 0.f) ? v.z * drop.inv_keep : 0.f;
@@ -421,10 +436,14 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
         if (act == 3) {      // SublayerConnection: x + dropout(sublayer(norm(x))) (transformer.py:98-106), the stream read here
           v.x += ax[g].x; v.y += ax[g].y; v.z += ax[g].z; v.w += ax[g].w;
         }
+        if (act == 4)        // (after the dropout scaling: a dropped unit is 0 in the saved activation and passes no gradient)
+          mbits[((j * RI + i) * 4 + g) >> 3] |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
+                                                << ((((j * RI + i) * 4 + g) & 7) * 4);
         __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(C + (size_t)row * ldc + col));
       }
     }
   }
+  if (act == 4) *mask_words = make_uint4(mbits[0], mbits[1], mbits[2], mbits[3]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -880,13 +899,27 @@ static void launch_nt(const float* A, int lda, const float* B, int ldb, float* C
                      ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step);
 }
 
+// bytes of the one-bit ReLU mask of an [M, N] activation (acts 4 / 5 of ltrx_gemm_nt), 0 where that form does not apply: the mask is
+// kept in the 256 x 256 tile kernel's (tile, thread) order, so both launches must take that kernel whatever their K, dropout and
+// epilogue -- N a multiple of 256 and a tile count the dispatch below sends there unconditionally.
+extern "C" size_t ltrx_gemm_nt_relu_bits_bytes(int M, int N) {
+  if (M <= 0 || N <= 0 || (N % 256)) return 0;
+  const size_t t = (size_t)((M + 255) / 256) * (N / 256);
+  if (!(t >= 380 || (t >= 168 && t <= 256))) return 0;
+  return t * 512 * 16;
+}
+
 extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, const void* B_image, float* C, int ldc, int M, int N, int K,
                             const float* bias, int act, const float* aux, int ldaux, float drop_p, uint32_t drop_seed,
                             const uint32_t* drop_step, int strict, int tile, ltrx_stream_t stream) {
-  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 3 || tile < 0) return LTRX_EINVAL;
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 5 || tile < 0) return LTRX_EINVAL;
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return LTRX_EINVAL;
   const ltrx::DropSpec drop = ltrx_make_drop(drop_p, drop_seed);
   if ((act == 2 || act == 3) && (!aux || ldaux < N)) return LTRX_EINVAL;
+  if (act == 4 || act == 5) {        // the one-bit mask lives in the large-tile kernel's own (tile, thread) order: only where it runs
+    if (!aux || ((uintptr_t)aux & 15) || tile != 0 || strict == 1 || ltrx_gemm_nt_relu_bits_bytes(M, N) == 0) return LTRX_EUNSUPPORTED;
+    ldaux = 0;
+  }
   if ((K & 3) || (lda & 3) || (ldb & 3) || lda < K || ldb < K || ldc < N) return LTRX_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   int v = tile;
@@ -898,6 +931,7 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, co
   // large-tile kernel: exact multiples only, and enough tiles to cover the 256 CUs at least ~1.4 times
   const bool vec_epi = (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
                        (!aux || ((ldaux & 3) == 0 && ((uintptr_t)aux & 15) == 0));      // 16-byte epilogue accesses
+  if ((act == 4 || act == 5) && (!vec_epi || (K % 32))) return LTRX_EUNSUPPORTED;
   const bool plain = strict == 2;                     // precision code: 0 = three products, 1 = six (strict), 2 = one (plain bf16)
   if (strict == 2) strict = 0;
   if (v == 0 && !strict && (N % 256) == 0 && (K % 32) == 0 && vec_epi) {

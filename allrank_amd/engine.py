@@ -86,7 +86,7 @@ class FusedTrainer(object):
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
                  optimizer="Adam", weight_decay=0.0, momentum=0.0, nesterov=False,
                  use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None, compact=False,
-                 weight_images=True, fc_step=True, group_wgrad=True):
+                 weight_images=True, fc_step=True, group_wgrad=True, relu_bits=True):
         """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
         products), "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs), or "bf16" -- the THROUGHPUT mode: one bf16
         product per contraction in the dense projections AND in attention (fp32 storage, accumulation, LayerNorm, softmax,
@@ -110,7 +110,9 @@ class FusedTrainer(object):
         matrix-vector product per slate with the exact rank-1 gradients (ltrx_fc_linear_listnet_step: fp32 FMAs, the slate in registers,
         HBM-bound).  ``self.fcstep`` tells which one is active (False / True / "collapse").
         group_wgrad=True: the four weight gradients of an encoder layer run as one ltrx_gemm_tn_group launch (4x fewer partial slabs
-        to write and reduce); False = one ltrx_gemm_tn per projection (A/B runs)."""
+        to write and reduce); False = one ltrx_gemm_tn per projection (A/B runs).
+        relu_bits=True: the feed-forward ReLU(+dropout) mask travels from the forward GEMM to the input-gradient GEMM as one bit per
+        element (ltrx_gemm_nt acts 4 / 5) instead of being re-read from the saved fp32 activation; same results bit for bit."""
         import torch.nn as nn
         from . import _lib as LB
         from .losses import FusedLoss
@@ -315,6 +317,10 @@ class FusedTrainer(object):
                 p_s1=float(lay.sublayer[1].dropout.p) if dropout else 0.0,
                 s_att=self._site(4 * i), s_ff=self._site(4 * i + 1), s_s0=self._site(4 * i + 2), s_s1=self._site(4 * i + 3))
             self.layers.append(st)
+        if relu_bits and self.N and self.dff % 256 == 0 and gemm not in ("hipblaslt", "split_bf16_strict"):
+            # one bit per feed-forward activation (written by the forward GEMM, read by the input-gradient GEMM instead of r)
+            for st in self.layers:
+                st["rbits"] = torch.zeros(((M + 255) // 256) * (self.dff // 256) * 8192, dtype=torch.uint8, device=dev)
         # (no active dropout site -> no mask counter to advance: one launch less per step)
         self._any_dropout = bool(self.p_fc or any(st[k] for st in self.layers for k in ("p_att", "p_ff", "p_s0", "p_s1")))
         if self.N:
@@ -571,7 +577,17 @@ class FusedTrainer(object):
         else:
             wait()
 
-    def _lin_fwd(self, x, w, b, out, act=0, p=0.0, seed=0, res=None):
+    def _relu_bits(self, st):
+        """the one-bit ReLU mask buffer of a layer's feed-forward activation for THIS step's row count, or None where the form does
+        not apply (ltrx_gemm_nt_relu_bits_bytes: the large-tile GEMM must run both launches) -- then the input-gradient GEMM reads
+        the saved fp32 activation instead (act 2)"""
+        buf = st.get("rbits")
+        if buf is None or self.gemm in ("hipblaslt", "split_bf16_strict"):
+            return None
+        need = self.lib.ltrx_gemm_nt_relu_bits_bytes(self.rows, self.dff)
+        return buf if 0 < need <= buf.numel() else None
+
+    def _lin_fwd(self, x, w, b, out, act=0, p=0.0, seed=0, res=None, bits=None):
         """out = drop_p(act(x w^T + b)) [+ res]   (nn.Linear forward, act 1 = ReLU; dropout in the epilogue; ``res`` = the
         residual stream of the SublayerConnection this projection closes, transformer.py:98-106: added in the epilogue, so the
         sum is written once by the GEMM instead of being re-read and re-written by the LayerNorm that follows)"""
@@ -586,11 +602,16 @@ class FusedTrainer(object):
                 out[:n].add_(res[:n])
             return
         P = self.LB.ptr
+        if bits is not None and act == 1:                         # ReLU + its one-bit mask for the backward (act 4)
+            self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), self._img(w), P(out), out.stride(0), self.rows,
+                                                w.shape[0], x.shape[1], P(b), 4, P(bits), 0, float(p), seed, P(self.drop_step), self._prec, 0,
+                                                self._st()), "gemm_nt(fwd, relu bits)")
+            return
         self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), self._img(w), P(out), out.stride(0), self.rows, w.shape[0],
                                             x.shape[1], P(b), 3 if res is not None else act, P(res), res.stride(0) if res is not None else 0,
                                             float(p), seed, P(self.drop_step), self._prec, 0, self._st()), "gemm_nt(fwd)")
 
-    def _lin_dgrad(self, dy, w, wT, out, relu_of=None, p=0.0, seed=0):
+    def _lin_dgrad(self, dy, w, wT, out, relu_of=None, p=0.0, seed=0, bits=None):
         """out = dy w   (input gradient of nn.Linear); wT = w^T contiguous.  With ``relu_of`` (the saved post-ReLU,
         post-dropout activation that produced the layer input) the ReLU(+dropout p) backward mask is applied in the GEMM
         epilogue; without it, p > 0 re-applies the dropout mask of site ``seed`` (identity activation)."""
@@ -602,6 +623,11 @@ class FusedTrainer(object):
                 self._drop_apply(out, out, p, seed)
             return
         P = self.LB.ptr
+        if bits is not None and relu_of is not None:              # the mask written by the forward launch (act 5): 1/32 of the bytes
+            self.LB.check(self.lib.ltrx_gemm_nt(P(dy), dy.stride(0), P(wT), wT.stride(0), self._img(wT), P(out), out.stride(0), self.rows,
+                                                wT.shape[0], dy.shape[1], None, 5, P(bits), 0, float(p), seed, P(self.drop_step),
+                                                self._prec, 0, self._st()), "gemm_nt(dgrad, relu bits)")
+            return
         self.LB.check(self.lib.ltrx_gemm_nt(P(dy), dy.stride(0), P(wT), wT.stride(0), self._img(wT), P(out), out.stride(0), self.rows,
                                             wT.shape[0], dy.shape[1], None, 2 if relu_of is not None else 0, P(relu_of),
                                             relu_of.stride(0) if relu_of is not None else 0, float(p), seed, P(self.drop_step),
@@ -717,7 +743,8 @@ class FusedTrainer(object):
             if self.probe is not None and train:                  # bench.py: HIP events around the roofline kernel, in the step
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            self._lin_fwd(st["xn1"], W(ff.w_1.weight), W(ff.w_1.bias), st["r"], 1, dp(st["p_ff"]), st["s_ff"])
+            self._lin_fwd(st["xn1"], W(ff.w_1.weight), W(ff.w_1.bias), st["r"], 1, dp(st["p_ff"]), st["s_ff"],
+                          bits=self._relu_bits(st) if train else None)
             if self.probe is not None and train:
                 ev1.record()
                 self.probe.append((ev0, ev1))
@@ -790,7 +817,8 @@ class FusedTrainer(object):
                 # (the four weight gradients of the layer are queued and run as one grouped launch before the first kernel that
                 #  overwrites one of their operands: the LN0 backward below, or the second use of the dropout buffer d_br)
                 self._lin_wgrad(db, st["r"], G(ff.w_2.weight), G(ff.w_2.bias), defer=True)
-                self._lin_dgrad(db, W(ff.w_2.weight), self._wT.get(id(ff.w_2.weight)), self.d_r, relu_of=st["r"], p=st["p_ff"])
+                self._lin_dgrad(db, W(ff.w_2.weight), self._wT.get(id(ff.w_2.weight)), self.d_r, relu_of=st["r"], p=st["p_ff"],
+                                bits=self._relu_bits(st))
                 self._lin_wgrad(self.d_r, st["xn1"], G(ff.w_1.weight), G(ff.w_1.bias), defer=True)
                 self._lin_dgrad(self.d_r, W(ff.w_1.weight), self._wT.get(id(ff.w_1.weight)), self.tmp_d)
                 self._ln_bwd(self.tmp_d, st["x1"], W(n1.a_2), st["mean1"], st["rstd1"], ds, other, G(n1.a_2), G(n1.b_2))

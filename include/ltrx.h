@@ -310,10 +310,15 @@ int ltrx_score_head_bwd(const float* dscores, const float* x, const float* w, in
  *                 backward fused into the input-gradient GEMM (aux = the saved post-activation tensor, ld ldaux);
  *                 3 add aux[m,n] AFTER the dropout: C = aux + drop_p(A B^T + bias), the residual connection of
  *                 SublayerConnection (transformer.py:98-106) written by the projection that closes the sublayer.
+ *                 4 / 5: the ReLU and its backward with the mask carried as ONE BIT per element: act 4 = act 1 that also writes
+ *                 the mask (of the post-dropout activation) to aux, act 5 = act 2 reading that mask instead of the fp32 activation
+ *                 (aux = a 16-byte aligned buffer of ltrx_gemm_nt_relu_bits_bytes(M, N) bytes, ldaux ignored; both launches must
+ *                 have the same M and N; LTRX_EUNSUPPORTED where that function returns 0).  Same results as acts 1 / 2.
  *                 drop_p > 0: nn.Dropout after the activation (model.py:43, transformer.py:227) fused in the epilogue
  *                 (act 0/1: counter-based mask over the [M,N] output; act 2: the mask is carried by aux, only 1/(1-p)).
  *   ltrx_gemm_tn: C[NP,KP] (dense) = A[M,NP]^T * B[M,KP]  -- weight gradient dW = dY^T X (split over M, deterministic);
  *                 bias_out[NP] (optional) = column sums of A = the bias gradient, produced in the same pass. */
+size_t ltrx_gemm_nt_relu_bits_bytes(int M, int N);
 int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, const void* B_image, float* C, int ldc, int M, int N, int K, const float* bias,
                  int act, const float* aux, int ldaux, float drop_p, uint32_t drop_seed, const uint32_t* drop_step, int strict,
                  int tile, ltrx_stream_t stream);

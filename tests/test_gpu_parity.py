@@ -1448,6 +1448,71 @@ def test_one_launch_weight_refresh_and_batch_ingest_are_bit_identical_to_the_sep
     assert lib.ltrx_ingest_batch(None, LB.ptr(y), 5, y.numel(), -1.0, None, LB.ptr(yd), LB.ptr(md), None) != 0
 
 
+def test_one_bit_relu_mask_gemm_epilogues_equal_the_fp32_activation_forms():
+    """ltrx_gemm_nt act 4 (ReLU + mask bits out) == act 1 and act 5 (mask bits in) == act 2, bit for bit, with and without dropout,
+    exact and ragged row counts; shapes the large-tile kernel does not take unconditionally report 0 bytes / LTRX_EUNSUPPORTED."""
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    rng = np.random.default_rng(41)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for (Mm, N, K1, p) in [(15360, 2048, 512, 0.0), (12300, 2048, 512, 0.1), (16384, 1024, 256, 0.3)]:
+        nbytes = lib.ltrx_gemm_nt_relu_bits_bytes(Mm, N)
+        assert nbytes == ((Mm + 255) // 256) * (N // 256) * 8192
+        x = _t(rng.standard_normal((Mm, K1)).astype(np.float32))
+        w1 = _t((rng.standard_normal((N, K1)) / np.sqrt(K1)).astype(np.float32))
+        b1 = _t(rng.standard_normal(N).astype(np.float32) * 0.1)
+        dy = _t(rng.standard_normal((Mm, K1)).astype(np.float32))             # gradient w.r.t. the NEXT layer's output [M, K1]
+        w2t = _t((rng.standard_normal((N, K1)) / np.sqrt(K1)).astype(np.float32))   # W2^T: [N, K1] (W2 is [K1, N])
+        bits = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+        r_ref, r_bit = torch.empty((Mm, N), device=DEV), torch.empty((Mm, N), device=DEV)
+        LB.check(lib.ltrx_gemm_nt(LB.ptr(x), K1, LB.ptr(w1), K1, None, LB.ptr(r_ref), N, Mm, N, K1, LB.ptr(b1), 1, None, 0, p, 77, LB.ptr(step),
+                                  0, 0, None), "act 1")
+        LB.check(lib.ltrx_gemm_nt(LB.ptr(x), K1, LB.ptr(w1), K1, None, LB.ptr(r_bit), N, Mm, N, K1, LB.ptr(b1), 4, LB.ptr(bits), 0, p, 77,
+                                  LB.ptr(step), 0, 0, None), "act 4")
+        assert torch.equal(r_ref, r_bit), (Mm, N, p)
+        assert 0.2 < float((r_ref > 0).float().mean()) < 0.6
+        g_ref, g_bit = torch.empty((Mm, N), device=DEV), torch.empty((Mm, N), device=DEV)
+        LB.check(lib.ltrx_gemm_nt(LB.ptr(dy), K1, LB.ptr(w2t), K1, None, LB.ptr(g_ref), N, Mm, N, K1, None, 2, LB.ptr(r_ref), N, p, 0, LB.ptr(step),
+                                  0, 0, None), "act 2")
+        LB.check(lib.ltrx_gemm_nt(LB.ptr(dy), K1, LB.ptr(w2t), K1, None, LB.ptr(g_bit), N, Mm, N, K1, None, 5, LB.ptr(bits), 0, p, 0, LB.ptr(step),
+                                  0, 0, None), "act 5")
+        assert torch.equal(g_ref, g_bit), (Mm, N, p)
+    for (Mm, N) in [(12000, 2048), (1000, 2048), (15360, 2000), (15360, 512)]:      # 376 tiles (split dispatch), 32 tiles, N % 256, 120 tiles
+        assert lib.ltrx_gemm_nt_relu_bits_bytes(Mm, N) == 0
+    a, w = torch.zeros((1000, 512), device=DEV), torch.zeros((2048, 512), device=DEV)
+    c, bits = torch.zeros((1000, 2048), device=DEV), torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
+    assert lib.ltrx_gemm_nt(LB.ptr(a), 512, LB.ptr(w), 512, None, LB.ptr(c), 2048, 1000, 2048, 512, None, 4, LB.ptr(bits), 0, 0.0, 0, None, 0, 0, None) != 0
+    assert lib.ltrx_gemm_nt(LB.ptr(a), 512, LB.ptr(w), 512, None, LB.ptr(c), 2048, 1000, 2048, 512, None, 6, LB.ptr(bits), 0, 0.0, 0, None, 0, 0, None) != 0
+
+
+def test_relu_bits_step_is_bit_identical_to_the_activation_reading_step():
+    """FusedTrainer(relu_bits=True) (default) vs relu_bits=False at a shape where the mask form applies (64 slates x 240, d_ff 2048),
+    with feed-forward dropout: same loss and same gradients, bit for bit, eager and captured."""
+    import copy
+    from allrank_amd.model import make_model
+    from allrank_amd.engine import FusedTrainer
+    rng = np.random.default_rng(6)
+    B, L, F = 64, 240, 40
+    x = _t(rng.standard_normal((B, L, F)).astype(np.float32))
+    y = rng.integers(0, 5, (B, L)).astype(np.float32)
+    y[5, 200:] = -1
+    yt = _t(y)
+    torch.manual_seed(4)
+    base = make_model(dict(sizes=[256], input_norm=False, activation=None, dropout=0.0),
+                      dict(N=1, d_ff=2048, h=4, positional_encoding=None, dropout=0.2),
+                      dict(d_output=1, output_activation=None), F).to(DEV)
+    out = {}
+    for bits in (True, False):
+        m = copy.deepcopy(base)
+        ft = FusedTrainer(m, "listNet", {}, B, L, lr=1e-3, use_graph=True, seed=9, relu_bits=bits)
+        assert (ft._relu_bits(ft.layers[0]) is not None) == bits
+        losses = [ft.step(x, yt).item() for _ in range(4)]                   # 2 eager + capture + replay
+        out[bits] = (losses, {k: p.detach().clone() for k, p in m.named_parameters()})
+    assert out[True][0] == out[False][0], (out[True][0], out[False][0])
+    for k, w in out[True][1].items():
+        assert torch.equal(w, out[False][1][k]), k
+
+
 def test_row4_losses_edge_shapes():
     """single-item slates, a fully padded slate, the maximum slate length and a single slate: engine == oracle (NaN where
     the reference's own arithmetic is 0/0)."""

@@ -1,5 +1,6 @@
-"""Same-box A/B of the grouped weight-gradient launch (FusedTrainer(group_wgrad=True) vs False) on the bench workload:
-   python tools/wgrad_group_ab.py [slates ...]   -> ms/step of both, interleaved, per batch size."""
+"""Same-box A/B of a FusedTrainer switch (default: group_wgrad -- the grouped weight-gradient launch; AB_OPT=relu_bits: the one-bit
+ReLU mask) on the bench workload:
+   [AB_OPT=name] python tools/wgrad_group_ab.py [slates ...]   -> ms/step with the switch on / off, interleaved, per batch size."""
 import os
 import sys
 import time
@@ -13,6 +14,7 @@ def main():
     from allrank_amd.model import make_model
     from allrank_amd.engine import FusedTrainer
     sizes = [int(a) for a in sys.argv[1:]] or [64, 256]
+    opt = os.environ.get("AB_OPT", "group_wgrad")
     dev = "cuda:0"
     L, F = 240, 136
     for B in sizes:
@@ -25,7 +27,7 @@ def main():
             m = make_model(dict(sizes=[512], input_norm=False, activation=None, dropout=0.0),
                            dict(N=2, d_ff=2048, h=8, positional_encoding=None, dropout=0.0),
                            dict(d_output=1, output_activation=None), F).to(dev)
-            trs[grouped] = FusedTrainer(m, "approxNDCGLoss", {}, B, L, lr=1e-3, group_wgrad=grouped)
+            trs[grouped] = FusedTrainer(m, "approxNDCGLoss", {}, B, L, lr=1e-3, **{opt: grouped})
             for _ in range(5):
                 trs[grouped].step(x, y)
         res = {True: [], False: []}
@@ -38,9 +40,9 @@ def main():
                 torch.cuda.synchronize()
                 res[grouped].append((time.perf_counter() - t0) / 20 * 1e3)
         g, s = min(res[True]), min(res[False])
-        print("   loss after the timed steps: grouped %.6f  per-projection %.6f" % (trs[True].step(x, y).item(), trs[False].step(x, y).item()))
-        print("slates %4d: grouped %.3f ms/step (%.2f M items/s)   per-projection %.3f ms/step (%.2f M items/s)   gain %.1f %%"
-              % (B, g, B * L / g / 1e3, s, B * L / s / 1e3, (s / g - 1) * 100), flush=True)
+        print("   loss after the timed steps: on %.6f  off %.6f" % (trs[True].step(x, y).item(), trs[False].step(x, y).item()))
+        print("slates %4d: %s on %.3f ms/step (%.2f M items/s)   off %.3f ms/step (%.2f M items/s)   gain %.1f %%"
+              % (B, opt, g, B * L / g / 1e3, s, B * L / s / 1e3, (s / g - 1) * 100), flush=True)
 
 
 if __name__ == "__main__":
