@@ -65,8 +65,8 @@ SIGNATURES = {
     "ltrx_gemm_nt_relu_bits_bytes": (_sz, [_i, _i]),
     "ltrx_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _f, ctypes.c_uint32, _vp, _i, _i, _vp]),
     "ltrx_split_image": (_i, [_vp, _vp, _sz, _vp]),
-    "ltrx_weight_images": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
-    "ltrx_ingest_batch": (_i, [_vp, _vp, _sz, _sz, _f, _vp, _vp, _vp, _vp]),
+    "ltrx_weight_images": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ltrx_ingest_batch": (_i, [_vp, _vp, _sz, _sz, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "ltrx_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i]),
     "ltrx_gemm_tn_splits": (_i, [_i, _i, _i]),
     "ltrx_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -574,6 +574,7 @@ struct TnGroup {
   float* slabs[LTRX_TN_GROUP];
   float* bias_slabs[LTRX_TN_GROUP];
   int lda[LTRX_TN_GROUP], ldb[LTRX_TN_GROUP], NP[LTRX_TN_GROUP], KP[LTRX_TN_GROUP], tiles_k[LTRX_TN_GROUP];
+  int kv[LTRX_TN_GROUP];             // columns of B that exist (= row length of the slabs and of C); KP = kv rounded up to the tile
   int tile_start[LTRX_TN_GROUP + 1];
   int nprob;
 };
@@ -599,7 +600,7 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const TnGroup grp,
   const float* __restrict__ B = grp.B[pi];
   float* __restrict__ slabs = grp.slabs[pi];
   float* __restrict__ bias_slabs = grp.bias_slabs[pi];
-  const int lda = grp.lda[pi], ldb = grp.ldb[pi], NP = grp.NP[pi], KP = grp.KP[pi], tiles_k = grp.tiles_k[pi];
+  const int lda = grp.lda[pi], ldb = grp.ldb[pi], NP = grp.NP[pi], tiles_k = grp.tiles_k[pi], kv = grp.kv[pi];
   const int tile = gtile - grp.tile_start[pi];
   const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 256;
   const int wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
@@ -709,17 +710,21 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const TnGroup grp,
       if (mg == 0) bias_slabs[(size_t)split * NP + n0 + 4 * cg + c] = v;
     }
   }
-  float* slab = slabs + (size_t)split * NP * KP;
+  // (kv < the tile's column range: B's row stride covers the whole tile -- the host checks -- but only kv columns exist; the
+  //  others were read from the padding and their products are dropped here)
+  float* slab = slabs + (size_t)split * NP * kv;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = k0 + wc * 64 + j * 32 + l31;
+    if (col < kv) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = n0 + wr * 128 + i * 32 + rowmap(q, half);
-        slab[(size_t)row * KP + col] = acc[i][j][q];
-      }
+        for (int q = 0; q < 16; ++q) {
+          const int row = n0 + wr * 128 + i * 32 + rowmap(q, half);
+          slab[(size_t)row * kv + col] = acc[i][j][q];
+        }
+    }
   }
 }
 
@@ -1057,8 +1062,8 @@ extern "C" size_t ltrx_gemm_tn_workspace_bytes(int M, int NP, int KP) {
   if (M <= 0 || NP <= 0 || KP <= 0) return 0;
   const int tiles = ((NP + 127) / 128) * ((KP + BN - 1) / BN);
   size_t sp = (size_t)tn_splits(M, tiles);
-  if ((NP % 256) == 0 && (KP % 256) == 0 && M >= 2048) {
-    int s2 = 256 / ((NP / 256) * (KP / 256));
+  if ((NP % 256) == 0 && M >= 2048) {                 // (KP % 256 != 0: the large tile over a padded B, when ldb allows it)
+    int s2 = 256 / ((NP / 256) * ((KP + 255) / 256));
     if (s2 > M / 128) s2 = M / 128;
     if (s2 < 1) s2 = 1;
     if ((size_t)s2 > sp) sp = (size_t)s2;
@@ -1072,7 +1077,12 @@ extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, fl
   if (lda < NP || ldb < KP) return LTRX_EUNSUPPORTED;
   const bool plain = strict == 2;                     // precision code as in ltrx_gemm_nt
   if (strict == 2) strict = 0;
-  if (!strict && tile != 1 && tn256_ok(M, NP, KP) && (lda & 3) == 0 && (ldb & 3) == 0) {
+  // the large tile also serves a B whose column count is not a multiple of 256 when its ROW STRIDE covers the last tile (the
+  // engine pads the input features to 256 floats per row): the surplus columns are computed from the padding and dropped
+  const int KPr = (KP + 255) / 256 * 256;
+  if (!strict && tile != 1 && tn256_ok(M, NP, KPr) && ldb >= KPr && (lda & 3) == 0 && (ldb & 3) == 0) {
+    const int kv = KP;
+    KP = KPr;
     hipStream_t s = (hipStream_t)stream;
     int splits, mps;
     tn256_plan(M, NP, KP, &splits, &mps);
@@ -1086,8 +1096,9 @@ extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, fl
       return LTRX_OK;
     });
     if (arc != LTRX_OK) return arc;
-    float* bslabs = bias_out ? (float*)ws + (size_t)splits * NP * KP : nullptr;
+    float* bslabs = bias_out ? (float*)ws + (((size_t)splits * NP * kv + 3) & ~(size_t)3) : nullptr;
     TnGroup g = {};
+    g.kv[0] = kv;
     g.A[0] = A;
     g.B[0] = B;
     g.slabs[0] = (float*)ws;
@@ -1105,7 +1116,7 @@ extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, fl
     else
       hipLaunchKernelGGL(ltrx_gemm_tn256_kernel<2>, dim3((NP / 256) * (KP / 256), splits), dim3(512), 2 * sizeof(SmemNT<256, 2>), s, g, M, mps);
     LTRX_LAUNCH_CHECK();
-    launch_slab_reduce((const float*)ws, splits, (size_t)NP * KP, C, bslabs, splits, (size_t)NP, bias_out, s);
+    launch_slab_reduce((const float*)ws, splits, (size_t)NP * kv, C, bslabs, splits, (size_t)NP, bias_out, s);
     LTRX_LAUNCH_CHECK();
     return LTRX_OK;
   }
@@ -1219,6 +1230,7 @@ extern "C" int ltrx_gemm_tn_group(int nprob, const float* const* A, const int* l
     g.ldb[p] = ldb[p];
     g.NP[p] = NP[p];
     g.KP[p] = KP[p];
+    g.kv[p] = KP[p];
     g.tiles_k[p] = KP[p] / 256;
     g.tile_start[p] = t0;
     t0 += (NP[p] / 256) * (KP[p] / 256);

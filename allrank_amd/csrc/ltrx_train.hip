@@ -446,12 +446,33 @@ extern "C" int ltrx_transpose_batch(const float* src_base, float* dst_base, cons
 // pre-split bf16 hi/lo image (each thread owns 4 consecutive elements of a transposed row = one 16-byte image group); the remaining
 // workgroups split the untransposed flat parameter buffer.  Needs every transposed matrix to have rows % 4 == 0 (the image groups
 // of 4 must not straddle a transposed row) -- the host checks and otherwise keeps the three-launch form.
+struct LtrxPadJob {
+  const float* src;
+  float* dst;
+  void* dst_image;
+  int rows, cols, ld;
+};
 __global__ void __launch_bounds__(256) ltrx_weight_images_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
                                                                  float4* __restrict__ dst_image, const int64_t* __restrict__ desc,
                                                                  const int32_t* __restrict__ tile_start, int n, int total_tiles,
-                                                                 float4* __restrict__ src_image, size_t nflat4) {
+                                                                 float4* __restrict__ src_image, size_t nflat4, int flat_blocks,
+                                                                 LtrxPadJob pad) {
+  if ((int)blockIdx.x >= total_tiles + flat_blocks) {
+    // row-padded copy of one matrix (the first FC weight [rows][cols] -> [rows][ld], so that its K extent is a multiple of the
+    // GEMM's 32-column step): fp32 copy and image; the padding columns keep the zeros they were allocated with
+    const int c4 = pad.cols >> 2, l4 = pad.ld >> 2;
+    const size_t tot = (size_t)pad.rows * c4, nb = gridDim.x - total_tiles - flat_blocks;
+    for (size_t i = (size_t)(blockIdx.x - total_tiles - flat_blocks) * blockDim.x + threadIdx.x; i < tot; i += nb * blockDim.x) {
+      const size_t r = i / c4;
+      const int c = (int)(i - r * c4);
+      const float4 v = reinterpret_cast<const float4*>(pad.src)[i];
+      reinterpret_cast<float4*>(pad.dst)[r * l4 + c] = v;
+      reinterpret_cast<float4*>(pad.dst_image)[r * l4 + c] = ltrx_split_image4(v);
+    }
+    return;
+  }
   if ((int)blockIdx.x >= total_tiles) {
-    const size_t nb = gridDim.x - total_tiles;
+    const size_t nb = flat_blocks;
     for (size_t i = (size_t)(blockIdx.x - total_tiles) * blockDim.x + threadIdx.x; i < nflat4; i += nb * blockDim.x)
       src_image[i] = ltrx_split_image4(reinterpret_cast<const float4*>(src_base)[i]);
     return;
@@ -483,17 +504,26 @@ __global__ void __launch_bounds__(256) ltrx_weight_images_kernel(const float* __
 }
 
 extern "C" int ltrx_weight_images(const float* src_base, size_t nflat, void* src_image, float* dst_base, void* dst_image,
-                                  const int64_t* desc, const int32_t* tile_start, int n, int total_tiles, ltrx_stream_t stream) {
+                                  const int64_t* desc, const int32_t* tile_start, int n, int total_tiles, const float* pad_src,
+                                  int pad_rows, int pad_cols, int pad_ld, float* pad_dst, void* pad_dst_image, ltrx_stream_t stream) {
+  LtrxPadJob pad = {pad_src, pad_dst, pad_dst_image, pad_rows, pad_cols, pad_ld};
+  if (pad_src) {
+    if (!pad_dst || !pad_dst_image || pad_rows <= 0 || pad_cols <= 0 || pad_ld < pad_cols || (pad_cols & 3) || (pad_ld & 3) ||
+        (((uintptr_t)pad_src | (uintptr_t)pad_dst | (uintptr_t)pad_dst_image) & 15))
+      return LTRX_EINVAL;
+  }
   if (!src_base || !src_image || (nflat & 3) || (((uintptr_t)src_base | (uintptr_t)src_image) & 15)) return LTRX_EINVAL;
   if (n < 0 || total_tiles < 0 || (n > 0 && (!dst_base || !dst_image || !desc || !tile_start || total_tiles <= 0))) return LTRX_EINVAL;
   if (n > 0 && (((uintptr_t)dst_base | (uintptr_t)dst_image) & 15)) return LTRX_EINVAL;
   if (n == 0) total_tiles = 0;
   size_t blocks = (nflat / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  if (blocks == 0 && total_tiles == 0) return LTRX_OK;
-  hipLaunchKernelGGL(ltrx_weight_images_kernel, dim3((unsigned)(total_tiles + blocks)), dim3(256), 0, (hipStream_t)stream, src_base,
-                     dst_base, reinterpret_cast<float4*>(dst_image), desc, tile_start, n, total_tiles,
-                     reinterpret_cast<float4*>(src_image), nflat / 4);
+  size_t pblocks = pad_src ? ((size_t)pad_rows * (pad_cols / 4) + 255) / 256 : 0;
+  if (pblocks > 256) pblocks = 256;
+  if (blocks == 0 && total_tiles == 0 && pblocks == 0) return LTRX_OK;
+  hipLaunchKernelGGL(ltrx_weight_images_kernel, dim3((unsigned)(total_tiles + blocks + pblocks)), dim3(256), 0, (hipStream_t)stream,
+                     src_base, dst_base, reinterpret_cast<float4*>(dst_image), desc, tile_start, n, total_tiles,
+                     reinterpret_cast<float4*>(src_image), nflat / 4, (int)blocks, pad);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }
@@ -503,7 +533,7 @@ extern "C" int ltrx_weight_images(const float* src_base, size_t nflat, void* src
 __global__ void __launch_bounds__(256) ltrx_ingest_batch_kernel(const float* __restrict__ x, const float* __restrict__ y, size_t nx,
                                                                 size_t ny, float pad_value, float* __restrict__ x_dst,
                                                                 float* __restrict__ y_dst, unsigned char* __restrict__ mask_dst,
-                                                                int x_blocks, int vec) {
+                                                                int x_blocks, int vec, int F, int ld_dst) {
   if ((int)blockIdx.x >= x_blocks) {
     const size_t i = (size_t)(blockIdx.x - x_blocks) * blockDim.x + threadIdx.x;
     if (i < ny) {
@@ -514,24 +544,36 @@ __global__ void __launch_bounds__(256) ltrx_ingest_batch_kernel(const float* __r
     return;
   }
   const size_t stride = (size_t)x_blocks * blockDim.x;
-  if (vec) {
+  if (vec && ld_dst != F) {            // rows of F floats into rows of ld_dst floats (the padding columns are never written)
+    const size_t n4 = nx >> 2;
+    const int f4 = F >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      const size_t r = i / f4;
+      const int c = (int)(i - r * f4);
+      reinterpret_cast<float4*>(x_dst + r * ld_dst)[c] = reinterpret_cast<const float4*>(x)[i];
+    }
+  } else if (vec) {
     const size_t n4 = nx >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
       reinterpret_cast<float4*>(x_dst)[i] = reinterpret_cast<const float4*>(x)[i];
+  } else if (ld_dst != F) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += stride) x_dst[(i / F) * ld_dst + (i % F)] = x[i];
   } else {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += stride) x_dst[i] = x[i];
   }
 }
 
-extern "C" int ltrx_ingest_batch(const float* x, const float* y, size_t nx, size_t ny, float pad_value, float* x_dst, float* y_dst,
-                                 unsigned char* mask_dst, ltrx_stream_t stream) {
+extern "C" int ltrx_ingest_batch(const float* x, const float* y, size_t nx, size_t ny, int F, int ld_dst, float pad_value, float* x_dst,
+                                 float* y_dst, unsigned char* mask_dst, ltrx_stream_t stream) {
   if (!y || !y_dst || !mask_dst || ny == 0 || (nx > 0 && (!x || !x_dst))) return LTRX_EINVAL;
-  const int vec = ((nx & 3) == 0 && (((uintptr_t)x | (uintptr_t)x_dst) & 15) == 0) ? 1 : 0;
+  if (nx > 0 && (F <= 0 || ld_dst < F || nx % (size_t)F)) return LTRX_EINVAL;
+  if (nx == 0) F = ld_dst = 1;
+  const int vec = ((nx & 3) == 0 && (F & 3) == 0 && (ld_dst & 3) == 0 && (((uintptr_t)x | (uintptr_t)x_dst) & 15) == 0) ? 1 : 0;
   size_t xb = ((vec ? nx / 4 : nx) + 255) / 256;
   if (xb > 4096) xb = 4096;
   const size_t yb = (ny + 255) / 256;
   hipLaunchKernelGGL(ltrx_ingest_batch_kernel, dim3((unsigned)(xb + yb)), dim3(256), 0, (hipStream_t)stream, x, y, nx, ny, pad_value,
-                     x_dst, y_dst, mask_dst, (int)xb, vec);
+                     x_dst, y_dst, mask_dst, (int)xb, vec, F, ld_dst);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }

@@ -86,7 +86,7 @@ class FusedTrainer(object):
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
                  optimizer="Adam", weight_decay=0.0, momentum=0.0, nesterov=False,
                  use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None, compact=False,
-                 weight_images=True, fc_step=True, group_wgrad=True, relu_bits=True):
+                 weight_images=True, fc_step=True, group_wgrad=True, relu_bits=True, pad_input=True):
         """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
         products), "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs), or "bf16" -- the THROUGHPUT mode: one bf16
         product per contraction in the dense projections AND in attention (fp32 storage, accumulation, LayerNorm, softmax,
@@ -112,7 +112,9 @@ class FusedTrainer(object):
         group_wgrad=True: the four weight gradients of an encoder layer run as one ltrx_gemm_tn_group launch (4x fewer partial slabs
         to write and reduce); False = one ltrx_gemm_tn per projection (A/B runs).
         relu_bits=True: the feed-forward ReLU(+dropout) mask travels from the forward GEMM to the input-gradient GEMM as one bit per
-        element (ltrx_gemm_nt acts 4 / 5) instead of being re-read from the saved fp32 activation; same results bit for bit."""
+        element (ltrx_gemm_nt acts 4 / 5) instead of being re-read from the saved fp32 activation; same results bit for bit.
+        pad_input=True: the static input buffer keeps the features in rows padded to 256 floats so that the first FC layer (F = 136 is
+        no multiple of the GEMM's 32-column step) runs the large-tile forward and weight-gradient kernels; False = dense rows (A/B)."""
         import torch.nn as nn
         from . import _lib as LB
         from .losses import FusedLoss
@@ -280,7 +282,21 @@ class FusedTrainer(object):
 
         M, d = self.M, self.d
         f32 = dict(dtype=torch.float32, device=dev)
-        self.x_in = torch.zeros((M, self.fc_sizes[0]), **f32)
+        # The input features: rows of F floats, or -- where the first FC layer can then run the large-tile GEMMs -- rows padded to a
+        # multiple of 256 floats (zeros): the forward projection contracts over F rounded up to the kernel's 32-column step against a
+        # row-padded copy of W_0 (refreshed with the weight images), the weight gradient reads the padded rows as operand tiles.
+        F0 = self.fc_sizes[0]
+        self._x_pad = bool(pad_input and self.in_norm is None and gemm in ("split_bf16", "bf16") and F0 % 4 == 0 and F0 % 256 != 0
+                           and F0 <= 1024 and self.fc_sizes[1] % 256 == 0 and M >= 2048)
+        if self._x_pad:
+            self.x_in_buf = torch.zeros((M, (F0 + 255) // 256 * 256), **f32)
+            self.x_in = self.x_in_buf[:, :F0]
+            kp = (F0 + 31) // 32 * 32
+            self.x_in_k = self.x_in_buf[:, :kp]
+            self.w0_pad = torch.zeros((self.fc_sizes[1], kp), **f32)
+            self.w0_pad_i = torch.zeros_like(self.w0_pad)
+        else:
+            self.x_in = torch.zeros((M, F0), **f32)
         if self.in_norm is not None:
             F_ = self.fc_sizes[0]
             self.x_norm = torch.zeros((M, F_), **f32)
@@ -517,11 +533,17 @@ class FusedTrainer(object):
         if self.gemm == "hipblaslt":
             return
         P = self.LB.ptr
+        w0 = self.W(self.model.input_layer.layers[0].weight) if self._x_pad else None
         if self._fused_images:
+            pad = (P(w0), w0.shape[0], w0.shape[1], self.w0_pad.shape[1], P(self.w0_pad), P(self.w0_pad_i)) if self._x_pad else \
+                  (None, 0, 0, 0, None, None)
             self.LB.check(self.lib.ltrx_weight_images(P(self.flat_p), self.nflat, P(self.flat_pi), P(self.flat_t), P(self.flat_ti),
                                                       P(self._tdesc), P(self._tstart), self._tn, self._ttiles if self._tn else 0,
-                                                      self._st()), "weight_images")
+                                                      *pad, self._st()), "weight_images")
             return
+        if self._x_pad:
+            self.w0_pad[:, :w0.shape[1]].copy_(w0)
+            self.LB.check(self.lib.ltrx_split_image(P(self.w0_pad), P(self.w0_pad_i), self.w0_pad.numel(), self._st()), "split_image(W0 padded)")
         if self._tn:
             self.LB.check(self.lib.ltrx_transpose_batch(P(self.flat_p), P(self.flat_t), P(self._tdesc), P(self._tstart), self._tn,
                                                         self._ttiles, self._st()), "transpose_batch")
@@ -545,7 +567,10 @@ class FusedTrainer(object):
         if w is None or self.gemm == "hipblaslt" or not self.weight_images:
             return None
         a = w.data_ptr()
-        for base, img in ((self.flat_p, self.flat_pi), (self.flat_t, self.flat_ti)):
+        pairs = ((self.flat_p, self.flat_pi), (self.flat_t, self.flat_ti))
+        if self._x_pad:
+            pairs += ((self.w0_pad, self.w0_pad_i),)
+        for base, img in pairs:
             lo = base.data_ptr()
             if lo <= a < lo + 4 * base.numel():
                 return ctypes.c_void_p(img.data_ptr() + (a - lo))
@@ -713,12 +738,15 @@ class FusedTrainer(object):
                                                        self._st()), "layernorm_torch_fwd")
             h = self.x_norm
         for i, lyr in enumerate(fc.layers):
+            w_i = W(lyr.weight)
+            if i == 0 and self._x_pad:                             # F rounded up to the GEMM's K step: padded rows x padded W_0
+                h, w_i = self.x_in_k, self.w0_pad
             if self.fc_act >= 3:                                   # Sigmoid / Tanh: GEMM + bias, then the activation in place
-                self._lin_fwd(h, W(lyr.weight), W(lyr.bias), self.fc_out[i])
+                self._lin_fwd(h, w_i, W(lyr.bias), self.fc_out[i])
                 self.LB.check(lib.ltrx_out_act_fwd(P(self.fc_out[i]), M * self.fc_out[i].shape[1], self.fc_act - 2, P(self.fc_out[i]),
                                                    self._st()), "fc_act_fwd")
             else:
-                self._lin_fwd(h, W(lyr.weight), W(lyr.bias), self.fc_out[i], self.fc_act, dp(self.p_fc), self._site(1000 + i))
+                self._lin_fwd(h, w_i, W(lyr.bias), self.fc_out[i], self.fc_act, dp(self.p_fc), self._site(1000 + i))
             h = self.fc_out[i]
         if self.pos is not None:                                  # transformer.py:51-52: x = sqrt(d) x + pe[rank]
             self.LB.check(lib.ltrx_posenc_fwd(P(h), P(self._pos_table()), P(self.idx_rows), P(kpm), M, d, self.pos_pad, float(d) ** 0.5,
@@ -960,7 +988,8 @@ class FusedTrainer(object):
         self.n_valid = n
         self.rows = max(32, min(self.M, (n + 31) // 32 * 32))     # alignment rows (zero input, zero gradient) keep M % 32 == 0
         F = self.x_in.shape[1]
-        self.LB.check(self.lib.ltrx_gather_rows(self.LB.ptr(xb), F, self.LB.ptr(self.idx), n, self.rows, F, self.LB.ptr(self.x_in), F,
+        self.LB.check(self.lib.ltrx_gather_rows(self.LB.ptr(xb), F, self.LB.ptr(self.idx), n, self.rows, F, self.LB.ptr(self.x_in),
+                                                self.x_in.stride(0),
                                                 self._st()), "gather_rows")
 
     def _reattach(self):
@@ -991,8 +1020,9 @@ class FusedTrainer(object):
         if direct:                                                # x, y and the padding mask in one launch
             P = self.LB.ptr
             self.LB.check(self.lib.ltrx_ingest_batch(None if self.compact else P(xb), P(yb), 0 if self.compact else xb.numel(), self.M,
-                                                     float(PADDED_Y_VALUE), None if self.compact else P(self.x_in), P(self.y_in),
-                                                     P(self.mask), self._st()), "ingest_batch")
+                                                     self.x_in.shape[1], self.x_in.stride(0), float(PADDED_Y_VALUE),
+                                                     None if self.compact else P(self.x_in), P(self.y_in), P(self.mask), self._st()),
+                          "ingest_batch")
         else:
             self.y_in.copy_(yb)
             self.mask.copy_(yb == PADDED_Y_VALUE)

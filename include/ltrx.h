@@ -333,12 +333,17 @@ int ltrx_split_image(const float* src, void* dst, size_t n, ltrx_stream_t stream
  * AND its image in dst_image (same offsets).  Requires nflat % 4 == 0, 16-byte aligned buffers, 4-float aligned dst offsets and
  * rows % 4 == 0 for every matrix.  Bit-identical to ltrx_transpose_batch + 2 x ltrx_split_image. */
 int ltrx_weight_images(const float* src_base, size_t nflat, void* src_image, float* dst_base, void* dst_image, const int64_t* desc,
-                       const int32_t* tile_start, int n, int total_tiles, ltrx_stream_t stream);
-/* A batch into the step's static input buffers in one launch: x_dst = x (nx floats; nx may be 0), y_dst = y (ny floats),
+                       const int32_t* tile_start, int n, int total_tiles, const float* pad_src, int pad_rows, int pad_cols, int pad_ld,
+                       float* pad_dst, void* pad_dst_image, ltrx_stream_t stream);
+/*   pad_src (optional, NULL = none): one more matrix [pad_rows][pad_cols] copied to pad_dst[pad_rows][pad_ld] (fp32) and
+ *   pad_dst_image (its image) in the same launch -- the engine keeps the first FC weight [H, F] with rows of ld = F rounded up to 32
+ *   so that the input projection runs the large-tile GEMM (padding columns: whatever the buffers hold, zeros in the engine). */
+/* A batch into the step's static input buffers in one launch: x (nx floats = rows of F) into rows of ld_dst >= F floats of x_dst
+ * (padding columns untouched; nx may be 0), y_dst = y (ny floats),
  * mask_dst[i] = (y[i] == pad_value) -- the padding mask the reference derives per batch (allrank/training/train_utils.py:19,
  * allrank/data/dataset_loading.py:15 PADDED_Y_VALUE). */
-int ltrx_ingest_batch(const float* x, const float* y, size_t nx, size_t ny, float pad_value, float* x_dst, float* y_dst,
-                      unsigned char* mask_dst, ltrx_stream_t stream);
+int ltrx_ingest_batch(const float* x, const float* y, size_t nx, size_t ny, int F, int ld_dst, float pad_value, float* x_dst,
+                      float* y_dst, unsigned char* mask_dst, ltrx_stream_t stream);
 /* `tile` (both GEMMs) is a per-call tuning argument: 0 = automatic choice per shape (what every product call passes);
  * ltrx_gemm_nt: 1 128x128x32, 2 128x128x64, 3 256x128x32, 4 256x128x64, 6 256x256x32, 7 128x256x32 (the large-tile forms
  * need N % 256 == 0, K % 32 == 0); ltrx_gemm_tn: 1 = the 128x128 kernel even where the 256x256 one applies.  Results do not

@@ -1272,6 +1272,68 @@ def test_large_tile_wgrad_gemm_matches_fp64_and_the_small_tile_kernel():
         pass
 
 
+def test_large_tile_wgrad_over_row_padded_features_matches_fp64():
+    """ltrx_gemm_tn with KP = 136 columns of a B whose rows are padded to 256 floats (the engine's input buffer): the 256 x 256 kernel
+    computes the tile, only the 136 real columns reach the slabs and C (dense [NP, 136]); garbage in the padding does not matter;
+    the same call on a dense B (ldb = 136) takes the small-tile kernel and agrees."""
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    rng = np.random.default_rng(13)
+    for (Mm, NP, KP, ld) in [(15360, 512, 136, 256), (4096, 256, 300, 512), (6176, 512, 136, 256)]:
+        A = rng.standard_normal((Mm, NP)).astype(np.float32)
+        Bp = rng.standard_normal((Mm, ld)).astype(np.float32) * 100.0           # padding = garbage
+        Bp[:, :KP] = rng.standard_normal((Mm, KP)).astype(np.float32)
+        At, Bt = _t(A), _t(Bp)
+        Bd = Bt[:, :KP].contiguous()
+        ws = torch.empty(max(lib.ltrx_gemm_tn_workspace_bytes(Mm, NP, KP), 64), dtype=torch.uint8, device=DEV)
+        C1, g1 = torch.full((NP, KP), float("nan"), device=DEV), torch.empty(NP, device=DEV)
+        C2, g2 = torch.full((NP, KP), float("nan"), device=DEV), torch.empty(NP, device=DEV)
+        LB.check(lib.ltrx_gemm_tn(LB.ptr(At), NP, LB.ptr(Bt), ld, LB.ptr(C1), LB.ptr(g1), Mm, NP, KP, 0, 0, LB.ptr(ws), None), "gemm_tn(padded B)")
+        LB.check(lib.ltrx_gemm_tn(LB.ptr(At), NP, LB.ptr(Bd), KP, LB.ptr(C2), LB.ptr(g2), Mm, NP, KP, 0, 0, LB.ptr(ws), None), "gemm_tn(dense B)")
+        ref = A.astype(np.float64).T @ Bp[:, :KP].astype(np.float64)
+        scale = (np.abs(A).astype(np.float64).T @ np.abs(Bp[:, :KP]).astype(np.float64)).max()
+        assert float(np.abs(C1.cpu().numpy() - ref).max() / scale) < 4e-6, (Mm, NP, KP)
+        assert float(np.abs(C2.cpu().numpy() - ref).max() / scale) < 4e-6, (Mm, NP, KP)
+        bref = A.astype(np.float64).sum(0)
+        assert float(np.abs(g1.cpu().numpy() - bref).max()) < 1e-5 * max(1.0, np.abs(A).sum(0).max())
+
+
+def test_padded_input_rows_step_equals_the_dense_rows_step():
+    """FusedTrainer(pad_input=True) (default: features in rows of 256 floats, first FC layer on the large-tile kernels) vs
+    pad_input=False: same loss to GEMM round-off, gradients within the split-bf16 bound, eager and captured; also through
+    variable-length execution."""
+    import copy
+    from allrank_amd.model import make_model
+    from allrank_amd.engine import FusedTrainer
+    rng = np.random.default_rng(8)
+    B, L, F = 16, 240, 136
+    x = _t(rng.standard_normal((B, L, F)).astype(np.float32))
+    y = rng.integers(0, 5, (B, L)).astype(np.float32)
+    y[3, 100:] = -1
+    x[3, 100:] = 0
+    yt = _t(y)
+    torch.manual_seed(5)
+    base = make_model(dict(sizes=[256], input_norm=False, activation=None, dropout=0.0),
+                      dict(N=1, d_ff=512, h=4, positional_encoding=None, dropout=0.0),
+                      dict(d_output=1, output_activation=None), F).to(DEV)
+    for compact in (False, True):
+        out = {}
+        for pad in (True, False):
+            m = copy.deepcopy(base)
+            ft = FusedTrainer(m, "approxNDCGLoss", {}, B, L, lr=1e-3, use_graph=True, pad_input=pad, compact=compact)
+            assert ft._x_pad == pad and (ft.x_in.stride(0) == 256) == pad
+            losses = [ft.step(x, yt).item()]
+            g0 = {k: p.grad.detach().clone() for k, p in m.named_parameters()}          # gradients of the first step (equal weights)
+            losses += [ft.step(x, yt).item() for _ in range(3)]                          # eager, capture, replay
+            out[pad] = (losses, g0)
+        assert abs(out[True][0][0] - out[False][0][0]) <= 2e-6 * (1 + abs(out[False][0][0])), (compact, out[True][0], out[False][0])
+        assert abs(out[True][0][3] - out[False][0][3]) <= 2e-3 * (1 + abs(out[False][0][3]))
+        floor = 1e-2 * max(float(r.abs().max()) for r in out[False][1].values())
+        for k, g in out[True][1].items():
+            ref = out[False][1][k]
+            assert float((g - ref).abs().max()) <= 5e-5 * max(floor, float(ref.abs().max())), (compact, k)
+
+
 def test_grouped_wgrad_launch_matches_fp64_is_deterministic_and_falls_back():
     """ltrx_gemm_tn_group: the four weight gradients of an encoder layer in one launch -- every result vs fp64 (same bound as the
     single-problem kernel), bit-identical run to run, bias sums present or absent per problem, strided operands (the fused QKV
@@ -1421,17 +1483,27 @@ def test_one_launch_weight_refresh_and_batch_ingest_are_bit_identical_to_the_sep
     LB.check(lib.ltrx_transpose_batch(LB.ptr(flat), LB.ptr(ft_a), LB.ptr(tdesc), LB.ptr(tst), len(mats), tstart[-1], None), "transpose_batch")
     LB.check(lib.ltrx_split_image(LB.ptr(ft_a), LB.ptr(ia_t), od, None), "split_image")
     LB.check(lib.ltrx_split_image(LB.ptr(flat), LB.ptr(ia_p), nflat, None), "split_image")
+    w0 = flat[offs[0]:offs[0] + 512 * 136].view(512, 136)                       # + the row-padded copy of one matrix: [512][136] -> [512][160]
+    wp, wpi = torch.zeros((512, 160), device=DEV), torch.zeros((512, 160), device=DEV)
     LB.check(lib.ltrx_weight_images(LB.ptr(flat), nflat, LB.ptr(ib_p), LB.ptr(ft_b), LB.ptr(ib_t), LB.ptr(tdesc), LB.ptr(tst), len(mats),
-                                    tstart[-1], None), "weight_images")
+                                    tstart[-1], LB.ptr(w0), 512, 136, 160, LB.ptr(wp), LB.ptr(wpi), None), "weight_images")
+    ref_p = torch.zeros((512, 160), device=DEV)
+    ref_p[:, :136] = w0
+    ref_pi = torch.zeros((512, 160), device=DEV)
+    LB.check(lib.ltrx_split_image(LB.ptr(ref_p), LB.ptr(ref_pi), ref_p.numel(), None), "split_image")
+    assert torch.equal(wp, ref_p) and torch.equal(wpi.view(torch.int32), ref_pi.view(torch.int32))
     assert torch.equal(ft_a, ft_b)
     assert torch.equal(ia_p.view(torch.int32), ib_p.view(torch.int32))
     assert torch.equal(ia_t.view(torch.int32), ib_t.view(torch.int32))
     for (r, c), so, k in zip(mats, offs, range(len(mats))):
         assert torch.equal(ft_b[desc[4 * k + 1]:desc[4 * k + 1] + r * c].view(c, r), flat[so:so + r * c].view(r, c).t())
     ib_p.zero_()
-    LB.check(lib.ltrx_weight_images(LB.ptr(flat), nflat, LB.ptr(ib_p), None, None, None, None, 0, 0, None), "weight_images(no transposes)")
+    LB.check(lib.ltrx_weight_images(LB.ptr(flat), nflat, LB.ptr(ib_p), None, None, None, None, 0, 0, None, 0, 0, 0, None, None, None),
+             "weight_images(no transposes)")
     assert torch.equal(ia_p.view(torch.int32), ib_p.view(torch.int32))
-    assert lib.ltrx_weight_images(LB.ptr(flat), nflat + 1, LB.ptr(ib_p), None, None, None, None, 0, 0, None) != 0
+    assert lib.ltrx_weight_images(LB.ptr(flat), nflat + 1, LB.ptr(ib_p), None, None, None, None, 0, 0, None, 0, 0, 0, None, None, None) != 0
+    assert lib.ltrx_weight_images(LB.ptr(flat), nflat, LB.ptr(ib_p), None, None, None, None, 0, 0, LB.ptr(w0), 512, 136, 130, LB.ptr(wp),
+                                  LB.ptr(wpi), None) != 0                                      # ld < cols
     for (B, L, F) in [(8, 240, 136), (3, 7, 5)]:
         x = _t(rng.standard_normal((B, L, F)).astype(np.float32))
         yv = rng.integers(0, 5, (B, L)).astype(np.float32)
@@ -1439,13 +1511,19 @@ def test_one_launch_weight_refresh_and_batch_ingest_are_bit_identical_to_the_sep
         y = _t(yv)
         xd, yd = torch.full((B * L, F), 7.0, device=DEV), torch.full((B, L), 7.0, device=DEV)
         md = torch.full((B, L), 9, dtype=torch.uint8, device=DEV)
-        LB.check(lib.ltrx_ingest_batch(LB.ptr(x), LB.ptr(y), x.numel(), y.numel(), -1.0, LB.ptr(xd), LB.ptr(yd), LB.ptr(md), None), "ingest")
+        LB.check(lib.ltrx_ingest_batch(LB.ptr(x), LB.ptr(y), x.numel(), y.numel(), F, F, -1.0, LB.ptr(xd), LB.ptr(yd), LB.ptr(md), None), "ingest")
         assert torch.equal(xd.view(-1), x.view(-1)) and torch.equal(yd, y) and torch.equal(md.bool(), y == -1)
+        ld = (F + 255) // 256 * 256 if F % 4 == 0 else F + 3                    # rows into padded rows: the padding is not touched
+        xp = torch.full((B * L, ld), 7.0, device=DEV)
+        LB.check(lib.ltrx_ingest_batch(LB.ptr(x), LB.ptr(y), x.numel(), y.numel(), F, ld, -1.0, LB.ptr(xp), LB.ptr(yd), LB.ptr(md), None),
+                 "ingest(padded rows)")
+        assert torch.equal(xp[:, :F], x.view(-1, F)) and bool((xp[:, F:] == 7.0).all())
         md.fill_(9)
         yd.fill_(7.0)
-        LB.check(lib.ltrx_ingest_batch(None, LB.ptr(y), 0, y.numel(), -1.0, None, LB.ptr(yd), LB.ptr(md), None), "ingest(y only)")
+        LB.check(lib.ltrx_ingest_batch(None, LB.ptr(y), 0, y.numel(), 0, 0, -1.0, None, LB.ptr(yd), LB.ptr(md), None), "ingest(y only)")
         assert torch.equal(yd, y) and torch.equal(md.bool(), y == -1)
-    assert lib.ltrx_ingest_batch(None, LB.ptr(y), 5, y.numel(), -1.0, None, LB.ptr(yd), LB.ptr(md), None) != 0
+    assert lib.ltrx_ingest_batch(None, LB.ptr(y), 5, y.numel(), 5, 5, -1.0, None, LB.ptr(yd), LB.ptr(md), None) != 0
+    assert lib.ltrx_ingest_batch(LB.ptr(x), LB.ptr(y), x.numel(), y.numel(), F, F - 1, -1.0, LB.ptr(xd), LB.ptr(yd), LB.ptr(md), None) != 0
 
 
 def test_one_bit_relu_mask_gemm_epilogues_equal_the_fp32_activation_forms():

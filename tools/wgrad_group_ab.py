@@ -14,7 +14,7 @@ def main():
     from allrank_amd.model import make_model
     from allrank_amd.engine import FusedTrainer
     sizes = [int(a) for a in sys.argv[1:]] or [64, 256]
-    opt = os.environ.get("AB_OPT", "group_wgrad")
+    opt = os.environ.get("AB_OPT", "group_wgrad")  # group_wgrad | relu_bits | pad_input
     dev = "cuda:0"
     L, F = 240, 136
     for B in sizes:
