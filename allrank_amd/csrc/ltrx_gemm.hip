@@ -258,11 +258,11 @@ struct SmemNT {
 // step).  The staging of B is then a plain copy: half of the kernel's split work (VALU, and the power it draws) is gone, the bits
 // that reach LDS -- and the results -- are identical.
 template <bool TAIL, int BM, int NT, bool BIMG>
-__global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
-                                                              int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
-                                                              const float* __restrict__ bias, int act,
-                                                              const float* __restrict__ aux, int ldaux, int tiles_n,
-                                                              ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step) {
+__device__ __forceinline__ void nt256_body(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                           int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
+                                           const float* __restrict__ bias, int act,
+                                           const float* __restrict__ aux, int ldaux, int tiles_n,
+                                           ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step) {
   constexpr int BK_ = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef SmemNT<BM, NT> SmemT;
@@ -444,6 +444,25 @@ __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __res
     }
   }
   if (act == 4) *mask_words = make_uint4(mbits[0], mbits[1], mbits[2], mbits[3]);
+}
+
+template <bool TAIL, int BM, int NT, bool BIMG>
+__global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
+                                                              int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
+                                                              const float* __restrict__ bias, int act,
+                                                              const float* __restrict__ aux, int ldaux, int tiles_n,
+                                                              ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step) {
+  nt256_body<TAIL, BM, NT, BIMG>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step);
+}
+// 64-row tiles, TWO workgroups per CU (2 x 80 KB of LDS, 128 registers per lane): for the shapes whose 128-row tiling is a single,
+// not even full round of workgroups (N = 512 projections at 64 slates per GPU: 240 tiles) -- twice the workgroups, four waves per
+// SIMD to hide the staging latency that two waves leave exposed
+template <bool TAIL, int NT, bool BIMG>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+ltrx_gemm_nt64_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc, int M,
+                      int N, int K, const float* __restrict__ bias, int act, const float* __restrict__ aux, int ldaux, int tiles_n,
+                      ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step) {
+  nt256_body<TAIL, 64, NT, BIMG>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -890,7 +909,8 @@ extern "C" int ltrx_split_image(const float* src, void* dst, size_t n, ltrx_stre
 // ------------------------------------------------------------------------------------------------------------------
 // `tile` argument of ltrx_gemm_nt / ltrx_gemm_tn (a per-call tuning argument, no process state): 0 = auto; 1 = 128x128x32
 // (4 waves); 2 = 128x128x64; 3 = 256x128x32 (8 waves); 4 = 256x128x64; 6 = 256x256x32 large-tile kernel (auto picks it for
-// exact multiples with >= 360 tiles); 7 = its 128x256x32 form; +100 = tuning experiment (every operand row aliases row 0)
+// exact multiples with >= 360 tiles); 7 = its 128x256x32 form; 8 = its 64x256x32 form with two workgroups per CU (small batches);
+// +100 = tuning experiment (every operand row aliases row 0)
 // (a PERSISTENT form of the 256x256x32 kernel -- one workgroup per CU walking its tiles, next tile's first K-steps prefetched
 //  behind the epilogue -- was built and measured in round 3: bit-identical results, 0 ... -13 % in speed; tools/lab/gemm_persist.inc,
 //  profiles/r03_gemm_persist_ab.md)
@@ -960,9 +980,48 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, co
     else {                                           // 128-row tiles when they make exactly one well-filled round
       const size_t t128 = (size_t)((M + 127) / 128) * (N / 256);
       if (t128 >= 176 && t128 <= 256) v = 7;
+      else if (t128 < 176) {                         // small batches (32 slates x 240 per GPU: 120 tiles of 128 rows): 64-row tiles, two
+        const size_t t64 = (size_t)((M + 63) / 64) * (N / 256);   // workgroups per CU -- 55 vs 77 (128-row) vs 108 us (small-tile kernel)
+        if (t64 >= 176 && t64 <= 512) v = 8;         // at M 7680 x N 512 x K 2048 (tools/gemm_nt64_ab.py); same bits as every other tile
+      }
     }
   }
   if (v == 0) v = 1;
+  if (v == 8) {              // 64-row tiles, two workgroups per CU
+    if ((N % 256) || (K % 32) || strict || !vec_epi || act == 4 || act == 5) return LTRX_EUNSUPPORTED;
+    static std::atomic<uint64_t> attr64_done{0};
+    const int arc = ltrx_once_per_device(attr64_done, []() {
+#define LTRX_NT64_ATTR(TAIL_, NT_, IMG_)                                                                                  \
+  (hipFuncSetAttribute((const void*)ltrx_gemm_nt64_kernel<TAIL_, NT_, IMG_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                       (int)(2 * sizeof(SmemNT<64, NT_>))) != hipSuccess)
+      if (LTRX_NT64_ATTR(false, 2, false) || LTRX_NT64_ATTR(false, 2, true) || LTRX_NT64_ATTR(true, 2, false) || LTRX_NT64_ATTR(true, 2, true) ||
+          LTRX_NT64_ATTR(false, 1, false) || LTRX_NT64_ATTR(false, 1, true) || LTRX_NT64_ATTR(true, 1, false) || LTRX_NT64_ATTR(true, 1, true))
+        return LTRX_EHIP;
+#undef LTRX_NT64_ATTR
+      return LTRX_OK;
+    });
+    if (arc != LTRX_OK) return arc;
+    const int tiles_n = N / 256;
+    const dim3 grid(((M + 63) / 64) * tiles_n);
+    const bool bimg = B_image != nullptr && (((uintptr_t)B_image) & 15) == 0;
+    const float* Bk = bimg ? reinterpret_cast<const float*>(B_image) : B;
+#define LTRX_NT64_(TAIL_, NT_, IMG_)                                                                                        \
+  hipLaunchKernelGGL((ltrx_gemm_nt64_kernel<TAIL_, NT_, IMG_>), grid, dim3(512), 2 * sizeof(SmemNT<64, NT_>), s, A, lda, Bk, ldb, C, \
+                     ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step)
+#define LTRX_NT64(TAIL_)                                                                                                    \
+  do {                                                                                                                      \
+    if (plain) {                                                                                                            \
+      if (bimg) LTRX_NT64_(TAIL_, 1, true); else LTRX_NT64_(TAIL_, 1, false);                                               \
+    } else {                                                                                                                \
+      if (bimg) LTRX_NT64_(TAIL_, 2, true); else LTRX_NT64_(TAIL_, 2, false);                                               \
+    }                                                                                                                       \
+  } while (0)
+    if (M % 64) LTRX_NT64(true); else LTRX_NT64(false);
+#undef LTRX_NT64_
+#undef LTRX_NT64
+    LTRX_LAUNCH_CHECK();
+    return LTRX_OK;
+  }
   if (v == 6 || v == 7) {
     if ((N % 256) || (K % 32) || strict || !vec_epi) return LTRX_EUNSUPPORTED;
     static std::atomic<uint64_t> attr_done{0};

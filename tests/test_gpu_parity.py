@@ -1591,6 +1591,39 @@ def test_relu_bits_step_is_bit_identical_to_the_activation_reading_step():
         assert torch.equal(w, out[False][1][k]), k
 
 
+def test_64_row_tile_gemm_equals_the_other_large_tile_forms_bit_for_bit():
+    """ltrx_gemm_nt tile 8 (64 x 256 tiles, two workgroups per CU: the automatic choice for small batches) == tiles 7 and 6, bits,
+    through every epilogue (bias, ReLU, ReLU mask, residual, dropout), exact and ragged row counts, with and without the image."""
+    from allrank_amd import _lib as LB
+    lib = LB.lib()
+    rng = np.random.default_rng(51)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for (Mm, N, K) in [(7680, 512, 2048), (3000, 512, 160), (6176, 256, 512)]:
+        A = _t(rng.standard_normal((Mm, K)).astype(np.float32))
+        Bw = _t((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+        bias = _t(rng.standard_normal(N).astype(np.float32))
+        aux = _t(rng.standard_normal((Mm, N)).astype(np.float32))
+        img = torch.empty_like(Bw)
+        LB.check(lib.ltrx_split_image(LB.ptr(Bw), LB.ptr(img), Bw.numel(), None), "split_image")
+        for (act, p, use_img) in [(0, 0.0, True), (1, 0.2, True), (2, 0.1, False), (3, 0.0, True), (3, 0.3, False)]:
+            outs = {}
+            for v in (8, 7, 6):
+                C = torch.full((Mm, N), float("nan"), device=DEV)
+                LB.check(lib.ltrx_gemm_nt(LB.ptr(A), K, LB.ptr(Bw), K, LB.ptr(img) if use_img else None, LB.ptr(C), N, Mm, N, K, LB.ptr(bias), act,
+                                          LB.ptr(aux) if act >= 2 else None, N if act >= 2 else 0, p, 5, LB.ptr(step), 0, v, None), "gemm_nt tile %d" % v)
+                outs[v] = C
+            assert torch.equal(outs[8], outs[7]) and torch.equal(outs[8], outs[6]), (Mm, N, K, act, p)
+    C = torch.empty((7680, 512), device=DEV)                                  # the automatic choice at 32 slates x 240 is this tile
+    auto = torch.empty((7680, 512), device=DEV)
+    A = _t(rng.standard_normal((7680, 2048)).astype(np.float32))
+    Bw = _t((rng.standard_normal((512, 2048)) / 45.0).astype(np.float32))
+    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), 2048, LB.ptr(Bw), 2048, None, LB.ptr(C), 512, 7680, 512, 2048, None, 0, None, 0, 0.0, 0, None, 0, 8, None), "t8")
+    LB.check(lib.ltrx_gemm_nt(LB.ptr(A), 2048, LB.ptr(Bw), 2048, None, LB.ptr(auto), 512, 7680, 512, 2048, None, 0, None, 0, 0.0, 0, None, 0, 0, None), "t0")
+    assert torch.equal(C, auto)
+    ref = A.double() @ Bw.double().t()
+    assert float((auto.double() - ref).abs().max() / (A.double().abs() @ Bw.double().abs().t()).max()) < 4e-6
+
+
 def test_row4_losses_edge_shapes():
     """single-item slates, a fully padded slate, the maximum slate length and a single slate: engine == oracle (NaN where
     the reference's own arithmetic is 0/0)."""
