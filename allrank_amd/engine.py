@@ -812,6 +812,9 @@ class FusedTrainer(object):
         fc = self.model.input_layer
         out = self.model.output_layer
         no = self.n_out
+        self._wg_pending.clear()                                  # (a step that raised half-way must not leave work queued)
+        self._red_pending.clear()
+        self._ln_slot = 0
         feat, sc_rows = self._forward(True)
         # ---------------- loss (value + d/dscores) ----------------
         loss, dsc = self.loss.run(self.scores_raw, self.y_in, self._divisor)

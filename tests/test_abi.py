@@ -85,6 +85,46 @@ def test_wgrad_workspace_covers_every_smaller_row_count(libpath):
             assert need <= have, (M, NP, KP, m, sp, need, have)
 
 
+def test_grouped_wgrad_workspace_and_relu_bits_queries(libpath):
+    """round 4 size queries, no GPU: the grouped weight-gradient workspace bounds the grouped plan of every row count <= M (at most
+    256 / total_tiles splits, never more than m / 128) and every single-problem call it may fall back to; the padded-B form of
+    ltrx_gemm_tn (KP not a multiple of 256, row stride covering the tile) is inside the single-problem bound; the one-bit ReLU mask
+    exists exactly where the large-tile kernel is unconditional."""
+    import ctypes
+    from allrank_amd import _lib
+    lib = _lib.lib()
+    for (M, probs) in [(64 * 240, [(1536, 512), (512, 512), (2048, 512), (512, 2048)]), (256 * 240, [(1536, 512), (512, 512), (2048, 512), (512, 2048)]),
+                       (6176, [(768, 256), (256, 256), (512, 256), (256, 512)]), (4096, [(256, 256)])]:
+        n = len(probs)
+        NP = (ctypes.c_int * n)(*[a for a, _ in probs])
+        KP = (ctypes.c_int * n)(*[b for _, b in probs])
+        have = lib.ltrx_gemm_tn_group_workspace_bytes(n, M, NP, KP)
+        tiles = sum((a // 256) * (b // 256) for a, b in probs)
+        for m in range(2048, M + 1, 32):
+            sp = max(1, min(256 // tiles, m // 128))
+            mps = ((m + sp - 1) // sp + 31) // 32 * 32
+            splits = (m + mps - 1) // mps
+            need = sum((splits * a * b + splits * a + 4) * 4 for a, b in probs)
+            assert need <= have, (M, m, splits, need, have)
+        assert have >= max(lib.ltrx_gemm_tn_workspace_bytes(M, a, b) for a, b in probs)
+    assert lib.ltrx_gemm_tn_group_workspace_bytes(0, 1024, None, None) == 0
+    # padded-B weight gradient (F = 136 in rows of 256 floats): splits <= min(256 / tiles256, m / 128) slabs of NP x KP
+    for (M, NP, KP) in [(64 * 240, 512, 136), (256 * 240, 512, 136), (4096, 256, 300)]:
+        have = lib.ltrx_gemm_tn_workspace_bytes(M, NP, KP)
+        tiles = (NP // 256) * ((KP + 255) // 256)
+        for m in range(2048, M + 1, 32):
+            sp = max(1, min(256 // tiles, m // 128))
+            assert (sp * NP * KP + sp * NP + 4) * 4 <= have, (M, NP, KP, m)
+    for (M, N, want) in [(61440, 2048, True), (15360, 2048, True), (16384, 1024, True), (12000, 2048, False), (15360, 512, False),
+                         (15360, 2000, False), (1000, 2048, False)]:
+        b = lib.ltrx_gemm_nt_relu_bits_bytes(M, N)
+        assert (b > 0) == want and (not want or b == ((M + 255) // 256) * (N // 256) * 8192), (M, N, b)
+    # argument validation before any HIP call
+    assert lib.ltrx_reduce_group(17, None, None, None, None, None, None) == -1
+    assert lib.ltrx_ingest_batch(None, None, 0, 0, 0, 0, -1.0, None, None, None, None) == -1
+    assert lib.ltrx_weight_images(None, 0, None, None, None, None, None, 0, 0, None, 0, 0, 0, None, None, None) == -1
+
+
 def test_loss_signatures_mirror_reference():
     """same parameter names and defaults as allrank/models/losses/*.py"""
     from allrank_amd import losses, metrics
