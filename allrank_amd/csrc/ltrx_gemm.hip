@@ -987,6 +987,9 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, co
     }
   }
   if (v == 0) v = 1;
+  // (the mask's (tile, thread) order is the 256-row kernel's: refuse rather than run any other tiling if the predicate above and this
+  //  dispatch ever disagree)
+  if ((act == 4 || act == 5) && v != 6) return LTRX_EUNSUPPORTED;
   if (v == 8) {              // 64-row tiles, two workgroups per CU
     if ((N % 256) || (K % 32) || strict || !vec_epi || act == 4 || act == 5) return LTRX_EUNSUPPORTED;
     static std::atomic<uint64_t> attr64_done{0};
