@@ -294,7 +294,10 @@ static int ln_bwd_grid(int rows) {
 #ifndef LTRX_LN_BWD_G16
 #define LTRX_LN_BWD_G16 256
 #endif
-static bool ln_bwd_wide(int rows, int D) { return D <= 512 && rows >= 16 * 4 * LTRX_LN_BWD_G16; }
+#ifndef LTRX_LN_BWD_WIDE_ROWS
+#define LTRX_LN_BWD_WIDE_ROWS (16 * 4 * LTRX_LN_BWD_G16)
+#endif
+static bool ln_bwd_wide(int rows, int D) { return D <= 512 && rows >= LTRX_LN_BWD_WIDE_ROWS; }
 static int ln_fwd_vec_grid(int rows) {
   int g = (rows + 7) / 8;
   return g > 1024 ? 1024 : (g < 1 ? 1 : g);

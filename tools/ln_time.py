@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from allrank_amd import _lib as LB
 lib = LB.lib()
-M, d = 61440, 512
+M, d = int(os.environ.get('LN_ROWS', 61440)), 512
 f = dict(device="cuda", dtype=torch.float32)
 dy, dres, xsum = (torch.randn(M, d, **f) for _ in range(3))
 a = torch.ones(d, **f)
@@ -22,4 +22,4 @@ for _ in range(20):
     fn()
 e1.record()
 torch.cuda.synchronize()
-print("layernorm_bwd (+reduce) %.1f us" % (e0.elapsed_time(e1) * 50))
+print("layernorm_bwd (+reduce) rows %d: %.1f us" % (M, e0.elapsed_time(e1) * 50))
