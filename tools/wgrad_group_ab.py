@@ -14,7 +14,7 @@ def main():
     from allrank_amd.model import make_model
     from allrank_amd.engine import FusedTrainer
     sizes = [int(a) for a in sys.argv[1:]] or [64, 256]
-    opt = os.environ.get("AB_OPT", "group_wgrad")  # group_wgrad | relu_bits | pad_input
+    opt = os.environ.get("AB_OPT", "group_wgrad")  # group_wgrad | relu_bits | pad_input | all (the three together)
     dev = "cuda:0"
     L, F = 240, 136
     for B in sizes:
@@ -27,7 +27,7 @@ def main():
             m = make_model(dict(sizes=[512], input_norm=False, activation=None, dropout=0.0),
                            dict(N=2, d_ff=2048, h=8, positional_encoding=None, dropout=0.0),
                            dict(d_output=1, output_activation=None), F).to(dev)
-            trs[grouped] = FusedTrainer(m, "approxNDCGLoss", {}, B, L, lr=1e-3, **{opt: grouped})
+            trs[grouped] = FusedTrainer(m, "approxNDCGLoss", {}, B, L, lr=1e-3, **({k: grouped for k in ("group_wgrad", "relu_bits", "pad_input")} if opt == "all" else {opt: grouped}))
             for _ in range(5):
                 trs[grouped].step(x, y)
         res = {True: [], False: []}
