@@ -1141,8 +1141,10 @@ extern "C" int ltrx_gemm_tn(const float* A, int lda, const float* B, int ldb, fl
   if (strict == 2) strict = 0;
   // the large tile also serves a B whose column count is not a multiple of 256 when its ROW STRIDE covers the last tile (the
   // engine pads the input features to 256 floats per row): the surplus columns are computed from the padding and dropped
+  // (opt-in, tile = 9: the kernel reads B[m][KP .. KPr) -- the caller states that every row, the last one included, is readable there)
   const int KPr = (KP + 255) / 256 * 256;
-  if (!strict && tile != 1 && tn256_ok(M, NP, KPr) && ldb >= KPr && (lda & 3) == 0 && (ldb & 3) == 0) {
+  if (tile == 9 && (KPr == KP || ldb < KPr)) tile = 0;
+  if (!strict && tile != 1 && (KPr == KP || tile == 9) && tn256_ok(M, NP, KPr) && ldb >= KPr && (lda & 3) == 0 && (ldb & 3) == 0) {
     const int kv = KP;
     KP = KPr;
     hipStream_t s = (hipStream_t)stream;

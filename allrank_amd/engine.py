@@ -669,8 +669,10 @@ class FusedTrainer(object):
             self._wg_pending.append((dy, x, gw, gb))
             return
         P = self.LB.ptr
+        # (tile 9: x is the padded input buffer -- its rows are readable up to the 256-column tile, see include/ltrx.h)
+        padded = self._x_pad and x.data_ptr() == self.x_in_buf.data_ptr() and x.stride(0) == self.x_in_buf.stride(0)
         self.LB.check(self.lib.ltrx_gemm_tn(P(dy), dy.stride(0), P(x), x.stride(0), P(gw), P(gb), self.rows, dy.shape[1],
-                                            x.shape[1], self._prec, 0, P(self.ws_tn), self._st()),
+                                            x.shape[1], self._prec, 9 if padded else 0, P(self.ws_tn), self._st()),
                       "gemm_tn(wgrad)")
 
     def _wgrad_flush(self, defer_reduce=False):

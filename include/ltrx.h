@@ -346,8 +346,11 @@ int ltrx_ingest_batch(const float* x, const float* y, size_t nx, size_t ny, int 
                       float* y_dst, unsigned char* mask_dst, ltrx_stream_t stream);
 /* `tile` (both GEMMs) is a per-call tuning argument: 0 = automatic choice per shape (what every product call passes);
  * ltrx_gemm_nt: 1 128x128x32, 2 128x128x64, 3 256x128x32, 4 256x128x64, 6 256x256x32, 7 128x256x32 (the large-tile forms
- * need N % 256 == 0, K % 32 == 0); ltrx_gemm_tn: 1 = the 128x128 kernel even where the 256x256 one applies.  Results do not
- * depend on it beyond fp32 summation order. */
+ * need N % 256 == 0, K % 32 == 0); ltrx_gemm_tn: 1 = the 128x128 kernel even where the 256x256 one applies; 9 = the caller states that
+ * every row of B (the last one included) is READABLE up to column KP rounded up to 256 (ldb >= that): the 256x256 kernel then also
+ * serves a KP that is no multiple of 256 -- it reads the padding, drops its products, C stays dense [NP, KP] (the engine's input
+ * buffer keeps F = 136 features in rows of 256 floats).  8 (ltrx_gemm_nt) = 64x256x32 tiles, two workgroups per CU.  Results do not
+ * depend on the tile beyond fp32 summation order. */
 /* workspace for ltrx_gemm_tn sized for M rows: sufficient for EVERY call with the same NP, KP and any row count <= M
  * (variable-length batches re-use one workspace); ltrx_gemm_tn_splits = the split count a call with exactly M rows uses
  * (each split owns an [NP,KP] slab + 2 bias rows of the workspace). */

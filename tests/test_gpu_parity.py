@@ -1274,8 +1274,8 @@ def test_large_tile_wgrad_gemm_matches_fp64_and_the_small_tile_kernel():
 
 def test_large_tile_wgrad_over_row_padded_features_matches_fp64():
     """ltrx_gemm_tn with KP = 136 columns of a B whose rows are padded to 256 floats (the engine's input buffer): the 256 x 256 kernel
-    computes the tile, only the 136 real columns reach the slabs and C (dense [NP, 136]); garbage in the padding does not matter;
-    the same call on a dense B (ldb = 136) takes the small-tile kernel and agrees."""
+    (opt-in: tile 9) computes the tile, only the 136 real columns reach the slabs and C (dense [NP, 136]); garbage in the padding does
+    not matter; the same call on a dense B (ldb = 136) takes the small-tile kernel and agrees."""
     from allrank_amd import _lib as LB
     lib = LB.lib()
     rng = np.random.default_rng(13)
@@ -1288,7 +1288,7 @@ def test_large_tile_wgrad_over_row_padded_features_matches_fp64():
         ws = torch.empty(max(lib.ltrx_gemm_tn_workspace_bytes(Mm, NP, KP), 64), dtype=torch.uint8, device=DEV)
         C1, g1 = torch.full((NP, KP), float("nan"), device=DEV), torch.empty(NP, device=DEV)
         C2, g2 = torch.full((NP, KP), float("nan"), device=DEV), torch.empty(NP, device=DEV)
-        LB.check(lib.ltrx_gemm_tn(LB.ptr(At), NP, LB.ptr(Bt), ld, LB.ptr(C1), LB.ptr(g1), Mm, NP, KP, 0, 0, LB.ptr(ws), None), "gemm_tn(padded B)")
+        LB.check(lib.ltrx_gemm_tn(LB.ptr(At), NP, LB.ptr(Bt), ld, LB.ptr(C1), LB.ptr(g1), Mm, NP, KP, 0, 9, LB.ptr(ws), None), "gemm_tn(padded B)")
         LB.check(lib.ltrx_gemm_tn(LB.ptr(At), NP, LB.ptr(Bd), KP, LB.ptr(C2), LB.ptr(g2), Mm, NP, KP, 0, 0, LB.ptr(ws), None), "gemm_tn(dense B)")
         ref = A.astype(np.float64).T @ Bp[:, :KP].astype(np.float64)
         scale = (np.abs(A).astype(np.float64).T @ np.abs(Bp[:, :KP]).astype(np.float64)).max()
