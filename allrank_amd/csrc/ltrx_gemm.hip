@@ -596,6 +596,10 @@ struct TnGroup {
   int kv[LTRX_TN_GROUP];             // columns of B that exist (= row length of the slabs and of C); KP = kv rounded up to the tile
   int tile_start[LTRX_TN_GROUP + 1];
   int nprob;
+  // grouped launches (nprob > 1, at most 256 workgroups): workgroup id -> (tile, split), built by the host so that the tiles of one
+  // (problem, split) -- which share their two operand row slabs -- sit on ONE XCD (workgroup w is dispatched to XCD w % 8)
+  unsigned char map_tile[256];
+  unsigned char map_split[256];
 };
 
 template <int NT>
@@ -611,8 +615,16 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const TnGroup grp,
   // 27 % -> 68 %, HBM-side reads 1.5 GB -> 0.63 GB per launch (= the algorithmic bytes); the duration does not change (the
   // kernel is bound by its staging path, not by HBM), the freed bandwidth is what the overlapped all-reduce needs.
   const int n_tiles = gridDim.x;
-  const int wg = xcd_remap(blockIdx.x + n_tiles * blockIdx.y, n_tiles * gridDim.y);
-  const int gtile = wg % n_tiles, split = wg / n_tiles;
+  int gtile, split;
+  if (grp.nprob > 1) {
+    const int w = blockIdx.x + n_tiles * blockIdx.y;
+    gtile = grp.map_tile[w];
+    split = grp.map_split[w];
+  } else {
+    const int wg = xcd_remap(blockIdx.x + n_tiles * blockIdx.y, n_tiles * gridDim.y);
+    gtile = wg % n_tiles;
+    split = wg / n_tiles;
+  }
   int pi = 0;                                                          // (workgroup-uniform)
   while (pi + 1 < grp.nprob && gtile >= grp.tile_start[pi + 1]) ++pi;
   const float* __restrict__ A = grp.A[pi];
@@ -1304,6 +1316,57 @@ extern "C" int ltrx_gemm_tn_group(int nprob, const float* const* A, const int* l
     w += ((size_t)splits * NP[p] + 3) & ~(size_t)3;
   }
   g.tile_start[nprob] = t0;
+  {
+    // (problem, split) groups, largest first, into the 8 XCDs (first fit, capacity = an even share of the grid; a group that fits
+    // nowhere whole is cut); XCD x owns the workgroup ids x, x + 8, x + 16, ...
+    const int nwg = total * splits;                        // <= 256 (tn_group_plan)
+    const int cap = (nwg + 7) / 8;
+    int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int order[LTRX_TN_GROUP];
+    for (int p = 0; p < nprob; ++p) order[p] = p;
+    for (int a = 0; a < nprob; ++a)
+      for (int b = a + 1; b < nprob; ++b)
+        if (g.tile_start[order[b] + 1] - g.tile_start[order[b]] > g.tile_start[order[a] + 1] - g.tile_start[order[a]]) {
+          const int t_ = order[a];
+          order[a] = order[b];
+          order[b] = t_;
+        }
+    auto slot_count = [&](int x) { return (nwg - x + 7) / 8; };      // ids x, x+8, ... < nwg
+    for (int oi = 0; oi < nprob; ++oi) {
+      const int p = order[oi], nt = g.tile_start[p + 1] - g.tile_start[p];
+      for (int sp_ = 0; sp_ < splits; ++sp_) {
+        int left = nt, next = 0;
+        while (left > 0) {
+          int best = -1;
+          for (int x = 0; x < 8; ++x)                      // an XCD that takes the rest whole, else the emptiest one
+            if (fill[x] + left <= (cap < slot_count(x) ? cap : slot_count(x))) {
+              best = x;
+              break;
+            }
+          if (best < 0) {
+            int room = -1;
+            for (int x = 0; x < 8; ++x) {
+              const int r_ = slot_count(x) - fill[x];
+              if (r_ > room) {
+                room = r_;
+                best = x;
+              }
+            }
+          }
+          int take = slot_count(best) - fill[best];
+          if (take > left) take = left;
+          for (int q = 0; q < take; ++q) {
+            const int w = best + 8 * (fill[best] + q);
+            g.map_tile[w] = (unsigned char)(g.tile_start[p] + next + q);
+            g.map_split[w] = (unsigned char)sp_;
+          }
+          fill[best] += take;
+          next += take;
+          left -= take;
+        }
+      }
+    }
+  }
   if (plain)
     hipLaunchKernelGGL(ltrx_gemm_tn256_kernel<1>, dim3(total, splits), dim3(512), 2 * sizeof(SmemNT<256, 1>), s, g, M, mps);
   else
