@@ -73,6 +73,7 @@ SIGNATURES = {
     "ltrx_gemm_tn_group_workspace_bytes": (_sz, [_i, _i, _vp, _vp]),
     "ltrx_gemm_tn_group": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "ltrx_reduce_group": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_debug_tn_group_map": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "ltrx_layernorm_torch_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "ltrx_posenc_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     "ltrx_posenc_table_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

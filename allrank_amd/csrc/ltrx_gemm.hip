@@ -1238,6 +1238,60 @@ static bool tn_group_ok(int nprob, int M, const int* NP, const int* KP, const in
   return t <= 256;
 }
 
+// (problem, split) groups -> XCDs: fills g.map_tile / g.map_split for the total * splits (<= 256) workgroups of a grouped launch
+static void tn_group_map(TnGroup& g, int total, int splits) {
+  const int nprob = g.nprob;
+  // (problem, split) groups, largest first, into the 8 XCDs (first fit, capacity = an even share of the grid; a group that fits
+  // nowhere whole is cut); XCD x owns the workgroup ids x, x + 8, x + 16, ...
+  const int nwg = total * splits;                        // <= 256 (tn_group_plan)
+  const int cap = (nwg + 7) / 8;
+  int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int order[LTRX_TN_GROUP];
+  for (int p = 0; p < nprob; ++p) order[p] = p;
+  for (int a = 0; a < nprob; ++a)
+    for (int b = a + 1; b < nprob; ++b)
+      if (g.tile_start[order[b] + 1] - g.tile_start[order[b]] > g.tile_start[order[a] + 1] - g.tile_start[order[a]]) {
+        const int t_ = order[a];
+        order[a] = order[b];
+        order[b] = t_;
+      }
+  auto slot_count = [&](int x) { return (nwg - x + 7) / 8; };      // ids x, x+8, ... < nwg
+  for (int oi = 0; oi < nprob; ++oi) {
+    const int p = order[oi], nt = g.tile_start[p + 1] - g.tile_start[p];
+    for (int sp_ = 0; sp_ < splits; ++sp_) {
+      int left = nt, next = 0;
+      while (left > 0) {
+        int best = -1;
+        for (int x = 0; x < 8; ++x)                      // an XCD that takes the rest whole, else the emptiest one
+          if (fill[x] + left <= (cap < slot_count(x) ? cap : slot_count(x))) {
+            best = x;
+            break;
+          }
+        if (best < 0) {
+          int room = -1;
+          for (int x = 0; x < 8; ++x) {
+            const int r_ = slot_count(x) - fill[x];
+            if (r_ > room) {
+              room = r_;
+              best = x;
+            }
+          }
+        }
+        int take = slot_count(best) - fill[best];
+        if (take > left) take = left;
+        for (int q = 0; q < take; ++q) {
+          const int w = best + 8 * (fill[best] + q);
+          g.map_tile[w] = (unsigned char)(g.tile_start[p] + next + q);
+          g.map_split[w] = (unsigned char)sp_;
+        }
+        fill[best] += take;
+        next += take;
+        left -= take;
+      }
+    }
+  }
+  }
+
 // bytes for ltrx_gemm_tn_group: an upper bound over every row count m <= M (variable-length batches): per problem at most
 // min(256 / total_tiles, m / 128) + 1 slabs of NP x KP (+ NP for the bias), and never less than the single-problem calls need (the
 // group call falls back to them when a shape does not qualify)
@@ -1316,57 +1370,7 @@ extern "C" int ltrx_gemm_tn_group(int nprob, const float* const* A, const int* l
     w += ((size_t)splits * NP[p] + 3) & ~(size_t)3;
   }
   g.tile_start[nprob] = t0;
-  {
-    // (problem, split) groups, largest first, into the 8 XCDs (first fit, capacity = an even share of the grid; a group that fits
-    // nowhere whole is cut); XCD x owns the workgroup ids x, x + 8, x + 16, ...
-    const int nwg = total * splits;                        // <= 256 (tn_group_plan)
-    const int cap = (nwg + 7) / 8;
-    int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int order[LTRX_TN_GROUP];
-    for (int p = 0; p < nprob; ++p) order[p] = p;
-    for (int a = 0; a < nprob; ++a)
-      for (int b = a + 1; b < nprob; ++b)
-        if (g.tile_start[order[b] + 1] - g.tile_start[order[b]] > g.tile_start[order[a] + 1] - g.tile_start[order[a]]) {
-          const int t_ = order[a];
-          order[a] = order[b];
-          order[b] = t_;
-        }
-    auto slot_count = [&](int x) { return (nwg - x + 7) / 8; };      // ids x, x+8, ... < nwg
-    for (int oi = 0; oi < nprob; ++oi) {
-      const int p = order[oi], nt = g.tile_start[p + 1] - g.tile_start[p];
-      for (int sp_ = 0; sp_ < splits; ++sp_) {
-        int left = nt, next = 0;
-        while (left > 0) {
-          int best = -1;
-          for (int x = 0; x < 8; ++x)                      // an XCD that takes the rest whole, else the emptiest one
-            if (fill[x] + left <= (cap < slot_count(x) ? cap : slot_count(x))) {
-              best = x;
-              break;
-            }
-          if (best < 0) {
-            int room = -1;
-            for (int x = 0; x < 8; ++x) {
-              const int r_ = slot_count(x) - fill[x];
-              if (r_ > room) {
-                room = r_;
-                best = x;
-              }
-            }
-          }
-          int take = slot_count(best) - fill[best];
-          if (take > left) take = left;
-          for (int q = 0; q < take; ++q) {
-            const int w = best + 8 * (fill[best] + q);
-            g.map_tile[w] = (unsigned char)(g.tile_start[p] + next + q);
-            g.map_split[w] = (unsigned char)sp_;
-          }
-          fill[best] += take;
-          next += take;
-          left -= take;
-        }
-      }
-    }
-  }
+  tn_group_map(g, total, splits);
   if (plain)
     hipLaunchKernelGGL(ltrx_gemm_tn256_kernel<1>, dim3(total, splits), dim3(512), 2 * sizeof(SmemNT<256, 1>), s, g, M, mps);
   else
@@ -1385,4 +1389,27 @@ extern "C" int ltrx_gemm_tn_group(int nprob, const float* const* A, const int* l
     LTRX_LAUNCH_CHECK();
   }
   return LTRX_OK;
+}
+
+// test hook (no GPU needed): the workgroup -> (tile, split) table ltrx_gemm_tn_group would launch with for these shapes; returns the
+// workgroup count (0 when the shapes take the per-problem path)
+extern "C" int ltrx_debug_tn_group_map(int nprob, int M, const int* NP, const int* KP, unsigned char* tile_out, unsigned char* split_out) {
+  if (nprob < 1 || nprob > LTRX_TN_GROUP || !NP || !KP || !tile_out || !split_out || M <= 0) return 0;
+  if (!tn_group_ok(nprob, M, NP, KP, nullptr, nullptr, 0)) return 0;
+  int total = 0, splits = 1, mps = M;
+  tn_group_plan(nprob, M, NP, KP, &total, &splits, &mps);
+  TnGroup g = {};
+  g.nprob = nprob;
+  int t0 = 0;
+  for (int p = 0; p < nprob; ++p) {
+    g.tile_start[p] = t0;
+    t0 += (NP[p] / 256) * (KP[p] / 256);
+  }
+  g.tile_start[nprob] = t0;
+  tn_group_map(g, total, splits);
+  for (int w = 0; w < total * splits; ++w) {
+    tile_out[w] = g.map_tile[w];
+    split_out[w] = g.map_split[w];
+  }
+  return total * splits;
 }

@@ -380,6 +380,10 @@ int ltrx_gemm_tn_group(int nprob, const float* const* A, const int* lda, const f
  * c < cols[i], each in a fixed order (deterministic).  Entries with splits[i] <= 0 are skipped.  (The engine sums the weight-gradient
  * slabs of an encoder layer and the parameter-gradient partials of its LayerNorms with it: 11 launches -> 1; autograd's per-tensor
  * accumulation in loss.backward(), allrank/training/train_utils.py:23.) */
+/* test hook, no GPU needed: the workgroup -> (tile, split) table ltrx_gemm_tn_group launches with for these shapes (the tiles of one
+ * (problem, split) group on one XCD where they fit); tile_out / split_out: 256 bytes each; returns the workgroup count, 0 when the shapes
+ * take the per-problem path. */
+int ltrx_debug_tn_group_map(int nprob, int M, const int* NP, const int* KP, unsigned char* tile_out, unsigned char* split_out);
 #define LTRX_REDUCE_GROUP_MAX 16
 int ltrx_reduce_group(int n, const float* const* src, const int* splits, const size_t* row_stride, const size_t* cols, float* const* dst,
                       ltrx_stream_t stream);

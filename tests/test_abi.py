@@ -125,6 +125,40 @@ def test_grouped_wgrad_workspace_and_relu_bits_queries(libpath):
     assert lib.ltrx_weight_images(None, 0, None, None, None, None, None, 0, 0, None, 0, 0, 0, None, None, None) == -1
 
 
+def test_grouped_wgrad_workgroup_map_is_a_permutation_that_keeps_groups_on_one_xcd(libpath):
+    """the host-built workgroup -> (tile, split) table of ltrx_gemm_tn_group (no GPU): every (tile, split) exactly once, at most 256
+    workgroups, and the tiles of a (problem, split) group on ONE XCD (workgroup w runs on XCD w % 8) wherever bin packing allows --
+    15 of the 20 groups of the bench layer, all of them for shapes that divide evenly."""
+    import ctypes
+    from allrank_amd import _lib
+    lib = _lib.lib()
+    cases = [(64 * 240, [(1536, 512), (512, 512), (2048, 512), (512, 2048)], 15), (256 * 240, [(1536, 512), (512, 512), (2048, 512), (512, 2048)], 15),
+             (8192, [(768, 256), (256, 256), (512, 256), (256, 512)], None), (4096, [(256, 256)], None), (6176, [(512, 512), (512, 512)], None)]
+    for (M, probs, want_whole) in cases:
+        n = len(probs)
+        NP = (ctypes.c_int * n)(*[a for a, _ in probs])
+        KP = (ctypes.c_int * n)(*[b for _, b in probs])
+        t_out, s_out = (ctypes.c_ubyte * 256)(), (ctypes.c_ubyte * 256)()
+        nwg = lib.ltrx_debug_tn_group_map(n, M, NP, KP, t_out, s_out)
+        tiles = [(a // 256) * (b // 256) for a, b in probs]
+        total = sum(tiles)
+        assert 0 < nwg <= 256 and nwg % total == 0, (M, probs, nwg)
+        splits = nwg // total
+        pairs = sorted((t_out[w], s_out[w]) for w in range(nwg))
+        assert pairs == sorted((t, s) for t in range(total) for s in range(splits)), (M, probs)
+        starts = [sum(tiles[:p]) for p in range(n + 1)]
+        whole = 0
+        for p in range(n):
+            for s in range(splits):
+                xcds = {w % 8 for w in range(nwg) if s_out[w] == s and starts[p] <= t_out[w] < starts[p + 1]}
+                whole += len(xcds) == 1
+                assert len(xcds) <= max(2, (tiles[p] + 31) // 32 + 1)
+        if want_whole is not None:
+            assert whole >= want_whole, (M, whole)
+    NPb, KPb = (ctypes.c_int * 1)(96), (ctypes.c_int * 1)(136)
+    assert lib.ltrx_debug_tn_group_map(1, 4096, NPb, KPb, t_out, s_out) == 0
+
+
 def test_loss_signatures_mirror_reference():
     """same parameter names and defaults as allrank/models/losses/*.py"""
     from allrank_amd import losses, metrics
