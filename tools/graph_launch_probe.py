@@ -36,7 +36,7 @@ flip = [0]
 
 
 def pingpong():
-    ft.step.__self__                                          # (same ingest as step())
+    # (the same ingest launch step() makes, then the replay)
     ft.LB.check(ft.lib.ltrx_ingest_batch(ft.LB.ptr(x), ft.LB.ptr(y), x.numel(), ft.M, ft.x_in.shape[1], ft.x_in.stride(0), -1.0,
                                          ft.LB.ptr(ft.x_in), ft.LB.ptr(ft.y_in), ft.LB.ptr(ft.mask), ft._st()), "ingest")
     for g, after in (segs_a if flip[0] else segs_b):
