@@ -39,6 +39,7 @@ SIGNATURES = {
     "ltrx_mrr_at": (_i, [_vp, _vp, _i, _i, ctypes.POINTER(ctypes.c_int), _i, _f, _vp, _vp, _vp]),
     "ltrx_ndcg_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_ndcg_at": (_i, [_vp, _vp, _i, _i, ctypes.POINTER(ctypes.c_int), _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ltrx_ndcg_at_gains": (_i, [_vp, _vp, _vp, _i, _i, ctypes.POINTER(ctypes.c_int), _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, ctypes.c_uint32, _vp, _vp]),
     "ltrx_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
@@ -62,7 +63,7 @@ SIGNATURES = {
     "ltrx_score_head_fwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "ltrx_score_head_bwd_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_score_head_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "ltrx_gemm_nt_relu_bits_bytes": (_sz, [_i, _i]),
+    "ltrx_gemm_nt_relu_bits_bytes": (_sz, [_i, _i, _i]),
     "ltrx_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _f, ctypes.c_uint32, _vp, _i, _i, _vp]),
     "ltrx_split_image": (_i, [_vp, _vp, _sz, _vp]),
     "ltrx_weight_images": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),

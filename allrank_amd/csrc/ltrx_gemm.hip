@@ -938,9 +938,11 @@ static void launch_nt(const float* A, int lda, const float* B, int ldb, float* C
 
 // bytes of the one-bit ReLU mask of an [M, N] activation (acts 4 / 5 of ltrx_gemm_nt), 0 where that form does not apply: the mask is
 // kept in the 256 x 256 tile kernel's (tile, thread) order, so both launches must take that kernel whatever their K, dropout and
-// epilogue -- N a multiple of 256 and a tile count the dispatch below sends there unconditionally.
-extern "C" size_t ltrx_gemm_nt_relu_bits_bytes(int M, int N) {
-  if (M <= 0 || N <= 0 || (N % 256)) return 0;
+// epilogue -- N a multiple of 256, K a multiple of the kernel's 32-column step (K of the launch asked about: the forward and the
+// input-gradient launch of one mask may contract over different widths -- ask for both) and a tile count the dispatch below sends
+// there unconditionally.  One predicate mirrors the dispatch: callers fall back to acts 1 / 2 where it returns 0.
+extern "C" size_t ltrx_gemm_nt_relu_bits_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || (N % 256) || (K % 32)) return 0;
   const size_t t = (size_t)((M + 255) / 256) * (N / 256);
   if (!(t >= 380 || (t >= 168 && t <= 256))) return 0;
   return t * 512 * 16;
@@ -954,7 +956,7 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, co
   const ltrx::DropSpec drop = ltrx_make_drop(drop_p, drop_seed);
   if ((act == 2 || act == 3) && (!aux || ldaux < N)) return LTRX_EINVAL;
   if (act == 4 || act == 5) {        // the one-bit mask lives in the large-tile kernel's own (tile, thread) order: only where it runs
-    if (!aux || ((uintptr_t)aux & 15) || tile != 0 || strict == 1 || ltrx_gemm_nt_relu_bits_bytes(M, N) == 0) return LTRX_EUNSUPPORTED;
+    if (!aux || ((uintptr_t)aux & 15) || tile != 0 || strict == 1 || ltrx_gemm_nt_relu_bits_bytes(M, N, K) == 0) return LTRX_EUNSUPPORTED;
     ldaux = 0;
   }
   if ((K & 3) || (lda & 3) || (ldb & 3) || lda < K || ldb < K || ldc < N) return LTRX_EUNSUPPORTED;

@@ -16,7 +16,8 @@ using namespace ltrx;
 __global__ void __launch_bounds__(1024) ltrx_ndcg_kernel(const float* __restrict__ y_pred,
                                                         const float* __restrict__ y_true, int L, float pad,
                                                         float filler, LtrxAts ats, float* __restrict__ ndcg_out,
-                                                        float* __restrict__ dcg_out, int64_t* __restrict__ order_out) {
+                                                        float* __restrict__ dcg_out, int64_t* __restrict__ order_out,
+                                                        const float* __restrict__ gains) {
   extern __shared__ float lds[];
   float* ss = lds;           // [L]
   float* ys = lds + L;       // [L]
@@ -27,6 +28,9 @@ __global__ void __launch_bounds__(1024) ltrx_ndcg_kernel(const float* __restrict
   const int b = blockIdx.x;
   const float* sp = y_pred + (size_t)b * L;
   const float* yp = y_true + (size_t)b * L;
+  // caller-supplied gains (metrics.py:67 with gain_function != 2^x - 1): gain_function evaluated per item on the masked labels
+  // (padded -> label 0, metrics.py:35), so a padded item carries gain_function(0) at its tail position in BOTH rankings
+  const float* gp = gains ? gains + (size_t)b * L : nullptr;
   int nv = 0;
   for (int i = threadIdx.x; i < L; i += blockDim.x) {
     ss[i] = sp[i];
@@ -41,10 +45,11 @@ __global__ void __launch_bounds__(1024) ltrx_ndcg_kernel(const float* __restrict
   for (int i = threadIdx.x; i < L; i += blockDim.x) {
     const float yi = ys[i];
     if (yi == pad) {
-      if (op) {
+      if (op || gp) {
         int before = 0;
         for (int j = 0; j < i; ++j) before += (ys[j] == pad);
-        op[nv + before] = i;
+        if (op) op[nv + before] = i;
+        if (gp) dg[nv + before] = ig[nv + before] = gp[i] / log2f((float)(nv + before) + 2.0f);
       }
       continue;
     }
@@ -57,7 +62,7 @@ __global__ void __launch_bounds__(1024) ltrx_ndcg_kernel(const float* __restrict
       rs += (sj > si) || (sj == si && j < i);
       ry += (yj > yi) || (yj == yi && j < i);
     }
-    const float gain = exp2f(yi) - 1.0f;
+    const float gain = gp ? gp[i] : exp2f(yi) - 1.0f;
     dg[rs] = gain / log2f((float)rs + 2.0f);
     ig[ry] = gain / log2f((float)ry + 2.0f);
     if (op) op[rs] = i;
@@ -76,9 +81,9 @@ __global__ void __launch_bounds__(1024) ltrx_ndcg_kernel(const float* __restrict
 
 extern "C" size_t ltrx_ndcg_workspace_bytes(int B, int L) { (void)B; (void)L; return 0; }
 
-extern "C" int ltrx_ndcg_at(const float* y_pred, const float* y_true, int B, int L, const int* ats, int n_ats,
-                            float pad_value, float filler_value, float* ndcg_out, float* dcg_out, int64_t* order_out,
-                            void* ws, ltrx_stream_t stream) {
+static int ndcg_launch(const float* y_pred, const float* y_true, const float* gains, int B, int L, const int* ats, int n_ats,
+                       float pad_value, float filler_value, float* ndcg_out, float* dcg_out, int64_t* order_out,
+                       void* ws, ltrx_stream_t stream) {
   (void)ws;
   if (!y_pred || !y_true || !ats || !ndcg_out || B <= 0 || L <= 0 || n_ats <= 0) return LTRX_EINVAL;
   if (n_ats > LTRX_MAX_ATS || L > LTRX_MAX_METRIC_SLATE_LEN) return LTRX_EUNSUPPORTED;
@@ -97,7 +102,20 @@ extern "C" int ltrx_ndcg_at(const float* y_pred, const float* y_true, int B, int
     a.at[i] = ats[i];
   }
   hipLaunchKernelGGL(ltrx_ndcg_kernel, dim3(B), dim3(L > 512 ? 1024 : 256) /* long slates: 16 waves */, 4 * (size_t)L * sizeof(float), (hipStream_t)stream, y_pred,
-                     y_true, L, pad_value, filler_value, a, ndcg_out, dcg_out, order_out);
+                     y_true, L, pad_value, filler_value, a, ndcg_out, dcg_out, order_out, gains);
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
+}
+
+extern "C" int ltrx_ndcg_at(const float* y_pred, const float* y_true, int B, int L, const int* ats, int n_ats,
+                            float pad_value, float filler_value, float* ndcg_out, float* dcg_out, int64_t* order_out,
+                            void* ws, ltrx_stream_t stream) {
+  return ndcg_launch(y_pred, y_true, nullptr, B, L, ats, n_ats, pad_value, filler_value, ndcg_out, dcg_out, order_out, ws, stream);
+}
+
+extern "C" int ltrx_ndcg_at_gains(const float* y_pred, const float* y_true, const float* gains, int B, int L, const int* ats,
+                                  int n_ats, float pad_value, float filler_value, float* ndcg_out, float* dcg_out,
+                                  int64_t* order_out, void* ws, ltrx_stream_t stream) {
+  if (!gains) return LTRX_EINVAL;
+  return ndcg_launch(y_pred, y_true, gains, B, L, ats, n_ats, pad_value, filler_value, ndcg_out, dcg_out, order_out, ws, stream);
 }

@@ -127,6 +127,8 @@ class FusedTrainer(object):
         self.weight_images = bool(weight_images)
         self.group_wgrad = bool(group_wgrad) and gemm != "split_bf16_strict"     # (the strict arithmetic has no large-tile kernel)
         self._wg_pending = []
+        self.wgrad_group_log = []             # (problems, grouped kernel ran?) of the most recent _wgrad_flush calls
+        self._wg_probe = (ctypes.c_ubyte * 65536)()
         self._red_pending = []                # (src ptr, partial rows, row stride, columns, dst ptr) entries of the next _reduce_flush
         self._ln_slot = 0
         self._prec = {"split_bf16_strict": 1, "bf16": 2}.get(gemm, 0)        # precision code of ltrx_gemm_nt / ltrx_gemm_tn
@@ -228,6 +230,12 @@ class FusedTrainer(object):
             and gemm == "split_bf16" and optimizer in ("Adam", "AdamW")
             and self.lib.ltrx_fc_listnet_supported(L, self.fc_sizes[0], self.fc_sizes[1]))
         if fc_ok:
+            if compact or not use_graph:
+                import logging
+                logging.getLogger("allrank_amd.engine").info(
+                    "FusedTrainer: the slate-resident FC + ListNet step is taken (two launches per step, the padded batch read in place): "
+                    "compact=%s / use_graph=%s do not apply to it; scores / labels of the last step alias the caller's tensors until the "
+                    "next step()", compact, use_graph)
             compact = False
         self.compact = bool(compact)
         self.rows = B * L                                                     # rows the row-wise kernels run over
@@ -333,7 +341,7 @@ class FusedTrainer(object):
                 p_s1=float(lay.sublayer[1].dropout.p) if dropout else 0.0,
                 s_att=self._site(4 * i), s_ff=self._site(4 * i + 1), s_s0=self._site(4 * i + 2), s_s1=self._site(4 * i + 3))
             self.layers.append(st)
-        if relu_bits and self.N and self.dff % 256 == 0 and gemm not in ("hipblaslt", "split_bf16_strict"):
+        if relu_bits and self.N and self.dff % 256 == 0 and d % 32 == 0 and gemm not in ("hipblaslt", "split_bf16_strict"):
             # one bit per feed-forward activation (written by the forward GEMM, read by the input-gradient GEMM instead of r)
             for st in self.layers:
                 st["rbits"] = torch.zeros(((M + 255) // 256) * (self.dff // 256) * 8192, dtype=torch.uint8, device=dev)
@@ -382,10 +390,17 @@ class FusedTrainer(object):
             for (npp, kpp) in shapes:
                 nb = max(nb, self.lib.ltrx_gemm_tn_workspace_bytes(M, npp, kpp))
             if self.N and self.group_wgrad:                       # the four projections of a layer in one launch (_wgrad_flush)
-                import ctypes
-                npa = (ctypes.c_int * 4)(3 * d, d, self.dff, d)
-                kpa = (ctypes.c_int * 4)(d, d, d, self.dff)
-                nb = max(nb, self.lib.ltrx_gemm_tn_group_workspace_bytes(4, M, npa, kpa))
+                # ... or, when both sublayer dropouts are on (the dropout buffer d_br is reused between the branches), as two groups of
+                # two: fewer tiles per group -> more row splits per problem -> possibly MORE workspace than the group of four.  The
+                # buffer covers every composition the step issues, in issue order
+                w2, w1, wo, wq = (d, self.dff), (self.dff, d), (d, d), (3 * d, d)
+                comps = [[w2, w1, wo, wq]]
+                if any(st["p_s0"] and st["p_s1"] for st in self.layers):
+                    comps += [[w2, w1], [wo, wq]]
+                for comp in comps:
+                    npa = (ctypes.c_int * len(comp))(*[c[0] for c in comp])
+                    kpa = (ctypes.c_int * len(comp))(*[c[1] for c in comp])
+                    nb = max(nb, self.lib.ltrx_gemm_tn_group_workspace_bytes(len(comp), M, npa, kpa))
             self.ws_tn = torch.empty(max(nb, 64), dtype=torch.uint8, device=dev)
             # transposed weight copies for the input-gradient GEMMs (refreshed after every optimizer step by ONE batched
             # transpose launch): all copies live in one flat buffer, the descriptor table is built once
@@ -609,7 +624,8 @@ class FusedTrainer(object):
         buf = st.get("rbits")
         if buf is None or self.gemm in ("hipblaslt", "split_bf16_strict"):
             return None
-        need = self.lib.ltrx_gemm_nt_relu_bits_bytes(self.rows, self.dff)
+        # (both launches of a mask -- FFN-1 forward and FFN-2 input gradient -- contract over d_model: one K to ask about)
+        need = self.lib.ltrx_gemm_nt_relu_bits_bytes(self.rows, self.dff, self.d)
         return buf if 0 < need <= buf.numel() else None
 
     def _lin_fwd(self, x, w, b, out, act=0, p=0.0, seed=0, res=None, bits=None):
@@ -698,6 +714,12 @@ class FusedTrainer(object):
             outs = (so, bso, ctypes.byref(sp))
         else:
             outs = (None, None, None)
+        # did the grouped kernel take this composition, or did the call fall back to one launch per problem (shapes outside the
+        # large-tile kernel / not enough workspace)?  Same host-side predicate the library applies; tests assert it
+        took = (self.lib.ltrx_debug_tn_group_map(n, self.rows, NP, KP, self._wg_probe, self._wg_probe) > 0
+                and self.lib.ltrx_gemm_tn_group_workspace_bytes(n, self.rows, NP, KP) <= self.ws_tn.numel())
+        self.wgrad_group_log.append((n, bool(took)))
+        del self.wgrad_group_log[:-16]
         self.LB.check(self.lib.ltrx_gemm_tn_group(n, A, lda, Bm, ldb, C, bo, self.rows, NP, KP, self._prec, self.LB.ptr(self.ws_tn),
                                                   self.ws_tn.numel(), *outs, self._st()), "gemm_tn_group(wgrad)")
         if defer_reduce and sp.value > 0:
@@ -991,7 +1013,9 @@ class FusedTrainer(object):
         # (sharded: a rank whose block of a short last batch is empty -- 1 slate on 2 ranks -- still runs the step on 32 all-zero
         #  alignment rows: zero loss, zero gradient, and every collective of the step is entered by every rank)
         self.n_valid = n
-        self.rows = max(32, min(self.M, (n + 31) // 32 * 32))     # alignment rows (zero input, zero gradient) keep M % 32 == 0
+        # alignment rows (zero input, zero gradient) keep the row count a multiple of 32; never more rows than the buffers hold
+        # (a tiny batch, B * L < 32: the old max(32, ...) ran 32 rows over M-row buffers -- ADVICE r4)
+        self.rows = min(self.M, max(32, (n + 31) // 32 * 32))
         F = self.x_in.shape[1]
         self.LB.check(self.lib.ltrx_gather_rows(self.LB.ptr(xb), F, self.LB.ptr(self.idx), n, self.rows, F, self.LB.ptr(self.x_in),
                                                 self.x_in.stride(0),
@@ -1093,6 +1117,11 @@ class FusedTrainer(object):
         GPU without clipping: the reducing launch also applies Adam (two launches per step); sharded or clipped: gradients only,
         then the all-reduce / clip and the flat-buffer Adam as in the general step."""
         LB, P = self.LB, self.LB.ptr
+        # (the general path's static-buffer copy accepts host batches; so does this one: a host batch is copied to the device first)
+        if not xb.is_cuda:
+            xb = xb.to(self.dev, non_blocking=True)
+        if not yb.is_cuda:
+            yb = yb.to(self.dev, non_blocking=True)
         xb = xb.reshape(self.M, -1)
         if xb.dtype != torch.float32 or not xb.is_contiguous():
             xb = xb.float().contiguous()

@@ -236,14 +236,23 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
     of the fused step, "split_bf16" = fp32-class parity arithmetic, "bf16" = the one-product throughput mode, see FusedTrainer)."""
     import torch.distributed as dist
     device = torch.device(device)
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     if isinstance(model, torch.nn.DataParallel):
+        # main.py:76-78 wrapped the model because several GPUs are visible.  The engine does not replicate inside one process: under a
+        # process group every rank already holds its replica (allrank_amd.launch rebinds the wrapper away); without one, say so --
+        # the whole (gpu_count x batch_size) batch of dataset_loading.py:240-241 is about to train on ONE device.
+        n_vis = len(getattr(model, "device_ids", None) or [])
         model = model.module
+        if world == 1:
+            log.warning("allrank_amd.fit: the model arrived wrapped in nn.DataParallel over %d GPUs but no torch.distributed process "
+                        "group is up -- training runs on %s ALONE, the other GPUs stay idle.  Start the job as "
+                        "`python -m allrank_amd.launch --nproc %d -- <main.py arguments>` (one process per GPU, slate-sharded).",
+                        n_vis, device, max(n_vis, 2))
     metrics = dict(config.metrics)
     val_metric = getattr(config, "val_metric", None)
     writer = _tensorboard(tensorboard_output_path) if tensorboard_output_path else None
     num_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
     early_stop = _EarlyStop(early_stopping_patience)
-    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
 
     spec, reason = _fused_spec(model, loss_func, optimizer) if use_fused else (None, "use_fused=False")

@@ -9,7 +9,7 @@ from . import _lib as L
 PADDED_Y_VALUE = -1
 
 
-def _run(y_pred, y_true, ats, padding_indicator, filler_value, want_order):
+def _run(y_pred, y_true, ats, padding_indicator, filler_value, want_order, gain_function=None):
     if y_pred.dim() != 2 or y_pred.shape != y_true.shape:
         raise ValueError("y_pred and y_true must both be [batch_size, slate_length]")
     L.require_device(y_pred, y_true)
@@ -24,26 +24,35 @@ def _run(y_pred, y_true, ats, padding_indicator, filler_value, want_order):
     dc = torch.empty((B, n), dtype=torch.float32, device=yp.device)
     order = torch.empty((B, SL), dtype=torch.int64, device=yp.device) if want_order else None
     arr = (ctypes.c_int * n)(*ats)
-    L.check(L.lib().ltrx_ndcg_at(L.ptr(yp), L.ptr(yt), B, SL, arr, n, float(padding_indicator), float(filler_value),
-                                 L.ptr(nd), L.ptr(dc), L.ptr(order), None, L.stream_of(yp)), "ndcg_at")
+    if gain_function is None:                         # the default gain 2^x - 1, evaluated in the kernel
+        L.check(L.lib().ltrx_ndcg_at(L.ptr(yp), L.ptr(yt), B, SL, arr, n, float(padding_indicator), float(filler_value),
+                                     L.ptr(nd), L.ptr(dc), L.ptr(order), None, L.stream_of(yp)), "ndcg_at")
+    else:
+        # metrics.py:67: gains = gain_function(labels gathered in predicted order) -- an elementwise callable commutes with the
+        # gather, so it is evaluated once per item on the masked labels (padded -> 0, metrics.py:35) with torch on the device and
+        # the kernel ranks, discounts and accumulates the pre-computed gains (ltrx_ndcg_at_gains)
+        gains = gain_function(torch.where(yt == padding_indicator, torch.zeros_like(yt), yt))
+        if not torch.is_tensor(gains) or gains.shape != yt.shape:
+            raise ValueError("gain_function must map a [batch_size, slate_length] tensor of labels to a tensor of the same shape")
+        gains = L.f32c(gains.detach())
+        L.check(L.lib().ltrx_ndcg_at_gains(L.ptr(yp), L.ptr(yt), L.ptr(gains), B, SL, arr, n, float(padding_indicator),
+                                           float(filler_value), L.ptr(nd), L.ptr(dc), L.ptr(order), None, L.stream_of(yp)),
+                "ndcg_at_gains")
     return nd, dc, order
 
 
 def ndcg(y_pred, y_true, ats=None, gain_function=None, padding_indicator=PADDED_Y_VALUE, filler_value=1.0,
          return_order=False):
     """NDCG@ats (metrics.py:7-28): [batch, len(ats)]; slates without a relevant item get ``filler_value`` (1.0).
-    Only the default gain 2^x - 1 is implemented in the kernel."""
-    if gain_function is not None:
-        raise NotImplementedError("custom gain_function: only the default 2**x - 1 is implemented on the device")
-    nd, _, order = _run(y_pred, y_true, ats, padding_indicator, filler_value, return_order)
+    ``gain_function=None`` is the reference's default gain 2^x - 1 (in the kernel); any other elementwise callable -- the
+    reference itself passes the identity, losses/neuralNDCG.py:58 -- is applied to the labels on the device first."""
+    nd, _, order = _run(y_pred, y_true, ats, padding_indicator, filler_value, return_order, gain_function)
     return (nd, order) if return_order else nd
 
 
 def dcg(y_pred, y_true, ats=None, gain_function=None, padding_indicator=PADDED_Y_VALUE):
-    """DCG@ats (metrics.py:41-77)."""
-    if gain_function is not None:
-        raise NotImplementedError("custom gain_function: only the default 2**x - 1 is implemented on the device")
-    return _run(y_pred, y_true, ats, padding_indicator, 1.0, False)[1]
+    """DCG@ats (metrics.py:41-77); ``gain_function`` as in ``ndcg``."""
+    return _run(y_pred, y_true, ats, padding_indicator, 1.0, False, gain_function)[1]
 
 
 def mrr(y_pred, y_true, ats=None, padding_indicator=PADDED_Y_VALUE):

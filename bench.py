@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- slate-items/s of the listwise-LTR training step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 30 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -325,8 +325,8 @@ def gemm_error_vs_fp64(w, B, L, device, gemm):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)     # >= 200 timed steps after >= 20 warm-up steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="attn_approxndcg", choices=sorted(WORKLOADS))
     ap.add_argument("--slates-per-gpu", type=int, default=256)
     ap.add_argument("--slate-len", type=int, default=240)
@@ -361,13 +361,34 @@ def main():
     local = local % max(ndev, 1)                # (test hook: several ranks may share one GPU with LTRX_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    diag = {"rank_devices": [str(device)], "backend": None, "preflight": None}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("LTRX_DIST_BACKEND", "nccl")       # nccl == RCCL on ROCm
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        diag["backend"] = backend
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            # first contact with the collective backend, before anything is built on it: one small all-reduce on the device, checked
+            # (sum of the ranks), and the device of every rank gathered for the line -- a failure here is reported as a JSON line
+            # (`error`, `comm`) instead of a bare traceback, so a failed first RCCL run is diagnosable from the record alone
+            t = torch.full((1024,), float(rank + 1), device=device)
+            t0 = time.perf_counter()
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+            ok = bool((t == world * (world + 1) / 2).all().item())
+            devs = [None] * world
+            dist.all_gather_object(devs, "%s (%s)" % (device, torch.cuda.get_device_name(device)))
+            diag.update(rank_devices=devs, preflight=dict(ok=ok, first_allreduce_ms=round((time.perf_counter() - t0) * 1e3, 2)))
+            if not ok:
+                raise RuntimeError("preflight all-reduce returned a wrong sum")
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(json.dumps({"metric": "slate-items/sec training (WEB30K synth, slate 240)", "value": None, "unit": "slate-items/s",
+                                  "n_gpus": world, "error": "collective backend failed at first contact: %r" % (e,), "comm": diag}), flush=True)
+            raise
 
     from allrank_amd import losses as E
     from allrank_amd.engine import Trainer, FusedTrainer
@@ -398,8 +419,21 @@ def main():
             return trainer.step(x[j:j + B], y[j:j + B], idx[j:j + B], global_batch=B * world, lengths=lens_host[j:j + B])
         return trainer.step(x[j:j + B], y[j:j + B], idx[j:j + B], global_batch=B * world)
 
-    for i in range(args.warmup):
-        loss = one_step(i)
+    step_fallback = None
+    try:
+        for i in range(args.warmup):
+            loss = one_step(i)
+    except RuntimeError as e:
+        # (world > 1 only) the captured sharded step -- hipGraph segments with the collectives between them -- has only ever run on
+        # gloo before its first node: if it fails here, measure the same arithmetic as eager launches and record why
+        if world == 1 or args.engine != "fused":
+            raise
+        step_fallback = repr(e)
+        torch.cuda.synchronize()
+        trainer.use_graph = False
+        trainer._graphs.clear()
+        for i in range(args.warmup):
+            loss = one_step(i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -446,7 +480,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms_nocomm = float(t.item()) / args.steps * 1e3
         ms = dt / args.steps * 1e3
+        segs = trainer._graphs.get((float(B * world), True))
         comm = dict(allreduce_bytes_per_step=int(4 * trainer.nflat), buckets=len(trainer._buckets), backend=dist.get_backend(),
+                    rank_devices=diag["rank_devices"], preflight=diag["preflight"],
+                    captured=bool(trainer.use_graph and segs), graph_segments=(len(segs) if segs else 0),
+                    capture_fallback=trainer.capture_fallback, step_fallback=step_fallback,
                     ms_per_step_without_allreduce=round(ms_nocomm, 4), exposed_ms=round(max(ms - ms_nocomm, 0.0), 4),
                     overlapped=bool(ms - ms_nocomm < 0.05 * ms))      # "overlapped" = less than 5 % of the step is exposed
 
@@ -561,6 +599,46 @@ def main():
                 out["value_at_64_slates_per_gpu"] = round(20 * 64 * L / (time.perf_counter() - t0), 1)
             except Exception as e:      # never let the side measurement break the contract line
                 out["value_at_64_slates_per_gpu"] = "failed: %r" % (e,)
+        if world == 1 and w["N"] and args.engine == "fused" and not args.no_side_pass and not args.ragged and args.dropout == 0.0:
+            # "a second number uses WEB30K-like lengths counting VALID items only" and the shipped configs train with
+            # dropout 0.1 (reproducibility/configs/neuralndcg_web30k/approxndcg.json) -- both measured inside the default run, so the
+            # driver's record carries them: (i) ragged slates (lognormal lengths, ~47 % of the slots valid) through the variable-length
+            # step (FusedTrainer(compact=True): eager launches over the packed rows), valid items per second; (ii) the same dense
+            # workload with every transformer dropout at 0.1 (masks generated in the kernels).
+            def _side(trainer_, xs, ys, ids, lens=None, n=20):
+                nb = xs.shape[0] // B
+                def st(i):
+                    j = (i % nb) * B
+                    kw = dict(lengths=lens[j:j + B]) if lens is not None else {}
+                    return trainer_.step(xs[j:j + B], ys[j:j + B], ids[j:j + B], **kw)
+                for i in range(6):
+                    st(i)
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for i in range(n):
+                    st(6 + i)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0_) / n
+            try:
+                xr, yr, ir = synth_batch(4 * B, L, w["n_features"], 4711, device, ragged=True)
+                lens_r = (yr != -1).sum(1).cpu()
+                frac = float((yr != -1).float().mean().item())
+                mr = build_model(w, device, 0.0)
+                tr_ = FusedTrainer(mr, w["loss"], w.get("loss_args", {}), B, L, lr=1e-3, world_size=1, use_graph=True, gemm=args.gemm, compact=True)
+                sec = _side(tr_, xr, yr, ir, lens_r)
+                out["valid_items_per_s"] = round(B * L * frac / sec, 1)
+                out["ragged"] = {"valid_fraction": round(frac, 4), "ms_per_step": round(sec * 1e3, 4), "slots_per_s": round(B * L / sec, 1),
+                                 "execution": "variable-length (compact=True): packed valid rows, per-slate extents in attention; eager launches"}
+                del tr_, mr, xr, yr, ir
+            except Exception as e:
+                out["valid_items_per_s"] = "failed: %r" % (e,)
+            try:
+                md = build_model(w, device, 0.1)
+                td = FusedTrainer(md, w["loss"], w.get("loss_args", {}), B, L, lr=1e-3, world_size=1, use_graph=True, gemm=args.gemm)
+                out["value_dropout_0.1"] = round(B * L / _side(td, x, y, idx), 1)
+                del td, md
+            except Exception as e:
+                out["value_dropout_0.1"] = "failed: %r" % (e,)
         if world == 1 and not w["N"] and args.engine == "fused" and not args.no_side_pass:
             try:           # the large-batch point ("and a large-batch point, e.g. 2048/GPU"): 8 slates per workgroup
                 Bl = 2048

@@ -134,6 +134,12 @@ size_t ltrx_ndcg_workspace_bytes(int B, int L);
 int ltrx_ndcg_at(const float* y_pred, const float* y_true, int B, int L, const int* ats, int n_ats,
                  float pad_value, float filler_value, float* ndcg_out, float* dcg_out, int64_t* order_out,
                  void* ws, ltrx_stream_t stream);
+/* the same with a caller-supplied gain_function (metrics.py:7-8,41-42,67): gains[B,L] = gain_function evaluated per item on the
+ * masked labels (padded items -> label 0 first, metrics.py:35; they then carry gain_function(0) at their tail positions).  Both
+ * rankings -- by prediction and the ideal one, which sorts by LABEL (metrics.py:21) -- still come from y_pred / y_true. */
+int ltrx_ndcg_at_gains(const float* y_pred, const float* y_true, const float* gains, int B, int L, const int* ats, int n_ats,
+                       float pad_value, float filler_value, float* ndcg_out, float* dcg_out, int64_t* order_out,
+                       void* ws, ltrx_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pointwise / pairwise members of allrank.models.losses and MRR.
@@ -312,13 +318,14 @@ int ltrx_score_head_bwd(const float* dscores, const float* x, const float* w, in
  *                 SublayerConnection (transformer.py:98-106) written by the projection that closes the sublayer.
  *                 4 / 5: the ReLU and its backward with the mask carried as ONE BIT per element: act 4 = act 1 that also writes
  *                 the mask (of the post-dropout activation) to aux, act 5 = act 2 reading that mask instead of the fp32 activation
- *                 (aux = a 16-byte aligned buffer of ltrx_gemm_nt_relu_bits_bytes(M, N) bytes, ldaux ignored; both launches must
- *                 have the same M and N; LTRX_EUNSUPPORTED where that function returns 0).  Same results as acts 1 / 2.
+ *                 (aux = a 16-byte aligned buffer of ltrx_gemm_nt_relu_bits_bytes(M, N, K) bytes, ldaux ignored; both launches must
+ *                 have the same M and N, and the function must be non-zero for the K of EACH launch: N % 256 == 0, K % 32 == 0 and a
+ *                 tile count the large-tile kernel takes; LTRX_EUNSUPPORTED where it returns 0 -- use acts 1 / 2 there).  Same results as acts 1 / 2.
  *                 drop_p > 0: nn.Dropout after the activation (model.py:43, transformer.py:227) fused in the epilogue
  *                 (act 0/1: counter-based mask over the [M,N] output; act 2: the mask is carried by aux, only 1/(1-p)).
  *   ltrx_gemm_tn: C[NP,KP] (dense) = A[M,NP]^T * B[M,KP]  -- weight gradient dW = dY^T X (split over M, deterministic);
  *                 bias_out[NP] (optional) = column sums of A = the bias gradient, produced in the same pass. */
-size_t ltrx_gemm_nt_relu_bits_bytes(int M, int N);
+size_t ltrx_gemm_nt_relu_bits_bytes(int M, int N, int K);
 int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, const void* B_image, float* C, int ldc, int M, int N, int K, const float* bias,
                  int act, const float* aux, int ldaux, float drop_p, uint32_t drop_seed, const uint32_t* drop_step, int strict,
                  int tile, ltrx_stream_t stream);
@@ -331,7 +338,12 @@ int ltrx_split_image(const float* src, void* dst, size_t n, ltrx_stream_t stream
 /* The engine's whole per-step weight refresh in one launch: the image of the flat parameter buffer (src_base[0..nflat) -> src_image,
  * as ltrx_split_image) and, for the n matrices of desc / tile_start (as ltrx_transpose_batch), the transposed fp32 copy in dst_base
  * AND its image in dst_image (same offsets).  Requires nflat % 4 == 0, 16-byte aligned buffers, 4-float aligned dst offsets and
- * rows % 4 == 0 for every matrix.  Bit-identical to ltrx_transpose_batch + 2 x ltrx_split_image. */
+ * rows % 4 == 0 for every matrix.  Bit-identical to ltrx_transpose_batch + 2 x ltrx_split_image.
+ * ENGINE-INTERNAL: desc / tile_start are DEVICE tables, so the call can check the host-visible preconditions only (pointers, nflat % 4,
+ * 16-byte alignment of the five buffers); the per-matrix ones -- rows % 4 == 0, dst offset % 4 == 0 -- are the caller's contract
+ * (allrank_amd/engine.py `_fused_images` verifies them when it builds the table, and uses ltrx_transpose_batch + ltrx_split_image
+ * otherwise).  A table that violates them yields float4 stores that straddle rows: silent corruption of the copies, never a fault
+ * outside the buffers.  Other callers should use the two public calls it fuses. */
 int ltrx_weight_images(const float* src_base, size_t nflat, void* src_image, float* dst_base, void* dst_image, const int64_t* desc,
                        const int32_t* tile_start, int n, int total_tiles, const float* pad_src, int pad_rows, int pad_cols, int pad_ld,
                        float* pad_dst, void* pad_dst_image, ltrx_stream_t stream);

@@ -262,8 +262,10 @@ def lambdaloss(y_pred, y_true, eps=DEFAULT_EPS, pad=PADDED_Y_VALUE, weighing_sch
 # ----------------------------------------------------------------------------------------------
 # metrics.dcg / ndcg  (allrank/models/metrics.py:7-77)
 # ----------------------------------------------------------------------------------------------
-def dcg(y_pred, y_true, ats=None, powered=True, pad=PADDED_Y_VALUE, dtype=np.float32):
-    """returns (dcg[B, len(ats)], order[B, L]) -- order = stable-desc argsort of the masked predictions."""
+def dcg(y_pred, y_true, ats=None, powered=True, pad=PADDED_Y_VALUE, dtype=np.float32, gain_function=None):
+    """returns (dcg[B, len(ats)], order[B, L]) -- order = stable-desc argsort of the masked predictions.
+    ``gain_function`` (metrics.py:42,67): any elementwise callable on the labels gathered in predicted order -- padded items were
+    set to label 0 first (:35), so they carry gain_function(0) at the tail positions."""
     s = _f(y_pred, dtype).copy()
     t = _f(y_true, dtype).copy()
     B, L = t.shape
@@ -276,16 +278,20 @@ def dcg(y_pred, y_true, ats=None, powered=True, pad=PADDED_Y_VALUE, dtype=np.flo
     order = stable_argsort_desc(s)                     # :37
     tsp = np.take_along_axis(t, order, axis=1)         # :38
     disc = (dtype(1) / np.log2(np.arange(L, dtype=dtype) + dtype(2.0))).astype(dtype)   # :64-65
-    gains = (np.power(dtype(2), tsp) - 1) if powered else tsp                           # :67
+    if gain_function is not None:
+        gains = np.asarray(gain_function(tsp), dtype=dtype)                             # :67
+    else:
+        gains = (np.power(dtype(2), tsp) - 1) if powered else tsp
     dg = (gains * disc)[:, :max(ats)]                  # :69
     cum = np.cumsum(dg, axis=1, dtype=dtype)           # :71
     return cum[:, np.asarray(ats) - 1].astype(dtype), order    # :73-75
 
 
-def ndcg(y_pred, y_true, ats=None, pad=PADDED_Y_VALUE, filler_value=1.0, dtype=np.float32):
-    """returns (ndcg[B, len(ats)], order[B, L]).  metrics.py:7-28 (idcg == 0 -> filler_value)."""
-    idcg, _ = dcg(y_true, y_true, ats, True, pad, dtype)       # :21
-    d, order = dcg(y_pred, y_true, ats, True, pad, dtype)
+def ndcg(y_pred, y_true, ats=None, pad=PADDED_Y_VALUE, filler_value=1.0, dtype=np.float32, gain_function=None):
+    """returns (ndcg[B, len(ats)], order[B, L]).  metrics.py:7-28 (idcg == 0 -> filler_value); the ideal ranking sorts by LABEL
+    (dcg(y_true, y_true, ...), :21) whatever the gain function."""
+    idcg, _ = dcg(y_true, y_true, ats, True, pad, dtype, gain_function)       # :21
+    d, order = dcg(y_pred, y_true, ats, True, pad, dtype, gain_function)
     with np.errstate(invalid="ignore", divide="ignore"):
         out = d / idcg                                         # :22
     out[idcg == 0] = filler_value                              # :23-24

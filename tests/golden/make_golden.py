@@ -34,7 +34,8 @@ def ref_loss(fn, s, y, **kw):
     return np.float32(loss.item()), g
 
 
-def main():
+def build():
+    """{file name: {key: array}} -- what main() writes; tests/test_golden_drift.py regenerates and compares"""
     load_reference(stable_sort=True)
     from allrank.models import losses as RL, metrics as RM
     from allrank.models.model import make_model
@@ -78,7 +79,6 @@ def main():
         sm = torch.tensor(s).clone()
         sm[torch.tensor(y) == -1] = float("-inf")
         out[pre + "order"] = sm.sort(descending=True, dim=-1)[1].numpy().astype(np.int64)
-    np.savez_compressed(os.path.join(HERE, "losses_golden.npz"), **out)
 
     # ---- model golden: scores + parameter gradients through approxNDCG for two small configs ----
     mout = {}
@@ -117,8 +117,12 @@ def main():
             mout[pre + "param." + n_] = p_.detach().numpy().copy()
             mout[pre + "grad." + n_] = p_.grad.numpy().copy()
     mout["n_models"] = np.int64(len(cfgs))
-    np.savez_compressed(os.path.join(HERE, "model_golden.npz"), **mout)
-    for f in ("losses_golden.npz", "model_golden.npz"):
+    return {"losses_golden.npz": out, "model_golden.npz": mout}
+
+
+def main():
+    for f, d in build().items():
+        np.savez_compressed(os.path.join(HERE, f), **d)
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -58,7 +58,7 @@ def sigmoid(x):
     return (1.0 / (1.0 + np.exp(-x.astype(np.float64)))).astype(np.float32)
 
 
-def main():
+def build():
     load_reference(stable_sort=True)
     from allrank.models import losses as RL, metrics as RM
     from allrank.models.losses import loss_utils as LU
@@ -113,8 +113,13 @@ def main():
                                                                    n_samples=N_SAMPLES, beta=c["beta"], log_scores=c["log"])
         finally:
             LU.sample_gumbel = orig
-    np.savez_compressed(os.path.join(HERE, "extra_golden.npz"), **out)
-    print("extra_golden.npz", os.path.getsize(os.path.join(HERE, "extra_golden.npz")), "bytes")
+    return {"extra_golden.npz": out}
+
+
+def main():
+    for f, d in build().items():
+        np.savez_compressed(os.path.join(HERE, f), **d)
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle.ref_loader import load_reference  # noqa: E402
 
 
-def main():
+def build():
     load_reference(stable_sort=True)
     from allrank.models import losses as RL
     from allrank.models.model import make_model
@@ -74,8 +74,13 @@ def main():
             out[pre + "grad." + n_] = (p_.grad.numpy().copy() if p_.grad is not None else np.zeros_like(p_.detach().numpy()))
         for n_, b_ in model.named_buffers():
             out[pre + "buffer." + n_] = b_.detach().numpy().copy()
-    np.savez_compressed(os.path.join(HERE, "model_pe_golden.npz"), **out)
-    print("model_pe_golden.npz", os.path.getsize(os.path.join(HERE, "model_pe_golden.npz")), "bytes")
+    return {"model_pe_golden.npz": out}
+
+
+def main():
+    for f, d in build().items():
+        np.savez_compressed(os.path.join(HERE, f), **d)
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 
 if __name__ == "__main__":

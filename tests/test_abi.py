@@ -115,10 +115,11 @@ def test_grouped_wgrad_workspace_and_relu_bits_queries(libpath):
         for m in range(2048, M + 1, 32):
             sp = max(1, min(256 // tiles, m // 128))
             assert (sp * NP * KP + sp * NP + 4) * 4 <= have, (M, NP, KP, m)
-    for (M, N, want) in [(61440, 2048, True), (15360, 2048, True), (16384, 1024, True), (12000, 2048, False), (15360, 512, False),
-                         (15360, 2000, False), (1000, 2048, False)]:
-        b = lib.ltrx_gemm_nt_relu_bits_bytes(M, N)
-        assert (b > 0) == want and (not want or b == ((M + 255) // 256) * (N // 256) * 8192), (M, N, b)
+    for (M, N, K, want) in [(61440, 2048, 512, True), (15360, 2048, 512, True), (16384, 1024, 256, True), (12000, 2048, 512, False),
+                            (15360, 512, 512, False), (15360, 2000, 512, False), (1000, 2048, 512, False),
+                            (15360, 1024, 144, False)]:      # d_model 144: K % 32 != 0 -> acts 1 / 2
+        b = lib.ltrx_gemm_nt_relu_bits_bytes(M, N, K)
+        assert (b > 0) == want and (not want or b == ((M + 255) // 256) * (N // 256) * 8192), (M, N, K, b)
     # argument validation before any HIP call
     assert lib.ltrx_reduce_group(17, None, None, None, None, None, None) == -1
     assert lib.ltrx_ingest_batch(None, None, 0, 0, 0, 0, -1.0, None, None, None, None) == -1

@@ -193,6 +193,13 @@ def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=
 GRAD_TOL = 1e-3
 GRAD_TOL_MODEL = 5e-4
 GRAD_RMS_TOL = 2e-4
+# Round 5 (VERDICT r4 weak #1 ii): the gradient bars are a FIXED table per loss -- (max error / tensor's own largest entry, max error /
+# the model's largest gradient, rms error / own largest entry).  Round 3-4 widened the bars at run time to twice the measured
+# conditioning shift of the loss; the measured errors never needed it (profiles/r04_parity_benchdims.md: NeuralNDCG <= 7.8e-4 / 3.2e-4 /
+# 1.2e-4 at a shift of 9.7e-4, lambdaLoss <= 2.1e-4 / 2.7e-5 / 4.5e-5 at a shift of 1.7e-3, every other loss <= 7.6e-5 / 5.1e-5 / 1.4e-5).
+# NeuralNDCG is the one ill-conditioned loss (50 Sinkhorn steps amplify a score error of 7e-5 into a 1e-3 shift of its own gradient in
+# exact arithmetic): it gets bars 2x the default, fixed.
+GRAD_BARS = {"default": (GRAD_TOL, GRAD_TOL_MODEL, GRAD_RMS_TOL), "neuralNDCG": (2e-3, 1e-3, 4e-4)}
 CFG3 = dict(n_features=136, fc_sizes=[512], fc_activation=None, fc_input_norm=False, N=2, d_ff=2048, h=8, output_activation=None)
 CFG5 = dict(n_features=1024, fc_sizes=[512], fc_activation=None, fc_input_norm=False, N=2, d_ff=2048, h=8, output_activation=None)
 CFG1_FC = dict(n_features=136, fc_sizes=[96], fc_activation=None, fc_input_norm=False, N=0, d_ff=0, h=1, output_activation=None)
@@ -201,7 +208,10 @@ CFG1_MLP = dict(n_features=136, fc_sizes=[256, 512, 1024, 512, 256], fc_activati
                 output_activation=None)          # the reference's reproducibility/configs/ndcgloss2pp_mlp.json stack
 
 
-def _check(rows, name, grad_tol=GRAD_TOL, ndcg=True):
+def _check(rows, name, grad_tol=None, ndcg=True):
+    tol, tol_model, tol_rms = GRAD_BARS["neuralNDCG" if "neuralNDCG" in name else "default"]
+    if grad_tol is not None:
+        tol = grad_tol
     for r in rows:
         s = r["step"]
         assert r["loss_err"] <= 1e-5 * (1 + abs(r["oracle_loss"])), (name, s, r["loss"], r["oracle_loss"])
@@ -213,11 +223,10 @@ def _check(rows, name, grad_tol=GRAD_TOL, ndcg=True):
         # The loss kernel itself, at the engine's own scores: <= 1e-4 of the largest d loss / d score (measured <= 2e-5).  What the
         # forward's score error does to the loss gradient IN EXACT ARITHMETIC (the oracle's gradient at the engine's scores vs at
         # its own) is the conditioning of the loss at this point, and every parameter gradient inherits it: NeuralNDCG at the
-        # third step of config 4 moves by 2e-3 for a score error of 9e-5 (its kernel error there: 2e-5) -- the bars above are
-        # widened to twice that shift where it exceeds them, and the shift is in the logged table.
+        # third step of config 4 moves by 1e-3 for a score error of 7e-5 (its kernel error there: 2e-5).  The shift is logged in the
+        # table; the bars are the fixed GRAD_BARS row of the loss (no run-time widening).
         shift = r["lossgrad_shift_from_score_err"]
-        assert r["lossgrad_kernel_err"] <= max(1e-4, grad_tol / 10), (name, s, r["lossgrad_kernel_err"])
-        tol, tol_model, tol_rms = max(grad_tol, 2 * shift), max(GRAD_TOL_MODEL, 2 * shift), max(GRAD_RMS_TOL, shift)
+        assert r["lossgrad_kernel_err"] <= 1e-4, (name, s, r["lossgrad_kernel_err"])
         bad = {k: v for k, v in r["grads"].items()
                if (v["own_max"] > 1e-6 * r["grad_model_scale"] and (v["rel"] > tol or v["rms_err"] > tol_rms * v["own_max"]))
                or v["rel_model"] > tol_model}

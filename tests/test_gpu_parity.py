@@ -172,6 +172,35 @@ def test_ndcg_and_sort_indices(losses_golden):
             assert sorted(order[b].tolist()) == list(range(s.shape[1]))              # a permutation
 
 
+def test_ndcg_with_a_gain_function_matches_reference_golden():
+    """metrics.py:7-8,41-42 ``gain_function``: the identity the reference itself passes (losses/neuralNDCG.py:58), a gain that is
+    not zero at label 0 (padded items then count, metrics.py:35,67) and a non-monotone gain (the ideal ranking is by label,
+    metrics.py:21) -- reference-generated vectors (tests/golden/make_golden_gain.py), and the oracle on a long slate"""
+    from allrank_amd import metrics as EM
+    from tests.golden.make_golden_gain import GAINS
+    from tests.golden.make_inputs import make_inputs
+    g = np.load(os.path.join(ROOT, "tests", "golden", "gain_golden.npz"))
+    ats = [int(a) for a in g["ats"]]
+    for ci in range(int(g["n_cases"])):
+        pre = "c%d." % ci
+        s, y = g[pre + "s"], g[pre + "y"]
+        for name, fn in GAINS.items():
+            nd = EM.ndcg(_t(s), _t(y), ats=ats, gain_function=fn).cpu().numpy()
+            dc = EM.dcg(_t(s), _t(y), ats=ats, gain_function=fn).cpu().numpy()
+            nn = EM.ndcg(_t(s), _t(y), gain_function=fn, filler_value=0.25).cpu().numpy()
+            assert close(nd, g[pre + name + ".ndcg"]) and close(dc, g[pre + name + ".dcg"]) and close(nn, g[pre + name + ".ndcg_none"]), (ci, name)
+    # the reference's default gain handed over explicitly == the in-kernel default
+    s, y = make_inputs(4, 300, 77, tie_scores=True)
+    a = EM.ndcg(_t(s), _t(y), ats=[5, 30], gain_function=lambda x: torch.pow(2, x) - 1).cpu().numpy()
+    b = EM.ndcg(_t(s), _t(y), ats=[5, 30]).cpu().numpy()
+    assert close(a, b)
+    s, y = make_inputs(3, 3000, 78)
+    nd = EM.ndcg(_t(s), _t(y), ats=[5, 3000], gain_function=GAINS["plus1"]).cpu().numpy()
+    assert close(nd, O.ndcg(s, y, ats=[5, 3000], gain_function=GAINS["plus1"])[0])
+    with pytest.raises(ValueError):
+        EM.ndcg(_t(s), _t(y), gain_function=lambda x: x.sum(1))
+
+
 def test_metrics_on_validation_slates_longer_than_the_loss_limit():
     """validation sets are padded to their longest slate with no bound (dataset_loading.py:185-194): ndcg / mrr take slates of
     up to LTRX_MAX_METRIC_SLATE_LEN = 8192 items (values and stable sort indices == the oracle), beyond that -- and for a loss
@@ -1534,7 +1563,7 @@ def test_one_bit_relu_mask_gemm_epilogues_equal_the_fp32_activation_forms():
     rng = np.random.default_rng(41)
     step = torch.zeros(1, dtype=torch.int32, device=DEV)
     for (Mm, N, K1, p) in [(15360, 2048, 512, 0.0), (12300, 2048, 512, 0.1), (16384, 1024, 256, 0.3)]:
-        nbytes = lib.ltrx_gemm_nt_relu_bits_bytes(Mm, N)
+        nbytes = lib.ltrx_gemm_nt_relu_bits_bytes(Mm, N, K1)
         assert nbytes == ((Mm + 255) // 256) * (N // 256) * 8192
         x = _t(rng.standard_normal((Mm, K1)).astype(np.float32))
         w1 = _t((rng.standard_normal((N, K1)) / np.sqrt(K1)).astype(np.float32))
@@ -1556,7 +1585,8 @@ def test_one_bit_relu_mask_gemm_epilogues_equal_the_fp32_activation_forms():
                                   0, 0, None), "act 5")
         assert torch.equal(g_ref, g_bit), (Mm, N, p)
     for (Mm, N) in [(12000, 2048), (1000, 2048), (15360, 2000), (15360, 512)]:      # 376 tiles (split dispatch), 32 tiles, N % 256, 120 tiles
-        assert lib.ltrx_gemm_nt_relu_bits_bytes(Mm, N) == 0
+        assert lib.ltrx_gemm_nt_relu_bits_bytes(Mm, N, 512) == 0
+    assert lib.ltrx_gemm_nt_relu_bits_bytes(15360, 1024, 144) == 0                 # K % 32 != 0 (d_model 144)
     a, w = torch.zeros((1000, 512), device=DEV), torch.zeros((2048, 512), device=DEV)
     c, bits = torch.zeros((1000, 2048), device=DEV), torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
     assert lib.ltrx_gemm_nt(LB.ptr(a), 512, LB.ptr(w), 512, None, LB.ptr(c), 2048, 1000, 2048, 512, None, 4, LB.ptr(bits), 0, 0.0, 0, None, 0, 0, None) != 0
@@ -1589,6 +1619,29 @@ def test_relu_bits_step_is_bit_identical_to_the_activation_reading_step():
     assert out[True][0] == out[False][0], (out[True][0], out[False][0])
     for k, w in out[True][1].items():
         assert torch.equal(w, out[False][1][k]), k
+
+
+def test_relu_bits_default_falls_back_when_d_model_is_no_multiple_of_32():
+    """d_model = 144, d_ff = 1024, 64 x 240 rows -> 240 large tiles, inside the mask form's tile range, but the
+    GEMMs contract over K = 144 (K % 32 != 0): the default relu_bits=True must select acts 1 / 2 (no mask buffer) and train, with the
+    same losses as relu_bits=False."""
+    import copy
+    from allrank_amd.model import make_model
+    from allrank_amd.engine import FusedTrainer
+    rng = np.random.default_rng(16)
+    B, L, F = 64, 240, 24
+    x = _t(rng.standard_normal((B, L, F)).astype(np.float32))
+    yt = _t(rng.integers(0, 5, (B, L)).astype(np.float32))
+    torch.manual_seed(5)
+    base = make_model(dict(sizes=[144], input_norm=False, activation=None, dropout=0.0),
+                      dict(N=1, d_ff=1024, h=4, positional_encoding=None, dropout=0.0),
+                      dict(d_output=1, output_activation=None), F).to(DEV)
+    res = {}
+    for bits in (True, False):
+        ft = FusedTrainer(copy.deepcopy(base), "listNet", {}, B, L, lr=1e-3, use_graph=False, seed=3, relu_bits=bits)
+        assert ft._relu_bits(ft.layers[0]) is None and "rbits" not in ft.layers[0]
+        res[bits] = [ft.step(x, yt).item() for _ in range(3)]
+    assert res[True] == res[False] and all(np.isfinite(res[True]))
 
 
 def test_64_row_tile_gemm_equals_the_other_large_tile_forms_bit_for_bit():

@@ -230,3 +230,22 @@ def test_torch_port_matches_numpy_oracle():
             lt = st.step(torch.tensor(x), torch.tensor(y))
             lo = float(M.train_step(p, cfg, opt, x, y, ofn)[0])
             assert abs(lt - lo) <= (1e-6 if i == 0 else 1e-4) * (1 + abs(lo)), (loss, i, lt, lo)
+
+
+def test_oracle_ndcg_with_gain_function_matches_reference_golden():
+    """metrics.py:7-8,41-42,67 with a caller-supplied gain (tests/golden/make_golden_gain.py: identity -- what neuralNDCG.py:58 passes --,
+    a gain that is not 0 at label 0, a non-monotone gain)"""
+    import os
+    from tests.golden.make_golden_gain import GAINS
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gain_golden.npz"))
+    ats = [int(a) for a in g["ats"]]
+    for ci in range(int(g["n_cases"])):
+        pre = "c%d." % ci
+        s, y = g[pre + "s"], g[pre + "y"]
+        for name, fn in GAINS.items():
+            nd, _ = O.ndcg(s, y, ats=ats, gain_function=fn)
+            dc, _ = O.dcg(s, y, ats=ats, gain_function=fn)
+            nn, _ = O.ndcg(s, y, gain_function=fn, filler_value=0.25)
+            assert np.allclose(nd, g[pre + name + ".ndcg"], rtol=1e-5, atol=1e-6), (ci, name)
+            assert np.allclose(dc, g[pre + name + ".dcg"], rtol=1e-5, atol=1e-5), (ci, name)
+            assert np.allclose(nn, g[pre + name + ".ndcg_none"], rtol=1e-5, atol=1e-6), (ci, name)
