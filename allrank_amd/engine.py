@@ -86,7 +86,7 @@ class FusedTrainer(object):
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
                  optimizer="Adam", weight_decay=0.0, momentum=0.0, nesterov=False,
                  use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None, compact=False,
-                 weight_images=True, fc_step=True, group_wgrad=True, relu_bits=True, pad_input=True):
+                 weight_images=True, fc_step=True, group_wgrad=True, relu_bits=True, pad_input=True, overlap_wgrad=False):
         """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
         products), "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs), or "bf16" -- the THROUGHPUT mode: one bf16
         product per contraction in the dense projections AND in attention (fp32 storage, accumulation, LayerNorm, softmax,
@@ -114,7 +114,16 @@ class FusedTrainer(object):
         relu_bits=True: the feed-forward ReLU(+dropout) mask travels from the forward GEMM to the input-gradient GEMM as one bit per
         element (ltrx_gemm_nt acts 4 / 5) instead of being re-read from the saved fp32 activation; same results bit for bit.
         pad_input=True: the static input buffer keeps the features in rows padded to 256 floats so that the first FC layer (F = 136 is
-        no multiple of the GEMM's 32-column step) runs the large-tile forward and weight-gradient kernels; False = dense rows (A/B)."""
+        no multiple of the GEMM's 32-column step) runs the large-tile forward and weight-gradient kernels; False = dense rows (A/B).
+        overlap_wgrad=True: fork / join inside the step -- the grouped weight-gradient launch of encoder layer i and its reducing launch
+        run on a SECOND stream (a parallel branch of the captured hipGraph) beside the backward chain of layer i-1 (LayerNorm backward,
+        input-gradient GEMMs, attention backward), which does not depend on them (loss.backward() at train_utils.py:23 imposes no
+        order between a layer's dW and the next layer's dX).  The operands a deferred launch still reads (d_r, dqkv, the residual-
+        stream gradients, dropout-branch gradients, LayerNorm partials) are double-buffered by layer parity; the main stream joins the
+        branch of layer i+1 right before the LayerNorm backward that closes layer i (the first kernel that reuses its buffers), which
+        is also where a sharded run releases that layer's gradient bucket.  Same arithmetic, same launches: bit-identical results
+        (without dropout; with both sublayer dropouts on, the four weight gradients form one group instead of two).  Measured A/B:
+        profiles/r05_wgrad_overlap_ab.md."""
         import torch.nn as nn
         from . import _lib as LB
         from .losses import FusedLoss
@@ -126,6 +135,10 @@ class FusedTrainer(object):
         self.gemm = gemm
         self.weight_images = bool(weight_images)
         self.group_wgrad = bool(group_wgrad) and gemm != "split_bf16_strict"     # (the strict arithmetic has no large-tile kernel)
+        self.overlap_wgrad = bool(overlap_wgrad)              # (resolved below once the model family is known)
+        self._side = None                                     # the second stream of the fork / join (overlap_wgrad)
+        self._cur_set = 0
+        self._side_busy = False
         self._wg_pending = []
         self.wgrad_group_log = []             # (problems, grouped kernel ran?) of the most recent _wgrad_flush calls
         self._wg_probe = (ctypes.c_ubyte * 65536)()
@@ -352,15 +365,27 @@ class FusedTrainer(object):
             self.xf = torch.zeros((M, d), **f32)
             self.mean_f = torch.zeros(M, **f32)
             self.rstd_f = torch.zeros(M, **f32)
-            self.d_r = torch.zeros((M, self.dff), **f32)
-            self.dqkv = torch.zeros((M, 3 * d), **f32)
+            self.overlap_wgrad = bool(self.overlap_wgrad and self.group_wgrad and gemm != "hipblaslt")
+            nset = 2 if self.overlap_wgrad else 1
+            # per layer parity (overlap_wgrad: two sets): what a layer's deferred weight-gradient launch still reads while the
+            # next layer's backward chain runs
+            self.d_r_set = [torch.zeros((M, self.dff), **f32) for _ in range(nset)]
+            self.dqkv_set = [torch.zeros((M, 3 * d), **f32) for _ in range(nset)]
+            self.d_r, self.dqkv = self.d_r_set[0], self.dqkv_set[0]
+            if self.overlap_wgrad:
+                self.c_mid = [torch.zeros((M, d), **f32) for _ in range(2)]      # d loss / d x1 of a layer (LN1 backward output)
+                self.c_out = [torch.zeros((M, d), **f32) for _ in range(2)]      # d loss / d (layer input) (LN0 backward output)
+                self.d_br_set = [[torch.zeros((M, d), **f32) for _ in range(2)] for _ in range(2)]     # [set][ffn / attention branch]
             self.d_o = torch.zeros((M, d), **f32)
             self.tmp_d = torch.zeros((M, d), **f32)
             self.d_br = torch.zeros((M, d), **f32)            # gradient of a dropped residual branch (ds * keep)
             self.ws_ln = torch.empty(max(self.lib.ltrx_layernorm_bwd_workspace_bytes(M, d), 64), dtype=torch.uint8, device=dev)
             # deferred parameter-gradient partials of up to three LayerNorm backwards per encoder layer (_reduce_flush)
             self.ws_ln_g = [self.ws_ln] + [torch.empty_like(self.ws_ln) for _ in range(2)]
+            self._ws_ln_sets = [self.ws_ln_g] + ([[torch.empty_like(self.ws_ln) for _ in range(3)]] if self.overlap_wgrad else [])
             self.ws_mha = torch.empty(max(self.lib.ltrx_mha_bwd_workspace_bytes(B, L, self.h, self.d // self.h, self._mha_mode), 64), dtype=torch.uint8, device=dev)
+        if not self.N:
+            self.overlap_wgrad = False
         no = self.n_out
         self.scores_raw = torch.zeros((B, L) if no == 1 else (B, L, no), **f32)      # what the loss sees (model.forward)
         self.scores = self.scores_raw if no == 1 else torch.zeros((B, L), **f32)      # model.score (sum over the output units)
@@ -509,18 +534,37 @@ class FusedTrainer(object):
         self.LB.check(self.lib.ltrx_dropout_apply(P(src), P(dst), self.rows * src.shape[1], float(p), seed, P(self.drop_step), self._st()),
                       "dropout_apply")
 
-    def _branch_grad(self, ds, p, seed):
+    def _branch_grad(self, ds, p, seed, buf=None):
         if p == 0.0:
             return ds
-        self._drop_apply(ds, self.d_br, p, seed)
-        return self.d_br
+        buf = self.d_br if buf is None else buf
+        self._drop_apply(ds, buf, p, seed)
+        return buf
+
+    # ---- fork / join of the second stream (overlap_wgrad) ------------------------------------------------------------
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
+
+    def _fork(self):
+        """the side stream waits for everything issued so far on the main (current) stream"""
+        self._side_stream().wait_stream(torch.cuda.current_stream(self.dev))
+        self._side_busy = True
+
+    def _join(self):
+        """the main (current) stream waits for everything issued so far on the side stream (nothing to wait for when the side stream
+        got no work since the last join -- in particular never an event from outside a stream capture inside one)"""
+        if self._side_busy:
+            torch.cuda.current_stream(self.dev).wait_stream(self._side_stream())
+            self._side_busy = False
 
     def _ln_bwd(self, dy, xsum, a, mean, rstd, dres, dx, da, db):
         P = self.LB.ptr
         if self.group_wgrad and self.gemm != "hipblaslt" and self._ln_slot < len(self.ws_ln_g):
             # dx now; the (da, db) partials join the layer's one reducing launch (_reduce_flush)
             import ctypes
-            buf = self.ws_ln_g[self._ln_slot]
+            buf = self._ws_ln_sets[self._cur_set][self._ln_slot]
             self._ln_slot += 1
             rows_out = ctypes.c_int(0)
             self.LB.check(self.lib.ltrx_layernorm_bwd_partial(P(dy), P(xsum), P(a), P(mean), P(rstd), P(dres), self.rows, self.d,
@@ -837,6 +881,7 @@ class FusedTrainer(object):
         out = self.model.output_layer
         no = self.n_out
         self._wg_pending.clear()                                  # (a step that raised half-way must not leave work queued)
+        self._side_busy = False
         self._red_pending.clear()
         self._ln_slot = 0
         feat, sc_rows = self._forward(True)
@@ -857,8 +902,10 @@ class FusedTrainer(object):
             self.dz_pad[:M, :no].copy_(dsc.reshape(-1, no)[:M])
             self._lin_wgrad(self.dz_pad[:, :no], feat, G(out.w_1.weight), G(out.w_1.bias))
             self._lin_dgrad(self.dz_pad, W(out.w_1.weight), self.woutT_pad, ga)
+        ov = self.overlap_wgrad
         if self.N:
             nf = self.enc.norm
+            self._cur_set = (self.N - 1) % 2 if ov else 0           # (the final norm's partials join the last layer's reducing launch)
             self._ln_bwd(ga, self.xsum_f, W(nf.a_2), self.mean_f, self.rstd_f, None, gb, G(nf.a_2), G(nf.b_2))
             ds = gb                                               # d loss / d (x1_last + ffn_last)
             other = ga
@@ -867,25 +914,32 @@ class FusedTrainer(object):
                 lay = st["mod"]
                 n0, n1 = lay.sublayer[0].norm, lay.sublayer[1].norm
                 ff = lay.feed_forward
+                sset = i % 2 if ov else 0
+                self._cur_set = sset
+                d_r, dq = self.d_r_set[sset], self.dqkv_set[sset]
+                # where the two LayerNorm backwards of the layer write: ping-pong over (ga, gb), or -- overlap_wgrad -- the layer
+                # parity's own pair (the deferred weight-gradient launch of THIS layer still reads ds and `mid` while the next
+                # layer's chain runs)
+                mid, outb = (self.c_mid[sset], self.c_out[sset]) if ov else (other, ds)
                 # FFN branch
-                db = self._branch_grad(ds, st["p_s1"], st["s_s1"])
+                db = self._branch_grad(ds, st["p_s1"], st["s_s1"], self.d_br_set[sset][0] if ov else None)
                 # (the four weight gradients of the layer are queued and run as one grouped launch before the first kernel that
                 #  overwrites one of their operands: the LN0 backward below, or the second use of the dropout buffer d_br)
                 self._lin_wgrad(db, st["r"], G(ff.w_2.weight), G(ff.w_2.bias), defer=True)
-                self._lin_dgrad(db, W(ff.w_2.weight), self._wT.get(id(ff.w_2.weight)), self.d_r, relu_of=st["r"], p=st["p_ff"],
+                self._lin_dgrad(db, W(ff.w_2.weight), self._wT.get(id(ff.w_2.weight)), d_r, relu_of=st["r"], p=st["p_ff"],
                                 bits=self._relu_bits(st))
-                self._lin_wgrad(self.d_r, st["xn1"], G(ff.w_1.weight), G(ff.w_1.bias), defer=True)
-                self._lin_dgrad(self.d_r, W(ff.w_1.weight), self._wT.get(id(ff.w_1.weight)), self.tmp_d)
-                self._ln_bwd(self.tmp_d, st["x1"], W(n1.a_2), st["mean1"], st["rstd1"], ds, other, G(n1.a_2), G(n1.b_2))
-                ds, other = other, ds                              # ds = d loss / d x1
+                self._lin_wgrad(d_r, st["xn1"], G(ff.w_1.weight), G(ff.w_1.bias), defer=True)
+                self._lin_dgrad(d_r, W(ff.w_1.weight), self._wT.get(id(ff.w_1.weight)), self.tmp_d)
+                self._ln_bwd(self.tmp_d, st["x1"], W(n1.a_2), st["mean1"], st["rstd1"], ds, mid, G(n1.a_2), G(n1.b_2))
+                ds = mid                                           # ds = d loss / d x1
                 # attention branch
                 lo = lay.self_attn.linears[3]
-                if st["p_s0"] and st["p_s1"]:                      # d_br still holds the FFN branch's dY
+                if st["p_s0"] and st["p_s1"] and not ov:           # d_br still holds the FFN branch's dY
                     self._wgrad_flush()
-                db = self._branch_grad(ds, st["p_s0"], st["s_s0"])
+                db = self._branch_grad(ds, st["p_s0"], st["s_s0"], self.d_br_set[sset][1] if ov else None)
                 self._lin_wgrad(db, st["o"], G(lo.weight), G(lo.bias), defer=True)
                 self._lin_dgrad(db, W(lo.weight), self._wT.get(id(lo.weight)), self.d_o)
-                qkv, dq = st["qkv"], self.dqkv
+                qkv = st["qkv"]
                 self.LB.check(lib.ltrx_mha_bwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(kpm), P(st["o"]),
                                                P(self.d_o), P(st["lse"]), B, L, self.h, d // self.h, 3 * d, d, P(dq),
                                                dq.data_ptr() + 4 * d, dq.data_ptr() + 8 * d, 3 * d, st["p_att"], st["s_att"],
@@ -895,11 +949,27 @@ class FusedTrainer(object):
                     dq[self.n_valid:M].zero_()
                 self._lin_wgrad(dq, st["xn0"], st["gwqkv"], st["gbqkv"], defer=True)
                 self._lin_dgrad(dq, st["wqkv"], st.get("wqkvT"), self.tmp_d)
-                self._wgrad_flush(defer_reduce=True)
-                self._ln_bwd(self.tmp_d, st["xin"], W(n0.a_2), st["mean0"], st["rstd0"], ds, other, G(n0.a_2), G(n0.b_2))
-                ds, other = other, ds                              # ds = d loss / d (layer input)
-                self._reduce_flush()                               # the layer's parameter gradients are final from here
-                self._bucket_done(self.N - 1 - i)
+                if ov:
+                    # join the branch of layer i+1 (its weight gradients and reductions are complete: its bucket may go, and its
+                    # buffers -- this layer's `outb` among them -- may be reused), then fork this layer's grouped launch: it runs on
+                    # the side stream beside the LN0 backward below and the whole chain of layer i-1
+                    self._join()
+                    if i + 1 < self.N:
+                        self._bucket_done(self.N - 1 - (i + 1))
+                    self._fork()
+                    with torch.cuda.stream(self._side):
+                        self._wgrad_flush(defer_reduce=True)
+                else:
+                    self._wgrad_flush(defer_reduce=True)
+                self._ln_bwd(self.tmp_d, st["xin"], W(n0.a_2), st["mean0"], st["rstd0"], ds, outb, G(n0.a_2), G(n0.b_2))
+                ds, other = outb, mid                              # ds = d loss / d (layer input)
+                if ov:
+                    self._fork()                                   # (the reducing launch also sums the LN0 partials just written)
+                    with torch.cuda.stream(self._side):
+                        self._reduce_flush()
+                else:
+                    self._reduce_flush()                           # the layer's parameter gradients are final from here
+                    self._bucket_done(self.N - 1 - i)
         else:
             ds, other = ga, gb
         if self.pos is not None:                                  # backward of x = sqrt(d) fc_out + pe[rank]
@@ -919,7 +989,13 @@ class FusedTrainer(object):
                 elif self.p_fc:
                     self._drop_apply(ds, ds, self.p_fc, self._site(1000 + i))
             inp = (self.x_norm if self.in_norm is not None else self.x_in) if i == 0 else self.fc_out[i - 1]
-            self._lin_wgrad(ds, inp, G(lyr.weight), G(lyr.bias))
+            if ov and self.N:
+                # (the FC weight gradients use the slab workspace of the deferred launch of layer 0: same stream, behind it)
+                self._fork()
+                with torch.cuda.stream(self._side):
+                    self._lin_wgrad(ds, inp, G(lyr.weight), G(lyr.bias))
+            else:
+                self._lin_wgrad(ds, inp, G(lyr.weight), G(lyr.bias))
             if i == 0 and self.in_norm is not None:
                 # nn.LayerNorm parameter gradients: dw = sum dy * xhat, db = sum dy with dy = ds W_0 (the input itself needs no
                 # gradient; ltrx_layernorm_bwd's da / db formulas only use the saved mean and rstd, its dx output is scratch)
@@ -936,6 +1012,9 @@ class FusedTrainer(object):
                 if self.fc_act >= 3:
                     self.LB.check(lib.ltrx_out_act_bwd(P(ds), P(self.fc_out[i - 1]), M * ds.shape[1], self.fc_act - 2, P(ds), self._st()),
                                   "fc_act_bwd")
+        if ov and self.N:
+            self._join()                                          # every gradient is final: the rest of the buckets, then the optimizer
+            self._bucket_done(self.N - 1)
         self._bucket_done(len(self._buckets) - 1)
         return loss
 

@@ -1644,6 +1644,71 @@ def test_relu_bits_default_falls_back_when_d_model_is_no_multiple_of_32():
     assert res[True] == res[False] and all(np.isfinite(res[True]))
 
 
+@pytest.mark.parametrize("N,B,dff", [(2, 64, 2048), (3, 40, 1024), (1, 64, 2048)])
+def test_overlap_wgrad_step_is_bit_identical_to_the_serial_step(N, B, dff):
+    """FusedTrainer(overlap_wgrad=True): the grouped weight-gradient launch and the reducing launch of every encoder layer on a second
+    stream (a parallel branch of the captured hipGraph), double-buffered operands -- same kernels on the same data: losses, every
+    gradient and every weight equal the serial step bit for bit over eager warm-up, capture and replays; also with a short last
+    batch (its own capture) and through score()."""
+    import copy
+    from allrank_amd.model import make_model
+    from allrank_amd.engine import FusedTrainer
+    rng = np.random.default_rng(60 + N)
+    L, F = 240, 40
+    x = _t(rng.standard_normal((B, L, F)).astype(np.float32))
+    y = rng.integers(0, 5, (B, L)).astype(np.float32)
+    y[3, 100:] = -1
+    yt = _t(y)
+    torch.manual_seed(14)
+    base = make_model(dict(sizes=[256], input_norm=False, activation=None, dropout=0.0),
+                      dict(N=N, d_ff=dff, h=4, positional_encoding=None, dropout=0.0),
+                      dict(d_output=1, output_activation=None), F).to(DEV)
+    out = {}
+    for ov in (True, False):
+        for graph in (True, False):
+            m = copy.deepcopy(base)
+            ft = FusedTrainer(m, "approxNDCGLoss", {}, B, L, lr=1e-3, use_graph=graph, seed=5, overlap_wgrad=ov)
+            assert ft.overlap_wgrad == ov
+            losses, grads = [], []
+            for k in range(5):
+                losses.append(ft.step(x, yt).item())
+                grads.append(ft.flat_g.clone())
+            losses.append(ft.step(x, yt, global_batch=B - 7).item())       # another divisor: its own capture
+            torch.cuda.synchronize()
+            out[(ov, graph)] = (losses, grads, ft.flat_p.clone(), ft.score(x, yt).clone())
+    ref = out[(False, False)]
+    for key, (losses, grads, w, sc) in out.items():
+        assert losses == ref[0], (key, losses, ref[0])
+        for k, g in enumerate(grads):
+            assert torch.equal(g, ref[1][k]), (key, "gradients of step", k)
+        assert torch.equal(w, ref[2]) and torch.equal(sc, ref[3]), key
+
+
+def test_overlap_wgrad_with_dropout_trains_and_matches_the_serial_loss_of_the_first_step():
+    """with both sublayer dropouts on, the serial step issues two groups of two weight gradients (the dropout buffer is reused between
+    the branches) and the overlapped step one group of four (own buffers): other split counts, so equality is to round-off, on the
+    same masks (same seed): first-step loss identical (the forward is untouched), gradients within 1e-5 of the largest entry"""
+    import copy
+    from allrank_amd.model import make_model
+    from allrank_amd.engine import FusedTrainer
+    rng = np.random.default_rng(71)
+    B, L, F = 64, 240, 40
+    x = _t(rng.standard_normal((B, L, F)).astype(np.float32))
+    yt = _t(rng.integers(0, 5, (B, L)).astype(np.float32))
+    torch.manual_seed(15)
+    base = make_model(dict(sizes=[256], input_norm=False, activation=None, dropout=0.0),
+                      dict(N=2, d_ff=2048, h=4, positional_encoding=None, dropout=0.1),
+                      dict(d_output=1, output_activation=None), F).to(DEV)
+    res = {}
+    for ov in (True, False):
+        ft = FusedTrainer(copy.deepcopy(base), "approxNDCGLoss", {}, B, L, lr=1e-3, use_graph=False, seed=5, overlap_wgrad=ov)
+        res[ov] = (ft.step(x, yt).item(), ft.flat_g.clone(), [n for n, _ in ft.wgrad_group_log])
+    assert res[True][0] == res[False][0]
+    assert res[True][2][-2:] == [4, 4] and res[False][2][-4:] == [2, 2, 2, 2], (res[True][2], res[False][2])
+    err = (res[True][1] - res[False][1]).abs().max().item() / res[False][1].abs().max().item()
+    assert err <= 1e-5, err
+
+
 def test_64_row_tile_gemm_equals_the_other_large_tile_forms_bit_for_bit():
     """ltrx_gemm_nt tile 8 (64 x 256 tiles, two workgroups per CU: the automatic choice for small batches) == tiles 7 and 6, bits,
     through every epilogue (bias, ReLU, ReLU mask, residual, dropout), exact and ragged row counts, with and without the image."""
