@@ -41,6 +41,7 @@ SIGNATURES = {
     "ltrx_ndcg_at": (_i, [_vp, _vp, _i, _i, ctypes.POINTER(ctypes.c_int), _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_ndcg_at_gains": (_i, [_vp, _vp, _vp, _i, _i, ctypes.POINTER(ctypes.c_int), _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, ctypes.c_uint32, _vp, _vp]),
+    "ltrx_layernorm_fwd_image": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, ctypes.c_uint32, _vp, _vp]),
     "ltrx_layernorm_bwd_workspace_bytes": (_sz, [_i, _i]),
     "ltrx_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_layernorm_bwd_partial": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
@@ -66,6 +67,8 @@ SIGNATURES = {
     "ltrx_gemm_nt_relu_bits_bytes": (_sz, [_i, _i, _i]),
     "ltrx_gemm_nt": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _f, ctypes.c_uint32, _vp, _i, _i, _vp]),
     "ltrx_split_image": (_i, [_vp, _vp, _sz, _vp]),
+    "ltrx_gemm_nt_image_ok": (_i, [_i, _i, _i]),
+    "ltrx_gemm_nt_img": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _f, ctypes.c_uint32, _vp, _i, _i, _i, _vp]),
     "ltrx_weight_images": (_i, [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ltrx_ingest_batch": (_i, [_vp, _vp, _sz, _sz, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "ltrx_gemm_tn_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -73,6 +76,7 @@ SIGNATURES = {
     "ltrx_gemm_tn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ltrx_gemm_tn_group_workspace_bytes": (_sz, [_i, _i, _vp, _vp]),
     "ltrx_gemm_tn_group": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "ltrx_gemm_tn_group_img": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_reduce_group": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ltrx_debug_tn_group_map": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "ltrx_layernorm_torch_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),

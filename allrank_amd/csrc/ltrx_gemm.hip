@@ -253,17 +253,21 @@ struct SmemNT {
   __bf16 b[NT][256 * 32];
 };
 
-// BIMG: B points at a pre-split IMAGE of the operand instead of fp32 values -- per 4 consecutive k the 16 bytes {hi0..hi3, lo0..lo3}
+// IMG >= 1: B points at a pre-split IMAGE of the operand instead of fp32 values -- per 4 consecutive k the 16 bytes {hi0..hi3, lo0..lo3}
 // (bf16) in place of the 4 floats, same addressing (ltrx_split_image; the weights and their transposes, refreshed once per optimizer
 // step).  The staging of B is then a plain copy: half of the kernel's split work (VALU, and the power it draws) is gone, the bits
 // that reach LDS -- and the results -- are identical.
-template <bool TAIL, int BM, int NT, bool BIMG>
+// IMG == 2 (round 5): A is an image too -- an ACTIVATION written that way by its producer (the LayerNorm forward, the feed-forward
+// GEMM's own epilogue: `cimg`), which has no fp32 reader: the loop then stages both operands with plain copies, no split at all.
+// cimg: the output tile leaves as an image (each 16-byte store = 4 consecutive columns of one row, split in the epilogue).
+template <bool TAIL, int BM, int NT, int IMG>
 __device__ __forceinline__ void nt256_body(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                            int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
                                            const float* __restrict__ bias, int act,
                                            const float* __restrict__ aux, int ldaux, int tiles_n,
-                                           ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step) {
+                                           ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step, int cimg) {
   constexpr int BK_ = 32;
+  constexpr bool BIMG = IMG >= 1, AIMG = IMG == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   typedef SmemNT<BM, NT> SmemT;
   constexpr int L1 = NT - 1;           // index of the lo image (aliases hi when there is none; never touched then)
@@ -299,9 +303,14 @@ __device__ __forceinline__ void nt256_body(const float* __restrict__ A, int lda,
     for (int p = 0; p < 4; ++p) {
       const int o = swz_off<BK_>(srow + 64 * p, sc4);
       if (p < RI) {
-        split4<2>(ra[p < RI ? p : 0], h, l, l2);
-        *reinterpret_cast<bf16x4*>(&d.a[0][o]) = h;
-        if (NT == 2) *reinterpret_cast<bf16x4*>(&d.a[L1][o]) = l;
+        if constexpr (AIMG) {
+          *reinterpret_cast<float2*>(&d.a[0][o]) = make_float2(ra[p < RI ? p : 0].x, ra[p < RI ? p : 0].y);
+          if (NT == 2) *reinterpret_cast<float2*>(&d.a[L1][o]) = make_float2(ra[p < RI ? p : 0].z, ra[p < RI ? p : 0].w);
+        } else {
+          split4<2>(ra[p < RI ? p : 0], h, l, l2);
+          *reinterpret_cast<bf16x4*>(&d.a[0][o]) = h;
+          if (NT == 2) *reinterpret_cast<bf16x4*>(&d.a[L1][o]) = l;
+        }
       }
       if constexpr (BIMG) {
         *reinterpret_cast<float2*>(&d.b[0][o]) = make_float2(rb[p].x, rb[p].y);
@@ -439,6 +448,10 @@ __device__ __forceinline__ void nt256_body(const float* __restrict__ A, int lda,
         if (act == 4)        // (after the dropout scaling: a dropped unit is 0 in the saved activation and passes no gradient)
           mbits[((j * RI + i) * 4 + g) >> 3] |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u))
                                                 << ((((j * RI + i) * 4 + g) & 7) * 4);
+        if (cimg) {          // the consumer GEMMs stage this activation as an operand image: split once, here
+          const float4 im = ltrx_split_image4(make_float4(v.x, v.y, v.z, v.w));
+          v = f32x4{im.x, im.y, im.z, im.w};
+        }
         __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(C + (size_t)row * ldc + col));
       }
     }
@@ -446,23 +459,23 @@ __device__ __forceinline__ void nt256_body(const float* __restrict__ A, int lda,
   if (act == 4) *mask_words = make_uint4(mbits[0], mbits[1], mbits[2], mbits[3]);
 }
 
-template <bool TAIL, int BM, int NT, bool BIMG>
+template <bool TAIL, int BM, int NT, int IMG>
 __global__ void __launch_bounds__(512) ltrx_gemm_nt256_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B,
                                                               int ldb, float* __restrict__ C, int ldc, int M, int N, int K,
                                                               const float* __restrict__ bias, int act,
                                                               const float* __restrict__ aux, int ldaux, int tiles_n,
-                                                              ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step) {
-  nt256_body<TAIL, BM, NT, BIMG>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step);
+                                                              ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step, int cimg) {
+  nt256_body<TAIL, BM, NT, IMG>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step, cimg);
 }
 // 64-row tiles, TWO workgroups per CU (2 x 80 KB of LDS, 128 registers per lane): for the shapes whose 128-row tiling is a single,
 // not even full round of workgroups (N = 512 projections at 64 slates per GPU: 240 tiles) -- twice the workgroups, four waves per
 // SIMD to hide the staging latency that two waves leave exposed
-template <bool TAIL, int NT, bool BIMG>
+template <bool TAIL, int NT, int IMG>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 ltrx_gemm_nt64_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc, int M,
                       int N, int K, const float* __restrict__ bias, int act, const float* __restrict__ aux, int ldaux, int tiles_n,
-                      ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step) {
-  nt256_body<TAIL, 64, NT, BIMG>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step);
+                      ltrx::DropSpec drop, const uint32_t* __restrict__ drop_step, int cimg) {
+  nt256_body<TAIL, 64, NT, IMG>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step, cimg);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -596,6 +609,7 @@ struct TnGroup {
   int kv[LTRX_TN_GROUP];             // columns of B that exist (= row length of the slabs and of C); KP = kv rounded up to the tile
   int tile_start[LTRX_TN_GROUP + 1];
   int nprob;
+  unsigned char bimg[LTRX_TN_GROUP];   // operand B of the problem is a pre-split image (an activation written that way by its producer)
   // grouped launches (nprob > 1, at most 256 workgroups): workgroup id -> (tile, split), built by the host so that the tiles of one
   // (problem, split) -- which share their two operand row slabs -- sit on ONE XCD (workgroup w is dispatched to XCD w % 8)
   unsigned char map_tile[256];
@@ -632,6 +646,7 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const TnGroup grp,
   float* __restrict__ slabs = grp.slabs[pi];
   float* __restrict__ bias_slabs = grp.bias_slabs[pi];
   const int lda = grp.lda[pi], ldb = grp.ldb[pi], NP = grp.NP[pi], tiles_k = grp.tiles_k[pi], kv = grp.kv[pi];
+  const bool bimg = grp.bimg[pi] != 0;                                  // (workgroup-uniform)
   const int tile = gtile - grp.tile_start[pi];
   const int n0 = (tile / tiles_k) * 256, k0 = (tile % tiles_k) * 256;
   const int wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
@@ -654,7 +669,30 @@ __global__ void __launch_bounds__(512) ltrx_gemm_tn256_kernel(const TnGroup grp,
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool want_bias = bias_slabs != nullptr && (tile % tiles_k) == 0;      // column sums of A = the bias gradient
   auto sstore1 = [&](SmemT& d, int g) {
-    {
+    if (g == 1 && bimg) {
+      // B is an image: row e of the thread's 4 (m) x 4 (column) block arrives as {hi(c0,c1), hi(c2,c3), lo(c0,c1), lo(c2,c3)} -- four
+      // dwords of two bf16 each.  The LDS image wants [column][m .. m+3]: a 4 x 4 transpose of 16-bit values, two v_perm_b32 per
+      // (column, term) instead of the split's ~6 VALU operations per element.
+      unsigned int wv[4][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        wv[e][0] = __float_as_uint(r[1][e].x); wv[e][1] = __float_as_uint(r[1][e].y);
+        wv[e][2] = __float_as_uint(r[1][e].z); wv[e][3] = __float_as_uint(r[1][e].w);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const unsigned int sel = (c & 1) ? 0x07060302u : 0x05040100u;     // high / low halves of the two source dwords
+        const int hw = c >> 1;                                            // dword holding the hi pair of columns (c, c^1); lo pair: + 2
+        uint2 hq, lq;
+        hq.x = __builtin_amdgcn_perm(wv[1][hw], wv[0][hw], sel);
+        hq.y = __builtin_amdgcn_perm(wv[3][hw], wv[2][hw], sel);
+        lq.x = __builtin_amdgcn_perm(wv[1][hw + 2], wv[0][hw + 2], sel);
+        lq.y = __builtin_amdgcn_perm(wv[3][hw + 2], wv[2][hw + 2], sel);
+        const int o = swz_t(4 * cg + c, 4 * mg);
+        *reinterpret_cast<uint2*>(&d.b[0][o]) = hq;
+        if (NT == 2) *reinterpret_cast<uint2*>(&d.b[L1][o]) = lq;
+      }
+    } else {
       __bf16* img0 = g ? d.b[0] : d.a[0];
       __bf16* img1 = g ? d.b[L1] : d.a[L1];
       const float cx[4][4] = {{r[g][0].x, r[g][1].x, r[g][2].x, r[g][3].x}, {r[g][0].y, r[g][1].y, r[g][2].y, r[g][3].y},
@@ -948,10 +986,49 @@ extern "C" size_t ltrx_gemm_nt_relu_bits_bytes(int M, int N, int K) {
   return t * 512 * 16;
 }
 
+// Would ltrx_gemm_nt_img accept operand / output IMAGES for this shape -- i.e. does the automatic tile choice land on the large-tile
+// kernel family (256 / 128 / 64-row tiles) for every epilogue?  A producer that writes an activation as an image asks this for each
+// GEMM that will consume it, BEFORE writing it (the image has no fp32 copy).  Mirrors the dispatch of ltrx_gemm_nt_img below.
+extern "C" int ltrx_gemm_nt_image_ok(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || (N % 256) || (K % 32)) return 0;
+  const size_t t = (size_t)((M + 255) / 256) * (N / 256);
+  if (t > 256 && t < 360) return 0;                    // (with dropout in the epilogue this range takes the small-tile kernel)
+  if (t >= 360 && t < 380 && N / 256 <= 256) {         // may run as one full round of large tiles + the remaining rows
+    const int m1 = (256 / (N / 256)) * 256;
+    if (M - m1 > 0 && !ltrx_gemm_nt_image_ok(M - m1, N, K)) return 0;
+  }
+  if (t >= 360 || (t >= 168 && t <= 256)) return 1;
+  if (t >= 136 && t < 168 && (size_t)((M + 127) / 128) * (N / 256) > 256) return 1;
+  const size_t t128 = (size_t)((M + 127) / 128) * (N / 256);
+  if (t128 >= 176 && t128 <= 256) return 1;
+  if (t128 < 176) {
+    const size_t t64 = (size_t)((M + 63) / 64) * (N / 256);
+    if (t64 >= 176 && t64 <= 512) return 1;
+  }
+  return 0;
+}
+
+extern "C" int ltrx_gemm_nt_img(const float* A, int lda, const float* B, int ldb, const void* B_image, float* C, int ldc, int M, int N, int K,
+                                const float* bias, int act, const float* aux, int ldaux, float drop_p, uint32_t drop_seed,
+                                const uint32_t* drop_step, int strict, int tile, int operand_flags, ltrx_stream_t stream);
+
 extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, const void* B_image, float* C, int ldc, int M, int N, int K,
                             const float* bias, int act, const float* aux, int ldaux, float drop_p, uint32_t drop_seed,
                             const uint32_t* drop_step, int strict, int tile, ltrx_stream_t stream) {
+  return ltrx_gemm_nt_img(A, lda, B, ldb, B_image, C, ldc, M, N, K, bias, act, aux, ldaux, drop_p, drop_seed, drop_step, strict, tile, 0,
+                          stream);
+}
+
+extern "C" int ltrx_gemm_nt_img(const float* A, int lda, const float* B, int ldb, const void* B_image, float* C, int ldc, int M, int N, int K,
+                                const float* bias, int act, const float* aux, int ldaux, float drop_p, uint32_t drop_seed,
+                                const uint32_t* drop_step, int strict, int tile, int operand_flags, ltrx_stream_t stream) {
   if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 5 || tile < 0) return LTRX_EINVAL;
+  if (operand_flags & ~(LTRX_GEMM_A_IS_IMAGE | LTRX_GEMM_C_AS_IMAGE)) return LTRX_EINVAL;
+  const bool aimg = (operand_flags & LTRX_GEMM_A_IS_IMAGE) != 0;
+  const int cimg = (operand_flags & LTRX_GEMM_C_AS_IMAGE) ? 1 : 0;
+  // images exist in the large-tile kernel family only; an image of A goes with an image of B (the engine's weights always have one)
+  if (operand_flags && (strict == 1 || ((uintptr_t)A & 15) || ((uintptr_t)C & 15))) return LTRX_EUNSUPPORTED;
+  if (aimg && (!B_image || (((uintptr_t)B_image) & 15))) return LTRX_EUNSUPPORTED;
   if (!(drop_p >= 0.f) || drop_p >= 1.f) return LTRX_EINVAL;
   const ltrx::DropSpec drop = ltrx_make_drop(drop_p, drop_seed);
   if ((act == 2 || act == 3) && (!aux || ldaux < N)) return LTRX_EINVAL;
@@ -984,10 +1061,11 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, co
       // generated in the epilogue -- its hash is indexed by the row of THIS launch.
       const int m1 = (256 / (N / 256)) * 256;
       const int prec = plain ? 2 : strict;
-      int rc = ltrx_gemm_nt(A, lda, B, ldb, B_image, C, ldc, m1, N, K, bias, act, aux, ldaux, drop_p, drop_seed, drop_step, prec, 0, stream);
+      int rc = ltrx_gemm_nt_img(A, lda, B, ldb, B_image, C, ldc, m1, N, K, bias, act, aux, ldaux, drop_p, drop_seed, drop_step, prec, 0,
+                                operand_flags, stream);
       if (rc != LTRX_OK) return rc;
-      return ltrx_gemm_nt(A + (size_t)m1 * lda, lda, B, ldb, B_image, C + (size_t)m1 * ldc, ldc, M - m1, N, K, bias, act,
-                          aux ? aux + (size_t)m1 * ldaux : nullptr, ldaux, drop_p, drop_seed, drop_step, prec, 0, stream);
+      return ltrx_gemm_nt_img(A + (size_t)m1 * lda, lda, B, ldb, B_image, C + (size_t)m1 * ldc, ldc, M - m1, N, K, bias, act,
+                              aux ? aux + (size_t)m1 * ldaux : nullptr, ldaux, drop_p, drop_seed, drop_step, prec, 0, operand_flags, stream);
     }
     if (t >= 360 || (t >= 168 && t <= 256)) v = 6;
     else if (t >= 136 && t < 168 && (size_t)((M + 127) / 128) * (N / 256) > 256) v = 6;   // one partial round still beats two rounds of smaller tiles
@@ -1011,8 +1089,9 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, co
 #define LTRX_NT64_ATTR(TAIL_, NT_, IMG_)                                                                                  \
   (hipFuncSetAttribute((const void*)ltrx_gemm_nt64_kernel<TAIL_, NT_, IMG_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                        (int)(2 * sizeof(SmemNT<64, NT_>))) != hipSuccess)
-      if (LTRX_NT64_ATTR(false, 2, false) || LTRX_NT64_ATTR(false, 2, true) || LTRX_NT64_ATTR(true, 2, false) || LTRX_NT64_ATTR(true, 2, true) ||
-          LTRX_NT64_ATTR(false, 1, false) || LTRX_NT64_ATTR(false, 1, true) || LTRX_NT64_ATTR(true, 1, false) || LTRX_NT64_ATTR(true, 1, true))
+      if (LTRX_NT64_ATTR(false, 2, 0) || LTRX_NT64_ATTR(false, 2, 1) || LTRX_NT64_ATTR(false, 2, 2) || LTRX_NT64_ATTR(true, 2, 0) ||
+          LTRX_NT64_ATTR(true, 2, 1) || LTRX_NT64_ATTR(true, 2, 2) || LTRX_NT64_ATTR(false, 1, 0) || LTRX_NT64_ATTR(false, 1, 1) ||
+          LTRX_NT64_ATTR(false, 1, 2) || LTRX_NT64_ATTR(true, 1, 0) || LTRX_NT64_ATTR(true, 1, 1) || LTRX_NT64_ATTR(true, 1, 2))
         return LTRX_EHIP;
 #undef LTRX_NT64_ATTR
       return LTRX_OK;
@@ -1024,13 +1103,13 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, co
     const float* Bk = bimg ? reinterpret_cast<const float*>(B_image) : B;
 #define LTRX_NT64_(TAIL_, NT_, IMG_)                                                                                        \
   hipLaunchKernelGGL((ltrx_gemm_nt64_kernel<TAIL_, NT_, IMG_>), grid, dim3(512), 2 * sizeof(SmemNT<64, NT_>), s, A, lda, Bk, ldb, C, \
-                     ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step)
+                     ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step, cimg)
 #define LTRX_NT64(TAIL_)                                                                                                    \
   do {                                                                                                                      \
     if (plain) {                                                                                                            \
-      if (bimg) LTRX_NT64_(TAIL_, 1, true); else LTRX_NT64_(TAIL_, 1, false);                                               \
+      if (aimg) LTRX_NT64_(TAIL_, 1, 2); else if (bimg) LTRX_NT64_(TAIL_, 1, 1); else LTRX_NT64_(TAIL_, 1, 0);              \
     } else {                                                                                                                \
-      if (bimg) LTRX_NT64_(TAIL_, 2, true); else LTRX_NT64_(TAIL_, 2, false);                                               \
+      if (aimg) LTRX_NT64_(TAIL_, 2, 2); else if (bimg) LTRX_NT64_(TAIL_, 2, 1); else LTRX_NT64_(TAIL_, 2, 0);              \
     }                                                                                                                       \
   } while (0)
     if (M % 64) LTRX_NT64(true); else LTRX_NT64(false);
@@ -1044,9 +1123,11 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, co
     static std::atomic<uint64_t> attr_done{0};
     const int arc = ltrx_once_per_device(attr_done, []() {
 #define LTRX_NT256_ATTR(TAIL_, BM_, NT_)                                                                                     \
-  (hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<TAIL_, BM_, NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+  (hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<TAIL_, BM_, NT_, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                        (int)(2 * sizeof(SmemNT<BM_, NT_>))) != hipSuccess ||                                               \
-   hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<TAIL_, BM_, NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+   hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<TAIL_, BM_, NT_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                       (int)(2 * sizeof(SmemNT<BM_, NT_>))) != hipSuccess ||                                               \
+   hipFuncSetAttribute((const void*)ltrx_gemm_nt256_kernel<TAIL_, BM_, NT_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                        (int)(2 * sizeof(SmemNT<BM_, NT_>))) != hipSuccess)
       if (LTRX_NT256_ATTR(false, 256, 2) || LTRX_NT256_ATTR(true, 256, 2) || LTRX_NT256_ATTR(false, 128, 2) ||
           LTRX_NT256_ATTR(true, 128, 2) || LTRX_NT256_ATTR(false, 256, 1) || LTRX_NT256_ATTR(true, 256, 1) ||
@@ -1064,13 +1145,13 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, co
     const float* Bk = bimg ? reinterpret_cast<const float*>(B_image) : B;
 #define LTRX_NT256_(TAIL_, BM_, NT_, IMG_)                                                                                   \
   hipLaunchKernelGGL((ltrx_gemm_nt256_kernel<TAIL_, BM_, NT_, IMG_>), grid, dim3(512), 2 * sizeof(SmemNT<BM_, NT_>), s, A, lda, Bk, \
-                     ldb, C, ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step)
+                     ldb, C, ldc, M, N, K, bias, act, aux, ldaux, tiles_n, drop, drop_step, cimg)
 #define LTRX_NT256(TAIL_, BM_)                                                                                               \
   do {                                                                                                                       \
     if (plain) {                                                                                                             \
-      if (bimg) LTRX_NT256_(TAIL_, BM_, 1, true); else LTRX_NT256_(TAIL_, BM_, 1, false);                                    \
+      if (aimg) LTRX_NT256_(TAIL_, BM_, 1, 2); else if (bimg) LTRX_NT256_(TAIL_, BM_, 1, 1); else LTRX_NT256_(TAIL_, BM_, 1, 0); \
     } else {                                                                                                                 \
-      if (bimg) LTRX_NT256_(TAIL_, BM_, 2, true); else LTRX_NT256_(TAIL_, BM_, 2, false);                                    \
+      if (aimg) LTRX_NT256_(TAIL_, BM_, 2, 2); else if (bimg) LTRX_NT256_(TAIL_, BM_, 2, 1); else LTRX_NT256_(TAIL_, BM_, 2, 0); \
     }                                                                                                                        \
   } while (0)
     if (v == 6) {
@@ -1083,6 +1164,7 @@ extern "C" int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, co
     LTRX_LAUNCH_CHECK();
     return LTRX_OK;
   }
+  if (operand_flags) return LTRX_EUNSUPPORTED;        // (ltrx_gemm_nt_image_ok said so: no image form in the small-tile kernels)
   if (strict) {
     launch_nt<3, 128, 32>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, drop, drop_step, s);
   } else if (plain) {
@@ -1314,9 +1396,22 @@ extern "C" size_t ltrx_gemm_tn_group_workspace_bytes(int nprob, int M, const int
   return grouped > single ? grouped : single;
 }
 
+extern "C" int ltrx_gemm_tn_group_img(int nprob, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
+                                      float* const* bias_out, int M, const int* NP, const int* KP, int strict, void* ws, size_t ws_bytes,
+                                      const float** slabs_out, const float** bias_slabs_out, int* splits_out, const int* b_is_image,
+                                      ltrx_stream_t stream);
+
 extern "C" int ltrx_gemm_tn_group(int nprob, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
                                   float* const* bias_out, int M, const int* NP, const int* KP, int strict, void* ws, size_t ws_bytes,
                                   const float** slabs_out, const float** bias_slabs_out, int* splits_out, ltrx_stream_t stream) {
+  return ltrx_gemm_tn_group_img(nprob, A, lda, B, ldb, C, bias_out, M, NP, KP, strict, ws, ws_bytes, slabs_out, bias_slabs_out, splits_out,
+                                nullptr, stream);
+}
+
+extern "C" int ltrx_gemm_tn_group_img(int nprob, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
+                                      float* const* bias_out, int M, const int* NP, const int* KP, int strict, void* ws, size_t ws_bytes,
+                                      const float** slabs_out, const float** bias_slabs_out, int* splits_out, const int* b_is_image,
+                                      ltrx_stream_t stream) {
   const bool defer = slabs_out && bias_slabs_out && splits_out;   // the caller sums the slabs (ltrx_reduce_group)
   if ((slabs_out || bias_slabs_out || splits_out) && !defer) return LTRX_EINVAL;
   if (defer) *splits_out = 0;
@@ -1333,6 +1428,8 @@ extern "C" int ltrx_gemm_tn_group(int nprob, const float* const* A, const int* l
     if (need > ws_bytes) grouped = false;
   }
   if (!grouped) {                                     // shapes outside the large-tile kernel: one call per problem
+    for (int p = 0; p < nprob; ++p)
+      if (b_is_image && b_is_image[p]) return LTRX_EUNSUPPORTED;       // (operand images exist in the grouped large-tile kernel only)
     for (int p = 0; p < nprob; ++p) {
       if (ltrx_gemm_tn_workspace_bytes(M, NP[p], KP[p]) > ws_bytes) return LTRX_EINVAL;
       const int rc = ltrx_gemm_tn(A[p], lda[p], B[p], ldb[p], C[p], bias_out[p], M, NP[p], KP[p], strict, 0, ws, stream);
@@ -1363,6 +1460,8 @@ extern "C" int ltrx_gemm_tn_group(int nprob, const float* const* A, const int* l
     g.NP[p] = NP[p];
     g.KP[p] = KP[p];
     g.kv[p] = KP[p];
+    g.bimg[p] = (b_is_image && b_is_image[p]) ? 1 : 0;
+    if (g.bimg[p] && (((uintptr_t)B[p]) & 15)) return LTRX_EUNSUPPORTED;
     g.tiles_k[p] = KP[p] / 256;
     g.tile_start[p] = t0;
     t0 += (NP[p] / 256) * (KP[p] / 256);

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) ltrx_layernorm_fwd_vec_kernel(const float
                                                                      int rows, float eps, float* __restrict__ xsum_out,
                                                                      float* __restrict__ y, float* __restrict__ mean_out,
                                                                      float* __restrict__ rstd_out, DropSpec drop,
-                                                                     const uint32_t* __restrict__ drop_step) {
+                                                                     const uint32_t* __restrict__ drop_step, int yimg) {
   constexpr int D = 256 * NV;
   const int lane = lane_id(), wpb = blockDim.x >> 6;
   if (drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
@@ -172,7 +172,9 @@ __global__ void __launch_bounds__(256) ltrx_layernorm_fwd_vec_kernel(const float
       o.y = av[t].y * ((v[t].y - mean) * r) + bv[t].y;
       o.z = av[t].z * ((v[t].z - mean) * r) + bv[t].z;
       o.w = av[t].w * ((v[t].w - mean) * r) + bv[t].w;
-      reinterpret_cast<float4*>(y + (size_t)row * D)[lane + 64 * t] = o;
+      // yimg: the normalised row only ever feeds GEMMs (the q/k/v or feed-forward projection and their weight gradients): written
+      // as their pre-split operand image -- same bytes, same address, no split left in the consumers' loops
+      reinterpret_cast<float4*>(y + (size_t)row * D)[lane + 64 * t] = yimg ? ltrx_split_image4(o) : o;
     }
     if (lane == 0) {
       mean_out[row] = mean;
@@ -306,9 +308,9 @@ static bool ln_vec_ok(int D, const void* p0, const void* p1, const void* p2) {
   return D % 256 == 0 && D <= 1024 && (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15) == 0;
 }
 
-extern "C" int ltrx_layernorm_fwd(const float* x, const float* res, const float* a, const float* b, int rows, int D,
-                                  float eps, float* xsum_out, float* y_out, float* mean_out, float* rstd_out,
-                                  float res_drop_p, uint32_t drop_seed, const uint32_t* drop_step, ltrx_stream_t stream) {
+static int ln_fwd_launch(const float* x, const float* res, const float* a, const float* b, int rows, int D,
+                         float eps, float* xsum_out, float* y_out, float* mean_out, float* rstd_out,
+                         float res_drop_p, uint32_t drop_seed, const uint32_t* drop_step, int y_as_image, ltrx_stream_t stream) {
   if (!x || !a || !b || !y_out || !mean_out || !rstd_out || rows <= 0 || D < 2) return LTRX_EINVAL;
   if (res && !xsum_out) return LTRX_EINVAL;
   if (!(res_drop_p >= 0.f) || res_drop_p >= 1.f) return LTRX_EINVAL;
@@ -316,7 +318,7 @@ extern "C" int ltrx_layernorm_fwd(const float* x, const float* res, const float*
   hipStream_t s = (hipStream_t)stream;
   if (ln_vec_ok(D, x, y_out, res) && ln_vec_ok(D, a, b, xsum_out)) {
     const dim3 g(ln_fwd_vec_grid(rows));
-#define LTRX_LN_FWD(NV) hipLaunchKernelGGL(ltrx_layernorm_fwd_vec_kernel<NV>, g, dim3(256), 0, s, x, res, a, b, rows, eps, xsum_out, y_out, mean_out, rstd_out, drop, drop_step)
+#define LTRX_LN_FWD(NV) hipLaunchKernelGGL(ltrx_layernorm_fwd_vec_kernel<NV>, g, dim3(256), 0, s, x, res, a, b, rows, eps, xsum_out, y_out, mean_out, rstd_out, drop, drop_step, y_as_image)
     switch (D / 256) {
       case 1: LTRX_LN_FWD(1); break;
       case 2: LTRX_LN_FWD(2); break;
@@ -325,11 +327,27 @@ extern "C" int ltrx_layernorm_fwd(const float* x, const float* res, const float*
     }
 #undef LTRX_LN_FWD
   } else {
+    if (y_as_image) return LTRX_EUNSUPPORTED;       // (the image form exists in the row-in-registers kernel: D = 256, 512, 768, 1024)
     hipLaunchKernelGGL(ltrx_layernorm_fwd_kernel, dim3(ln_grid(rows)), dim3(256), 0, s, x, res, a, b, rows, D, eps, xsum_out,
                        y_out, mean_out, rstd_out, drop, drop_step);
   }
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
+}
+
+extern "C" int ltrx_layernorm_fwd(const float* x, const float* res, const float* a, const float* b, int rows, int D,
+                                  float eps, float* xsum_out, float* y_out, float* mean_out, float* rstd_out,
+                                  float res_drop_p, uint32_t drop_seed, const uint32_t* drop_step, ltrx_stream_t stream) {
+  return ln_fwd_launch(x, res, a, b, rows, D, eps, xsum_out, y_out, mean_out, rstd_out, res_drop_p, drop_seed, drop_step, 0, stream);
+}
+
+// the same with y written as a pre-split operand IMAGE (include/ltrx.h: ltrx_split_image's layout) -- for a normalised activation
+// that only feeds GEMMs (ltrx_gemm_nt_img with LTRX_GEMM_A_IS_IMAGE, ltrx_gemm_tn_group_img with b_is_image)
+extern "C" int ltrx_layernorm_fwd_image(const float* x, const float* res, const float* a, const float* b, int rows, int D,
+                                        float eps, float* xsum_out, void* y_image_out, float* mean_out, float* rstd_out,
+                                        float res_drop_p, uint32_t drop_seed, const uint32_t* drop_step, ltrx_stream_t stream) {
+  return ln_fwd_launch(x, res, a, b, rows, D, eps, xsum_out, reinterpret_cast<float*>(y_image_out), mean_out, rstd_out, res_drop_p,
+                       drop_seed, drop_step, 1, stream);
 }
 
 extern "C" size_t ltrx_layernorm_bwd_workspace_bytes(int rows, int D) {

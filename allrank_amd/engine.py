@@ -86,7 +86,8 @@ class FusedTrainer(object):
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
                  optimizer="Adam", weight_decay=0.0, momentum=0.0, nesterov=False,
                  use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None, compact=False,
-                 weight_images=True, fc_step=True, group_wgrad=True, relu_bits=True, pad_input=True, overlap_wgrad=False):
+                 weight_images=True, fc_step=True, group_wgrad=True, relu_bits=True, pad_input=True, overlap_wgrad=False,
+                 act_images=False):
         """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
         products), "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs), or "bf16" -- the THROUGHPUT mode: one bf16
         product per contraction in the dense projections AND in attention (fp32 storage, accumulation, LayerNorm, softmax,
@@ -115,6 +116,14 @@ class FusedTrainer(object):
         element (ltrx_gemm_nt acts 4 / 5) instead of being re-read from the saved fp32 activation; same results bit for bit.
         pad_input=True: the static input buffer keeps the features in rows padded to 256 floats so that the first FC layer (F = 136 is
         no multiple of the GEMM's 32-column step) runs the large-tile forward and weight-gradient kernels; False = dense rows (A/B).
+        act_images=True (round 5, opt-in): the activations that only ever feed GEMMs -- the LayerNorm outputs in front of the q/k/v and
+        feed-forward projections and the post-ReLU feed-forward activation -- are written by their producers (LayerNorm forward, the
+        FFN-1 GEMM's epilogue) as pre-split bf16 hi / lo operand IMAGES (same bytes, same buffers, no fp32 copy) and staged by the
+        forward GEMMs (operand A) and the grouped weight-gradient GEMM (operand B) with plain copies: no split left in those loops.
+        Applies per step where every consumer runs a large-tile kernel and the one-bit ReLU mask is active (``images_active``);
+        bit-identical results.  MEASURED (profiles/r05_act_images_ab.md): the consumers execute 6-28 % fewer VALU instructions and
+        take the same number of cycles -- the three-product GEMMs are bound by the matrix pipe at the chip's power limit, not by
+        VALU issue -- while the producers pay for the split: -1 % on the step.  Hence off by default.
         overlap_wgrad=True: fork / join inside the step -- the grouped weight-gradient launch of encoder layer i and its reducing launch
         run on a SECOND stream (a parallel branch of the captured hipGraph) beside the backward chain of layer i-1 (LayerNorm backward,
         input-gradient GEMMs, attention backward), which does not depend on them (loss.backward() at train_utils.py:23 imposes no
@@ -135,6 +144,9 @@ class FusedTrainer(object):
         self.gemm = gemm
         self.weight_images = bool(weight_images)
         self.group_wgrad = bool(group_wgrad) and gemm != "split_bf16_strict"     # (the strict arithmetic has no large-tile kernel)
+        self.act_images = bool(act_images)
+        self.images_active = False                            # this step's activations travel as operand images (_images_ok)
+        self._img_cache = {}
         self.overlap_wgrad = bool(overlap_wgrad)              # (resolved below once the model family is known)
         self._side = None                                     # the second stream of the fork / join (overlap_wgrad)
         self._cur_set = 0
@@ -521,12 +533,13 @@ class FusedTrainer(object):
         x = ((x ^ (x >> 15)) * 0x846CA68B) & 0xFFFFFFFF
         return x ^ (x >> 16)
 
-    def _ln_fwd(self, x, res, a, b, xsum, y, mean, rstd, p=0.0, seed=0):
-        """y = LN(x + drop_p(res)); xsum = x + drop_p(res)"""
+    def _ln_fwd(self, x, res, a, b, xsum, y, mean, rstd, p=0.0, seed=0, image=False):
+        """y = LN(x + drop_p(res)); xsum = x + drop_p(res).  ``image``: y is written as a pre-split operand image (act_images)"""
         P = self.LB.ptr
-        self.LB.check(self.lib.ltrx_layernorm_fwd(P(x), P(res), P(a), P(b), self.rows, self.d, float(self.ln_eps), P(xsum), P(y),
-                                                  P(mean), P(rstd), float(p), seed, P(self.drop_step), self._st()),
-                      "layernorm_fwd")
+        fn = self.lib.ltrx_layernorm_fwd_image if image else self.lib.ltrx_layernorm_fwd
+        self.LB.check(fn(P(x), P(res), P(a), P(b), self.rows, self.d, float(self.ln_eps), P(xsum), P(y),
+                         P(mean), P(rstd), float(p), seed, P(self.drop_step), self._st()),
+                      "layernorm_fwd_image" if image else "layernorm_fwd")
 
     def _drop_apply(self, src, dst, p, seed):
         """dst = src * keep-mask/(1-p) of the site (the backward of a dropped branch)"""
@@ -585,6 +598,53 @@ class FusedTrainer(object):
     def _relu_bwd(self, dr, r, p=0.0):
         """dr *= (r > 0) / (1 - p): backward of dropout(relu(z)) given the stored post-dropout activation r"""
         self.LB.check(self.lib.ltrx_relu_bwd(self.LB.ptr(dr), self.LB.ptr(r), self.rows * dr.shape[1], 1.0 / (1.0 - p), self._st()), "relu_bwd")
+
+    def _images_ok(self):
+        """may THIS step (row count self.rows) hand its GEMM-only activations over as operand images?  Every consumer must run a
+        kernel that stages images -- the large-tile forward GEMMs (ltrx_gemm_nt_image_ok) and the grouped weight-gradient GEMM -- and
+        nobody may need their fp32 values: the ReLU backward reads the one-bit mask (``_relu_bits``), LayerNorm's row kernel writes
+        the image (d_model 256 ... 1024)."""
+        key = (self.rows, self.ws_tn.numel() if hasattr(self, "ws_tn") else 0)
+        hit = self._img_cache.get(key)
+        if hit is not None:
+            return hit
+        ok = bool(self.act_images and self.N and self.weight_images and self.group_wgrad and self.gemm in ("split_bf16", "bf16"))
+        if ok:
+            d, dff, rows, lib = self.d, self.dff, self.rows, self.lib
+            ok = d % 256 == 0 and d <= 1024 and all(self._relu_bits(st) is not None for st in self.layers)
+            ok = ok and all(lib.ltrx_gemm_nt_image_ok(rows, n_, k_) for n_, k_ in ((3 * d, d), (dff, d), (d, dff)))
+            if ok:
+                w2, w1, wo, wq = (d, dff), (dff, d), (d, d), (3 * d, d)
+                comps = [[w2, w1, wo, wq]]
+                if not self.overlap_wgrad and any(st["p_s0"] and st["p_s1"] for st in self.layers):
+                    comps = [[w2, w1], [wo, wq]]
+                for comp in comps:
+                    npa = (ctypes.c_int * len(comp))(*[c[0] for c in comp])
+                    kpa = (ctypes.c_int * len(comp))(*[c[1] for c in comp])
+                    ok = ok and (lib.ltrx_debug_tn_group_map(len(comp), rows, npa, kpa, self._wg_probe, self._wg_probe) > 0
+                                 and lib.ltrx_gemm_tn_group_workspace_bytes(len(comp), rows, npa, kpa) <= self.ws_tn.numel())
+        self._img_cache[key] = bool(ok)
+        return bool(ok)
+
+    @staticmethod
+    def decode_image(t):
+        """fp32 values (hi + lo: the value to 2^-17 relative, sign and zero exact) of a buffer that holds an operand image"""
+        g = t.contiguous().view(torch.int32).view(-1, 4)
+
+        def lo16(x_):
+            return (x_ << 16).view(torch.float32)
+
+        def hi16(x_):
+            return (x_ & -65536).view(torch.float32)
+        vals = torch.stack([lo16(g[:, 0]) + lo16(g[:, 2]), hi16(g[:, 0]) + hi16(g[:, 2]),
+                            lo16(g[:, 1]) + lo16(g[:, 3]), hi16(g[:, 1]) + hi16(g[:, 3])], 1)
+        return vals.view(t.shape)
+
+    def saved_activation(self, layer, key):
+        """the saved activation ``key`` ("r", "xn0", "xn1", ...) of encoder layer ``layer`` of the LAST step as fp32 values -- decoded
+        when the step handed it over as an operand image (tests, diagnostics)"""
+        t = self.layers[layer][key]
+        return self.decode_image(t) if (self.images_active and key in ("r", "xn0", "xn1")) else t
 
     def _refresh_transposes(self):
         if self.n_out > 1:                                        # W_out^T [d, d_output] zero-padded to a multiple of 4 columns
@@ -672,7 +732,7 @@ class FusedTrainer(object):
         need = self.lib.ltrx_gemm_nt_relu_bits_bytes(self.rows, self.dff, self.d)
         return buf if 0 < need <= buf.numel() else None
 
-    def _lin_fwd(self, x, w, b, out, act=0, p=0.0, seed=0, res=None, bits=None):
+    def _lin_fwd(self, x, w, b, out, act=0, p=0.0, seed=0, res=None, bits=None, a_img=False, c_img=False):
         """out = drop_p(act(x w^T + b)) [+ res]   (nn.Linear forward, act 1 = ReLU; dropout in the epilogue; ``res`` = the
         residual stream of the SublayerConnection this projection closes, transformer.py:98-106: added in the epilogue, so the
         sum is written once by the GEMM instead of being re-read and re-written by the LayerNorm that follows)"""
@@ -687,14 +747,16 @@ class FusedTrainer(object):
                 out[:n].add_(res[:n])
             return
         P = self.LB.ptr
+        # operand images of ACTIVATIONS (act_images): x holds an image (a_img) / out is to be written as one (c_img)
+        fl = (1 if a_img else 0) | (2 if c_img else 0)
         if bits is not None and act == 1:                         # ReLU + its one-bit mask for the backward (act 4)
-            self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), self._img(w), P(out), out.stride(0), self.rows,
-                                                w.shape[0], x.shape[1], P(b), 4, P(bits), 0, float(p), seed, P(self.drop_step), self._prec, 0,
-                                                self._st()), "gemm_nt(fwd, relu bits)")
+            self.LB.check(self.lib.ltrx_gemm_nt_img(P(x), x.stride(0), P(w), w.stride(0), self._img(w), P(out), out.stride(0), self.rows,
+                                                    w.shape[0], x.shape[1], P(b), 4, P(bits), 0, float(p), seed, P(self.drop_step), self._prec, 0,
+                                                    fl, self._st()), "gemm_nt(fwd, relu bits)")
             return
-        self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), self._img(w), P(out), out.stride(0), self.rows, w.shape[0],
-                                            x.shape[1], P(b), 3 if res is not None else act, P(res), res.stride(0) if res is not None else 0,
-                                            float(p), seed, P(self.drop_step), self._prec, 0, self._st()), "gemm_nt(fwd)")
+        self.LB.check(self.lib.ltrx_gemm_nt_img(P(x), x.stride(0), P(w), w.stride(0), self._img(w), P(out), out.stride(0), self.rows, w.shape[0],
+                                                x.shape[1], P(b), 3 if res is not None else act, P(res), res.stride(0) if res is not None else 0,
+                                                float(p), seed, P(self.drop_step), self._prec, 0, fl, self._st()), "gemm_nt(fwd)")
 
     def _lin_dgrad(self, dy, w, wT, out, relu_of=None, p=0.0, seed=0, bits=None):
         """out = dy w   (input gradient of nn.Linear); wT = w^T contiguous.  With ``relu_of`` (the saved post-ReLU,
@@ -718,7 +780,7 @@ class FusedTrainer(object):
                                             relu_of.stride(0) if relu_of is not None else 0, float(p), seed, P(self.drop_step),
                                             self._prec, 0, self._st()), "gemm_nt(dgrad)")
 
-    def _lin_wgrad(self, dy, x, gw, gb, defer=False):
+    def _lin_wgrad(self, dy, x, gw, gb, defer=False, x_img=False):
         """gw = dy^T x, gb = column sums of dy   (weight and bias gradients of nn.Linear).  ``defer``: an encoder-layer projection
         -- queued for the layer's one grouped launch (_wgrad_flush); dy and x must stay untouched until then."""
         if self.gemm == "hipblaslt":
@@ -726,8 +788,10 @@ class FusedTrainer(object):
             self._colsum(dy, gb)
             return
         if defer and self.group_wgrad:
-            self._wg_pending.append((dy, x, gw, gb))
+            self._wg_pending.append((dy, x, gw, gb, bool(x_img)))
             return
+        if x_img:
+            raise RuntimeError("FusedTrainer: an activation image reached a weight gradient outside the grouped launch")
         P = self.LB.ptr
         # (tile 9: x is the padded input buffer -- its rows are readable up to the 256-column tile, see include/ltrx.h)
         padded = self._x_pad and x.data_ptr() == self.x_in_buf.data_ptr() and x.stride(0) == self.x_in_buf.stride(0)
@@ -764,8 +828,9 @@ class FusedTrainer(object):
                 and self.lib.ltrx_gemm_tn_group_workspace_bytes(n, self.rows, NP, KP) <= self.ws_tn.numel())
         self.wgrad_group_log.append((n, bool(took)))
         del self.wgrad_group_log[:-16]
-        self.LB.check(self.lib.ltrx_gemm_tn_group(n, A, lda, Bm, ldb, C, bo, self.rows, NP, KP, self._prec, self.LB.ptr(self.ws_tn),
-                                                  self.ws_tn.numel(), *outs, self._st()), "gemm_tn_group(wgrad)")
+        bimg = ci(*[1 if t[4] else 0 for t in q])                 # operand B (the layer input) of a problem is an activation image
+        self.LB.check(self.lib.ltrx_gemm_tn_group_img(n, A, lda, Bm, ldb, C, bo, self.rows, NP, KP, self._prec, self.LB.ptr(self.ws_tn),
+                                                      self.ws_tn.numel(), *outs, bimg, self._st()), "gemm_tn_group(wgrad)")
         if defer_reduce and sp.value > 0:
             for i, t in enumerate(q):
                 nw = t[0].shape[1] * t[1].shape[1]
@@ -821,12 +886,13 @@ class FusedTrainer(object):
                                               P(self.x_pe), self._st()), "posenc_fwd")
             h = self.x_pe
         x = h                                                     # residual stream
+        img = self.images_active = self._images_ok()
         for i, st in enumerate(self.layers):
             lay = st["mod"]
             n0, n1 = lay.sublayer[0].norm, lay.sublayer[1].norm
-            self._ln_fwd(x, None, W(n0.a_2), W(n0.b_2), None, st["xn0"], st["mean0"], st["rstd0"])
+            self._ln_fwd(x, None, W(n0.a_2), W(n0.b_2), None, st["xn0"], st["mean0"], st["rstd0"], image=img)
             st["xin"] = x
-            self._lin_fwd(st["xn0"], st["wqkv"], st["bqkv"], st["qkv"])
+            self._lin_fwd(st["xn0"], st["wqkv"], st["bqkv"], st["qkv"], a_img=img)
             qkv = st["qkv"]
             self.LB.check(lib.ltrx_mha_fwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(kpm), B, L, self.h,
                                            d // self.h, 3 * d, P(st["o"]), d, P(st["lse"]), dp(st["p_att"]), st["s_att"],
@@ -834,19 +900,19 @@ class FusedTrainer(object):
             lo = lay.self_attn.linears[3]
             # x1 = x + dropout(attention branch): the residual sum is the out-projection's epilogue (act 3)
             self._lin_fwd(st["o"], W(lo.weight), W(lo.bias), st["x1"], 0, dp(st["p_s0"]), st["s_s0"], res=x)
-            self._ln_fwd(st["x1"], None, W(n1.a_2), W(n1.b_2), None, st["xn1"], st["mean1"], st["rstd1"])
+            self._ln_fwd(st["x1"], None, W(n1.a_2), W(n1.b_2), None, st["xn1"], st["mean1"], st["rstd1"], image=img)
             ff = lay.feed_forward
             if self.probe is not None and train:                  # bench.py: HIP events around the roofline kernel, in the step
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
             self._lin_fwd(st["xn1"], W(ff.w_1.weight), W(ff.w_1.bias), st["r"], 1, dp(st["p_ff"]), st["s_ff"],
-                          bits=self._relu_bits(st) if train else None)
+                          bits=self._relu_bits(st) if train else None, a_img=img, c_img=img)
             if self.probe is not None and train:
                 ev1.record()
                 self.probe.append((ev0, ev1))
             # x(next layer) = x1 + dropout(feed-forward branch), again in the epilogue of the projection that closes the sublayer
             nxt = self.layers[i + 1]["xsum0"] if i + 1 < len(self.layers) else self.xsum_f
-            self._lin_fwd(st["r"], W(ff.w_2.weight), W(ff.w_2.bias), nxt, 0, dp(st["p_s1"]), st["s_s1"], res=st["x1"])
+            self._lin_fwd(st["r"], W(ff.w_2.weight), W(ff.w_2.bias), nxt, 0, dp(st["p_s1"]), st["s_s1"], res=st["x1"], a_img=img)
             x = nxt
         out = self.model.output_layer
         if self.N:
@@ -903,6 +969,7 @@ class FusedTrainer(object):
             self._lin_wgrad(self.dz_pad[:, :no], feat, G(out.w_1.weight), G(out.w_1.bias))
             self._lin_dgrad(self.dz_pad, W(out.w_1.weight), self.woutT_pad, ga)
         ov = self.overlap_wgrad
+        img = self.images_active
         if self.N:
             nf = self.enc.norm
             self._cur_set = (self.N - 1) % 2 if ov else 0           # (the final norm's partials join the last layer's reducing launch)
@@ -925,10 +992,10 @@ class FusedTrainer(object):
                 db = self._branch_grad(ds, st["p_s1"], st["s_s1"], self.d_br_set[sset][0] if ov else None)
                 # (the four weight gradients of the layer are queued and run as one grouped launch before the first kernel that
                 #  overwrites one of their operands: the LN0 backward below, or the second use of the dropout buffer d_br)
-                self._lin_wgrad(db, st["r"], G(ff.w_2.weight), G(ff.w_2.bias), defer=True)
+                self._lin_wgrad(db, st["r"], G(ff.w_2.weight), G(ff.w_2.bias), defer=True, x_img=img)
                 self._lin_dgrad(db, W(ff.w_2.weight), self._wT.get(id(ff.w_2.weight)), d_r, relu_of=st["r"], p=st["p_ff"],
                                 bits=self._relu_bits(st))
-                self._lin_wgrad(d_r, st["xn1"], G(ff.w_1.weight), G(ff.w_1.bias), defer=True)
+                self._lin_wgrad(d_r, st["xn1"], G(ff.w_1.weight), G(ff.w_1.bias), defer=True, x_img=img)
                 self._lin_dgrad(d_r, W(ff.w_1.weight), self._wT.get(id(ff.w_1.weight)), self.tmp_d)
                 self._ln_bwd(self.tmp_d, st["x1"], W(n1.a_2), st["mean1"], st["rstd1"], ds, mid, G(n1.a_2), G(n1.b_2))
                 ds = mid                                           # ds = d loss / d x1
@@ -947,7 +1014,7 @@ class FusedTrainer(object):
                               "mha_bwd")
                 if self.compact and M > self.n_valid:              # alignment rows belong to no slate: no gradient
                     dq[self.n_valid:M].zero_()
-                self._lin_wgrad(dq, st["xn0"], st["gwqkv"], st["gbqkv"], defer=True)
+                self._lin_wgrad(dq, st["xn0"], st["gwqkv"], st["gbqkv"], defer=True, x_img=img)
                 self._lin_dgrad(dq, st["wqkv"], st.get("wqkvT"), self.tmp_d)
                 if ov:
                     # join the branch of layer i+1 (its weight gradients and reductions are complete: its bucket may go, and its

@@ -191,6 +191,11 @@ int ltrx_mrr_at(const float* y_pred, const float* y_true, int B, int L, const in
 int ltrx_layernorm_fwd(const float* x, const float* res, const float* a, const float* b, int rows, int D, float eps,
                        float* xsum_out, float* y_out, float* mean_out, float* rstd_out, float res_drop_p, uint32_t drop_seed,
                        const uint32_t* drop_step, ltrx_stream_t stream);
+/* the same with y written as a pre-split operand image (ltrx_split_image's layout; for an output that only feeds GEMMs, see
+ * ltrx_gemm_nt_img).  D must be 256, 512, 768 or 1024 and the buffers 16-byte aligned (LTRX_EUNSUPPORTED otherwise). */
+int ltrx_layernorm_fwd_image(const float* x, const float* res, const float* a, const float* b, int rows, int D, float eps,
+                             float* xsum_out, void* y_image_out, float* mean_out, float* rstd_out, float res_drop_p, uint32_t drop_seed,
+                             const uint32_t* drop_step, ltrx_stream_t stream);
 /* dx = LN backward of dy (+ dres_in if given: the gradient arriving through the residual branch);
  * da_out/db_out (fp32, length D) are written via a deterministic two-stage reduction through ws. */
 size_t ltrx_layernorm_bwd_workspace_bytes(int rows, int D);
@@ -335,6 +340,22 @@ int ltrx_gemm_nt(const float* A, int lda, const float* B, int ldb, const void* B
  * is for: nn.Linear weights (model.py:35-44, transformer.py:193-227) change once per optimizer step but are staged by every tile of
  * every GEMM of the step.  ltrx_split_image: n floats (multiple of 4), src and dst 16-byte aligned. */
 int ltrx_split_image(const float* src, void* dst, size_t n, ltrx_stream_t stream);
+/* Round 5: ACTIVATIONS as operand images.  An activation that only ever feeds GEMMs -- the LayerNorm output in front of the q/k/v and
+ * feed-forward projections (transformer.py:105, 193-196, 227), the post-ReLU feed-forward activation (transformer.py:227) -- is
+ * written by its producer directly in ltrx_split_image's layout (same bytes, same addresses, no fp32 copy), and its consumers stage it
+ * with plain copies: ltrx_gemm_nt_img = ltrx_gemm_nt + operand_flags (LTRX_GEMM_A_IS_IMAGE: A holds an image -- requires B_image;
+ * LTRX_GEMM_C_AS_IMAGE: C is written as an image, epilogue applied first); ltrx_layernorm_fwd_image (below); ltrx_gemm_tn_group_img
+ * (b_is_image[p]: operand B of problem p is an image).  Results are bit-identical to the fp32 hand-over (the split is the same
+ * expression, evaluated once by the producer instead of once per consuming tile).  Images exist in the large-tile kernel families
+ * only: ltrx_gemm_nt_image_ok(M, N, K) says whether ltrx_gemm_nt_img will take them for a shape (ask for every consumer BEFORE producing
+ * an image; a call that cannot returns LTRX_EUNSUPPORTED); ltrx_gemm_tn_group_img takes them whenever the grouped kernel runs
+ * (ltrx_debug_tn_group_map(...) > 0 and the workspace fits). */
+#define LTRX_GEMM_A_IS_IMAGE 1
+#define LTRX_GEMM_C_AS_IMAGE 2
+int ltrx_gemm_nt_image_ok(int M, int N, int K);
+int ltrx_gemm_nt_img(const float* A, int lda, const float* B, int ldb, const void* B_image, float* C, int ldc, int M, int N, int K,
+                     const float* bias, int act, const float* aux, int ldaux, float drop_p, uint32_t drop_seed, const uint32_t* drop_step,
+                     int strict, int tile, int operand_flags, ltrx_stream_t stream);
 /* The engine's whole per-step weight refresh in one launch: the image of the flat parameter buffer (src_base[0..nflat) -> src_image,
  * as ltrx_split_image) and, for the n matrices of desc / tile_start (as ltrx_transpose_batch), the transposed fp32 copy in dst_base
  * AND its image in dst_image (same offsets).  Requires nflat % 4 == 0, 16-byte aligned buffers, 4-float aligned dst offsets and
@@ -388,6 +409,12 @@ size_t ltrx_gemm_tn_group_workspace_bytes(int nprob, int M, const int* NP, const
 int ltrx_gemm_tn_group(int nprob, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
                        float* const* bias_out, int M, const int* NP, const int* KP, int strict, void* ws, size_t ws_bytes,
                        const float** slabs_out, const float** bias_slabs_out, int* splits_out, ltrx_stream_t stream);
+/* the same with b_is_image[p] != 0 marking problems whose operand B (the layer INPUT x of dW = dY^T x) is a pre-split image (see
+ * ltrx_gemm_nt_img); NULL = none.  LTRX_EUNSUPPORTED if an image is given and the grouped kernel cannot run the call. */
+int ltrx_gemm_tn_group_img(int nprob, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
+                           float* const* bias_out, int M, const int* NP, const int* KP, int strict, void* ws, size_t ws_bytes,
+                           const float** slabs_out, const float** bias_slabs_out, int* splits_out, const int* b_is_image,
+                           ltrx_stream_t stream);
 /* n <= LTRX_REDUCE_GROUP_MAX independent reductions in one launch: dst[i][c] = sum_{s < splits[i]} src[i][s * row_stride[i] + c] for
  * c < cols[i], each in a fixed order (deterministic).  Entries with splits[i] <= 0 are skipped.  (The engine sums the weight-gradient
  * slabs of an encoder layer and the parameter-gradient partials of its LayerNorms with it: 11 launches -> 1; autograd's per-tensor

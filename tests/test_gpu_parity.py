@@ -1709,6 +1709,132 @@ def test_overlap_wgrad_with_dropout_trains_and_matches_the_serial_loss_of_the_fi
     assert err <= 1e-5, err
 
 
+def _image_of(t):
+    from allrank_amd import _lib as LB
+    img = torch.empty_like(t)
+    LB.check(LB.lib().ltrx_split_image(LB.ptr(t), LB.ptr(img), t.numel(), None), "split_image")
+    return img
+
+
+def test_activation_operand_images_equal_the_fp32_hand_over_bit_for_bit():
+    """round 5: an activation written as a pre-split bf16 hi / lo image by its producer and staged by its consumers with plain copies.
+    Kernel level: ltrx_layernorm_fwd_image == split_image(ltrx_layernorm_fwd); ltrx_gemm_nt_img with LTRX_GEMM_A_IS_IMAGE == the fp32
+    operand, with LTRX_GEMM_C_AS_IMAGE == split_image(C) (through bias / ReLU-mask / residual / dropout epilogues, the 256-, 128- and
+    64-row tile forms, ragged row counts); ltrx_gemm_tn_group_img with image B operands == ltrx_gemm_tn_group; the predicate refuses
+    shapes of the small-tile kernels and the call returns LTRX_EUNSUPPORTED there; FusedTrainer.decode_image inverts an image."""
+    import ctypes
+    from allrank_amd import _lib as LB
+    from allrank_amd.engine import FusedTrainer
+    lib = LB.lib()
+    rng = np.random.default_rng(81)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    # LayerNorm forward
+    for (rows, D) in [(3000, 512), (777, 256), (640, 1024)]:
+        x, a, b = _t(rng.standard_normal((rows, D)).astype(np.float32)), _t(rng.standard_normal(D).astype(np.float32)), _t(rng.standard_normal(D).astype(np.float32))
+        y, yi = torch.empty_like(x), torch.empty_like(x)
+        m1, r1, m2, r2 = (torch.empty(rows, device=DEV) for _ in range(4))
+        LB.check(lib.ltrx_layernorm_fwd(LB.ptr(x), None, LB.ptr(a), LB.ptr(b), rows, D, 1e-6, None, LB.ptr(y), LB.ptr(m1), LB.ptr(r1), 0.0, 0, None, None), "ln")
+        LB.check(lib.ltrx_layernorm_fwd_image(LB.ptr(x), None, LB.ptr(a), LB.ptr(b), rows, D, 1e-6, None, LB.ptr(yi), LB.ptr(m2), LB.ptr(r2), 0.0, 0, None, None), "ln image")
+        assert torch.equal(yi.view(torch.int32), _image_of(y).view(torch.int32)) and torch.equal(m1, m2) and torch.equal(r1, r2)
+        dec = FusedTrainer.decode_image(yi)
+        assert float((dec - y).abs().max()) <= 2.0 ** -16 * float(y.abs().max()) and torch.equal(dec > 0, y > 0)
+    assert lib.ltrx_layernorm_fwd_image(LB.ptr(x[:, :300].contiguous()), None, LB.ptr(a), LB.ptr(b), 10, 300, 1e-6, None, LB.ptr(yi), LB.ptr(m2), LB.ptr(r2), 0.0, 0, None, None) == -2
+    # NT GEMM: (M, N, K) -> 256-row tiles (exact / ragged), 128-row, 64-row, the split dispatch (one round + the rest)
+    for (Mm, N, K) in [(15360, 2048, 512), (12300, 2048, 256), (15360, 512, 2048), (7680, 512, 512), (15360, 1536, 512), (61440, 512, 64)]:
+        assert lib.ltrx_gemm_nt_image_ok(Mm, N, K) == 1, (Mm, N, K)
+        A = _t(rng.standard_normal((Mm, K)).astype(np.float32))
+        Bw = _t((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+        bias = _t(rng.standard_normal(N).astype(np.float32))
+        aux = _t(rng.standard_normal((Mm, N)).astype(np.float32))
+        Ai, Bi = _image_of(A), _image_of(Bw)
+        nb = lib.ltrx_gemm_nt_relu_bits_bytes(Mm, N, K)
+        for act, p in [(0, 0.0), (1, 0.2), (3, 0.1)] + ([(4, 0.0), (4, 0.3)] if nb else []):
+            outs = []
+            for fl in (0, 1, 2, 3):
+                C = torch.zeros((Mm, N), device=DEV)
+                bits = torch.zeros(max(nb, 16), dtype=torch.uint8, device=DEV)
+                ax = bits if act == 4 else (aux if act == 3 else None)
+                rc = lib.ltrx_gemm_nt_img(LB.ptr(Ai if fl & 1 else A), K, LB.ptr(Bw), K, LB.ptr(Bi), LB.ptr(C), N, Mm, N, K, LB.ptr(bias), act,
+                                          LB.ptr(ax), N if act == 3 else 0, p, 99, LB.ptr(step), 0, 0, fl, None)
+                assert rc == 0, (Mm, N, K, act, fl, rc)
+                outs.append((C, bits))
+            ref = outs[0][0]
+            assert torch.equal(outs[1][0], ref), (Mm, N, K, act, p, "A image")
+            assert torch.equal(outs[2][0].view(torch.int32), _image_of(ref).view(torch.int32)), (Mm, N, K, act, p, "C image")
+            assert torch.equal(outs[3][0].view(torch.int32), _image_of(ref).view(torch.int32)), (Mm, N, K, act, p, "A and C image")
+            assert all(torch.equal(o[1], outs[0][1]) for o in outs), (Mm, N, K, act, p, "mask bits")
+    for (Mm, N, K) in [(1000, 2048, 512), (15360, 2000, 512), (15360, 512, 144), (70000, 1024, 512)]:      # small-tile kernel territory
+        if lib.ltrx_gemm_nt_image_ok(Mm, N, K):
+            continue
+        A, Bw, C = torch.zeros((Mm, K), device=DEV), torch.zeros((N, K), device=DEV), torch.zeros((Mm, N), device=DEV)
+        assert lib.ltrx_gemm_nt_img(LB.ptr(A), K, LB.ptr(Bw), K, LB.ptr(Bw), LB.ptr(C), N, Mm, N, K, None, 0, None, 0, 0.0, 0, None, 0, 0, 1, None) != 0
+    assert lib.ltrx_gemm_nt_image_ok(1000, 2048, 512) == 0 and lib.ltrx_gemm_nt_image_ok(15360, 512, 144) == 0
+    # grouped weight gradient with image B operands (the four projections of an encoder layer; 3 of the 4 inputs as images)
+    Mm, d, dff = 15360, 512, 2048
+    probs = [(d, dff, True), (dff, d, True), (d, d, False), (3 * d, d, True)]       # (NP, KP, B is an image)
+    dys = [_t(rng.standard_normal((Mm, n_)).astype(np.float32)) for n_, _, _ in probs]
+    xs = [_t(rng.standard_normal((Mm, k_)).astype(np.float32)) for _, k_, _ in probs]
+    xi = [_image_of(x_) if im else x_ for x_, (_, _, im) in zip(xs, probs)]
+    n = len(probs)
+    vp, ci = ctypes.c_void_p * n, ctypes.c_int * n
+    NP, KP = ci(*[p_[0] for p_ in probs]), ci(*[p_[1] for p_ in probs])
+    wsb = lib.ltrx_gemm_tn_group_workspace_bytes(n, Mm, NP, KP)
+    res = []
+    for use_img in (False, True):
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        Cs = [torch.zeros((n_, k_), device=DEV) for n_, k_, _ in probs]
+        bs = [torch.zeros(n_, device=DEV) for n_, _, _ in probs]
+        Bops = xi if use_img else xs
+        rc = lib.ltrx_gemm_tn_group_img(n, vp(*[t.data_ptr() for t in dys]), ci(*[t.stride(0) for t in dys]), vp(*[t.data_ptr() for t in Bops]),
+                                        ci(*[t.stride(0) for t in Bops]), vp(*[t.data_ptr() for t in Cs]), vp(*[t.data_ptr() for t in bs]), Mm, NP, KP, 0,
+                                        LB.ptr(ws), wsb, None, None, None, ci(*[1 if (use_img and p_[2]) else 0 for p_ in probs]), None)
+        assert rc == 0, rc
+        res.append((Cs, bs))
+    for a_, b_ in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        assert torch.equal(a_, b_)
+    ref = dys[0].double().t() @ xs[0].double()
+    assert float((res[1][0][0].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("B,d,dff,p", [(64, 512, 2048, 0.0), (64, 256, 2048, 0.1), (256, 512, 2048, 0.0)])
+def test_activation_image_step_is_bit_identical_to_the_fp32_hand_over_step(B, d, dff, p):
+    """FusedTrainer(act_images=True) (opt-in) vs False (default): LayerNorm outputs and the feed-forward activation as operand images -- same
+    losses, gradients and weights bit for bit over eager warm-up, capture and replay; score() too; where the shapes do not take the
+    large-tile kernels the switch stays off by itself."""
+    import copy
+    from allrank_amd.model import make_model
+    from allrank_amd.engine import FusedTrainer
+    rng = np.random.default_rng(90 + B)
+    L, F = 240, 40
+    x = _t(rng.standard_normal((B, L, F)).astype(np.float32))
+    y = rng.integers(0, 5, (B, L)).astype(np.float32)
+    y[2, 77:] = -1
+    yt = _t(y)
+    torch.manual_seed(24)
+    base = make_model(dict(sizes=[d], input_norm=False, activation=None, dropout=0.0),
+                      dict(N=2, d_ff=dff, h=4, positional_encoding=None, dropout=p),
+                      dict(d_output=1, output_activation=None), F).to(DEV)
+    out = {}
+    for img in (True, False):
+        ft = FusedTrainer(copy.deepcopy(base), "approxNDCGLoss", {}, B, L, lr=1e-3, use_graph=True, seed=5, act_images=img)
+        losses, grads = [], []
+        for k in range(4):
+            losses.append(ft.step(x, yt).item())
+            grads.append(ft.flat_g.clone())
+        assert ft.images_active == img, (img, ft.images_active)
+        r = ft.saved_activation(0, "r").clone()
+        out[img] = (losses, grads, ft.flat_p.clone(), ft.score(x, yt).clone(), r)
+    assert out[True][0] == out[False][0], (out[True][0], out[False][0])
+    for k in range(4):
+        assert torch.equal(out[True][1][k], out[False][1][k]), k
+    assert torch.equal(out[True][2], out[False][2]) and torch.equal(out[True][3], out[False][3])
+    assert torch.equal(out[True][4] > 0, out[False][4] > 0)
+    assert float((out[True][4] - out[False][4]).abs().max()) <= 2.0 ** -16 * float(out[False][4].abs().max())
+    small = FusedTrainer(copy.deepcopy(base), "approxNDCGLoss", {}, 4, L, lr=1e-3, use_graph=False, seed=5)      # 960 rows: small-tile kernels
+    small.step(x[:4], yt[:4])
+    assert small.images_active is False
+
+
 def test_64_row_tile_gemm_equals_the_other_large_tile_forms_bit_for_bit():
     """ltrx_gemm_nt tile 8 (64 x 256 tiles, two workgroups per CU: the automatic choice for small batches) == tiles 7 and 6, bits,
     through every epilogue (bias, ReLU, ReLU mask, residual, dropout), exact and ragged row counts, with and without the image."""
