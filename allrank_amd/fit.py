@@ -23,8 +23,9 @@ What changes (all outside the arithmetic of a step):
     mode (train_utils.py:99; same mode, same data, SURVEY.md §8f row 2);
   * the last, short batch of an epoch (DataLoader drop_last=False) is topped up with fully padded slates for the static-shape step
     and its loss is normalised by the real slate count;
-  * under an initialised ``torch.distributed`` group every rank takes its contiguous block of each global batch (the reference
-    wraps the model in nn.DataParallel instead, main.py:76-78; a DataParallel wrapper passed in is unwrapped).
+  * under an initialised ``torch.distributed`` group every rank takes its contiguous block of each global batch -- training AND
+    validation batches (``_evaluate``) -- (the reference wraps the model in nn.DataParallel instead, main.py:76-78; a DataParallel
+    wrapper passed in is unwrapped).
 """
 import functools
 import logging
@@ -201,32 +202,61 @@ def _check_same_batch(xb, yb, world):
                            "contiguous block of each of them")
 
 
-def _evaluate(model, loss_func, dl, device, metrics, trainer=None):
+def _evaluate(model, loss_func, dl, device, metrics, trainer=None, world=1, rank=0):
     """validation pass of train_utils.py:101-107: mean loss (weighted by batch size) and metric means, no autograd.  With a
     FusedTrainer the scores come from its forward-only pass (``FusedTrainer.score``: the kernels of the training step, dropout
-    off, hipGraph replay) instead of the nn.Module forward (fp32 library GEMMs)."""
+    off, hipGraph replay) instead of the nn.Module forward (fp32 library GEMMs).
+    Sharded (``world`` > 1, round 5): every rank scores its contiguous block of each validation batch -- the same partition as the
+    training step -- under ``shard_context(global batch)``, so its loss is its share of the reference's loss on the whole batch
+    (global divisors / normalisers); shares, slate counts and per-slate metric sums are all-reduced once at the end, and
+    every rank returns the same numbers (scheduler and early stopping stay in step).  Before, every rank evaluated the whole set."""
+    import torch.distributed as dist
+    from . import sharding
     tot, num = torch.zeros((), device=device), 0
-    acc = {name: [] for name in metrics}
+    acc = {name: None for name in metrics}
     with torch.no_grad():
         for xb, yb, idx in (dl if isinstance(dl, _Prefetcher) else _Prefetcher(dl, device)):
+            n_glob = int(xb.shape[0])
+            if world > 1:
+                a, b = shard_slates(n_glob, rank, world)
+                xb, yb, idx = xb[a:b], yb[a:b], idx[a:b]
             n = int(xb.shape[0])
             if trainer is not None and n <= trainer.B and tuple(xb.shape[1:2]) == (trainer.L,):
                 xs, ys, ids = _pad_batch(xb, yb, idx, trainer.B)
                 sc = trainer.score(xs, ys, ids)[:n]
-                out = trainer.scores_raw[:n]
+                # (an empty shard of a short last batch still enters the loss -- its normaliser all-reduce is a collective -- with
+                #  one fully padded slate: value 0, count 0)
+                out, yl = trainer.scores_raw[:max(n, 1)], ys[:max(n, 1)]
             else:
+                if n == 0:
+                    xb, yb, idx = _pad_batch(xb, yb, idx, 1)
                 mask = yb == PADDED_Y_VALUE
                 out = model(xb, mask, idx)
-                sc = out if out.dim() == 2 else model.score(xb, mask, idx)
-            tot += loss_func(out, yb).detach().float() * n
+                sc = (out if out.dim() == 2 else model.score(xb, mask, idx))[:n]
+                yl = yb
+            if world > 1:
+                with sharding.shard_context(n_glob):
+                    share = loss_func(out, yl).detach().float()
+            else:
+                share = loss_func(out, yl).detach().float()
+            tot += share.reshape(()) * n_glob
             num += n
-            for name, ats in metrics.items():
-                acc[name].append(getattr(EM, name)(sc, yb, ats=ats))
-    out = {}
+            if n > 0:
+                for name, ats in metrics.items():
+                    v = getattr(EM, name)(sc, yb[:n], ats=ats).sum(0)
+                    acc[name] = v if acc[name] is None else acc[name] + v
+    sums = [acc[name].float() if acc[name] is not None else torch.zeros(len(metrics[name]), device=device) for name in metrics]
+    stats = torch.cat([tot.reshape(1), torch.tensor([float(num)], device=device)] + sums)
+    if world > 1:
+        dist.all_reduce(stats)
+    stats = stats.cpu().numpy()
+    n_all = max(float(stats[1]), 1.0)
+    out, off = {}, 2
     for name, ats in metrics.items():
-        vals = torch.cat(acc[name]).mean(0).cpu().numpy()
-        out.update({"%s_%d" % (name, at): v for at, v in zip(ats, vals)})
-    return float(tot.item()) / max(num, 1), out
+        for at in ats:
+            out["%s_%d" % (name, at)] = np.float32(stats[off] / n_all)
+            off += 1
+    return float(stats[0]) / n_all, out
 
 
 def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, config, gradient_clipping_norm, early_stopping_patience,
@@ -319,7 +349,7 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
                 off += 1
 
         model.eval()
-        val_loss, val_metrics = _evaluate(model, loss_func, valid_pf, device, metrics, trainer if fused else None)
+        val_loss, val_metrics = _evaluate(model, loss_func, valid_pf, device, metrics, trainer if fused else None, world, rank)
 
         lr_now = optimizer.param_groups[0]["lr"]
         if writer is not None:

@@ -552,6 +552,30 @@ def main():
                         traffic=traffic, traffic_detail=traffic_detail, algorithmic_bytes_per_launch=by, avg_launch_us=round(step_us, 1),
                         timing="HIP events around 20 training steps after the timed region (both launches of a step)",
                         host_bound_note="wall-clock per step in the timed region: %.1f us" % (dt / args.steps * 1e6))
+        att_roof = None
+        if w["N"] and "ltrx_mha_fwd (res split-bf16)" in kern:
+            # the attention kernels against the matrix-core roof: algorithmic flops 4 L^2 d_k per (slate, head)
+            # forward, 10 L^2 d_k backward (five tile products: S, dP, dV, dK in the dK/dV kernel, dQ in the second kernel), each
+            # contraction executed as 3 bf16 MFMA products; HBM side: the compulsory tensors and the dS hand-over between the two
+            # backward kernels (fp32 [B, h, LK, LK], written once and read once).  Timed back to back after the timed region.
+            d_, h_ = w["fc_sizes"][-1], w["h"]
+            LK = (L + 63) // 64 * 64
+            kf, kb = kern["ltrx_mha_fwd (res split-bf16)"], kern["ltrx_mha_bwd (dq+dkdv, res split-bf16)"]
+            def _ar(k_, io_bytes, extra=None):
+                tf = k_["flops"] / k_["sec"] / 1e12
+                r_ = dict(avg_launch_us=round(k_["sec"] * 1e6, 1), algorithmic_flops_per_launch=k_["flops"], achieved=round(tf, 1), unit="TFLOP/s",
+                          peak=PEAK_BF16_MFMA_TFLOPS, frac=round(tf / PEAK_BF16_MFMA_TFLOPS, 4), executed_mfma_tflops=round(3 * tf, 1),
+                          executed_frac=round(3 * tf / PEAK_BF16_MFMA_TFLOPS, 4), algorithmic_bytes_per_launch=io_bytes,
+                          hbm_gbps_if_compulsory_only=round(io_bytes / k_["sec"] / 1e9, 1))
+                r_.update(extra or {})
+                return r_
+            ds_b = 2.0 * 4.0 * B * h_ * LK * LK
+            att_roof = dict(bound="mfma (VALU-side: softmax and the split of P / dS beside the matrix pipe)", launches_per_step=w["N"],
+                            forward=_ar(kf, 4.0 * B * L * 4 * d_ + 4.0 * B * h_ * L),
+                            backward=_ar(kb, 4.0 * B * L * 8 * d_ + 4.0 * B * h_ * L,
+                                         dict(ds_handover_bytes=ds_b, hbm_gbps_with_ds_handover=round((4.0 * B * L * 8 * d_ + ds_b) / kb["sec"] / 1e9, 1),
+                                              kernels="ltrx_mha_bwd_dkdv_res_kernel + ltrx_mha_bwd_dq_res_kernel")),
+                            notes="profiles/r04_pmc_step_bytes_256.md (PMC traffic of both backward kernels), profiles/NOTES.md (chunked / 24-bit dS hand-over: measured slower)")
         loss_roof = None
         if w["loss"].startswith("neuralNDCG"):
             # the Sinkhorn kernels are VALU bound (no contraction): algorithmic flops = n^2 x (4 per forward step + 6 per backward step)
@@ -582,6 +606,7 @@ def main():
             "last_loss": last_loss,
             "valid_items_per_s": (round(value * float((y != -1).float().mean().item()), 1) if args.ragged else None),
             "roofline": roof,
+            "roofline_attention": att_roof,
             "roofline_loss_kernels": loss_roof,
             "kernel_times_us": {n: round(v["sec"] * 1e6, 1) for n, v in kern.items()},
         }
