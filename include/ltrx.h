@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTRX_VERSION 121 /* 0.2.0: slate-resident FC + ListNet step (round 4) */
+#define LTRX_VERSION 122 /* 0.2.1 (round 5): ltrx_ndcg_at_gains, operand images of activations (ltrx_gemm_nt_img, ltrx_gemm_tn_group_img, ltrx_layernorm_fwd_image), ltrx_gemm_nt_relu_bits_bytes(M, N, K) */
 
 #define LTRX_OK 0
 #define LTRX_EINVAL (-1)

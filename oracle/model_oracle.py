@@ -2,8 +2,10 @@
 
 numpy restatement (forward, hand-derived backward, Adam) of allRank's LTRModel:
 FCModel -> N x pre-norm Transformer encoder layers over the slate -> custom LayerNorm -> OutputLayer
-(allrank/models/model.py:12-151, allrank/models/transformer.py:28-247).  Dropout is not modelled
-(parity runs use dropout=0 / eval()).  Parameters are a dict keyed exactly like the
+(allrank/models/model.py:12-151, allrank/models/transformer.py:28-247).  Dropout is modelled as INJECTED masks
+(``forward(..., drop=)``: one multiplier array -- 0 or 1/(1-p) -- per nn.Dropout site of the reference: model.py:43,
+transformer.py:105,155,227; None = every dropout off, the parity default): the reference draws its masks from
+torch's generator, the engine's are counter-based and reproducible (oracle/dropout_oracle.py).  Parameters are a dict keyed exactly like the
 reference ``state_dict`` so weights can be exchanged with the real thing.
 
 Pinned by tests/test_oracle_pinned.py against golden vectors generated from the reference itself
@@ -116,30 +118,42 @@ def torch_ln_bwd(cache, w, gy, grads, name):
     return r * (g - g.mean(-1, keepdims=True) - xhat * (g * xhat).mean(-1, keepdims=True))
 
 
-def attention_fwd(q, k, v, mask):
-    """transformer.py:137-156 on q,k,v [B,h,L,dk]; mask [B,L] True = padded KEY (masked_fill -inf)."""
+def attention_fwd(q, k, v, mask, pdrop=None):
+    """transformer.py:137-156 on q,k,v [B,h,L,dk]; mask [B,L] True = padded KEY (masked_fill -inf); pdrop: the dropout
+    multipliers of the probabilities (transformer.py:154-155), applied after the softmax.  Returns (p_dropped @ v, p)."""
     dk = q.shape[-1]
     sc = (q @ np.swapaxes(k, -1, -2)) / q.dtype.type(math.sqrt(dk))
     sc = np.where(mask[:, None, None, :], -np.inf, sc)
     m = sc.max(-1, keepdims=True)
     e = np.exp(sc - m)
     p = e / e.sum(-1, keepdims=True)
-    return p @ v, p
+    pd = p if pdrop is None else p * pdrop
+    return pd @ v, p
 
 
-def attention_bwd(q, k, v, p, go):
+def attention_bwd(q, k, v, p, go, pdrop=None):
     dk = q.shape[-1]
-    gv = np.swapaxes(p, -1, -2) @ go
+    pd = p if pdrop is None else p * pdrop
+    gv = np.swapaxes(pd, -1, -2) @ go
     gp = go @ np.swapaxes(v, -1, -2)
+    if pdrop is not None:
+        gp = gp * pdrop
     gs = p * (gp - (gp * p).sum(-1, keepdims=True))
     gs = gs / q.dtype.type(math.sqrt(dk))
     return gs @ k, np.swapaxes(gs, -1, -2) @ q, gv
 
 
-def forward(p, cfg, x, mask):
-    """LTRModel.forward (model.py:72-80) for d_output == 1 (scores [B,L]); returns (scores, cache)."""
+def forward(p, cfg, x, mask, drop=None):
+    """LTRModel.forward (model.py:72-80) for d_output == 1 (scores [B,L]); returns (scores, cache).
+    drop: None (model.eval() / dropout 0) or {"fc": [mask per FC layer], "layers": [{"att", "ff", "s0", "s1"} per encoder layer]}
+    -- multiplier arrays (0 or 1/(1-p)) of the nn.Dropout sites: after every FC activation (model.py:43), on the attention
+    probabilities (transformer.py:155), after the feed-forward ReLU (:227), on each residual branch (:105)."""
     B, L, _ = x.shape
-    cache = {"x": x, "mask": mask}
+    cache = {"x": x, "mask": mask, "drop": drop}
+    dt = x.dtype
+
+    def dm(m_):
+        return None if m_ is None else np.asarray(m_, dtype=dt)
     act_f, _ = ACTS[cfg.get("fc_activation")]
     h = x
     if cfg.get("fc_input_norm"):
@@ -150,7 +164,7 @@ def forward(p, cfg, x, mask):
         z = linear_fwd(h, p["input_layer.layers.%d.weight" % i], p["input_layer.layers.%d.bias" % i])
         y = act_f(z)
         fc.append((h, z, y))
-        h = y
+        h = y if drop is None else y * dm(drop["fc"][i])
     cache["fc"] = fc
     d = h.shape[-1]
     H = cfg.get("h", 1)
@@ -165,18 +179,23 @@ def forward(p, cfg, x, mask):
         for j in range(3):                                         # transformer.py:193-195
             t = linear_fwd(xn, p[pre + "self_attn.linears.%d.weight" % j], p[pre + "self_attn.linears.%d.bias" % j])
             qkv.append(t.reshape(B, L, H, dk).transpose(0, 2, 1, 3))
-        o, pa = attention_fwd(qkv[0], qkv[1], qkv[2], mask)
+        ld = None if drop is None else drop["layers"][n]
+        o, pa = attention_fwd(qkv[0], qkv[1], qkv[2], mask, None if ld is None else dm(ld["att"]))
         lc["qkv"], lc["p"] = qkv, pa
         oc = o.transpose(0, 2, 1, 3).reshape(B, L, d)              # :201-202
         lc["oc"] = oc
-        h = h + linear_fwd(oc, p[pre + "self_attn.linears.3.weight"], p[pre + "self_attn.linears.3.bias"])   # :203, :105
+        br = linear_fwd(oc, p[pre + "self_attn.linears.3.weight"], p[pre + "self_attn.linears.3.bias"])      # :203
+        h = h + (br if ld is None else br * dm(ld["s0"]))                                                    # :105
         lc["x1"] = h
         xn, lc["ln1"] = custom_ln_fwd(h, p[pre + "sublayer.1.norm.a_2"], p[pre + "sublayer.1.norm.b_2"])
         lc["xn1"] = xn
         z = linear_fwd(xn, p[pre + "feed_forward.w_1.weight"], p[pre + "feed_forward.w_1.bias"])
         r = np.maximum(z, 0)                                       # :227
+        if ld is not None:
+            r = r * dm(ld["ff"])
         lc["z"], lc["r"] = z, r
-        h = h + linear_fwd(r, p[pre + "feed_forward.w_2.weight"], p[pre + "feed_forward.w_2.bias"])
+        br = linear_fwd(r, p[pre + "feed_forward.w_2.weight"], p[pre + "feed_forward.w_2.bias"])
+        h = h + (br if ld is None else br * dm(ld["s1"]))
         layers.append(lc)
     cache["layers"] = layers
     if cfg.get("N", 0):
@@ -199,6 +218,8 @@ def backward(p, cfg, cache, gscores, relu_masks=None, fc_relu_masks=None):
     activations (one bool array per FC layer, ReLU stacks only)."""
     grads = {}
     B, L = gscores.shape
+    drop = cache.get("drop")
+    dt = gscores.dtype
     _, oact_b = ACTS[cfg.get("output_activation")]
     gz = oact_b(cache["out_z"], cache["out_y"], gscores)[..., None]
     g = linear_bwd(cache["out_in"], p["output_layer.w_1.weight"], gz, grads, "output_layer.w_1")
@@ -210,14 +231,19 @@ def backward(p, cfg, cache, gscores, relu_masks=None, fc_relu_masks=None):
         lc = cache["layers"][n]
         d = lc["x0"].shape[-1]
         dk = d // H
-        gr = linear_bwd(lc["r"], p[pre + "feed_forward.w_2.weight"], g, grads, pre + "feed_forward.w_2")
+        ld = None if drop is None else {k_: np.asarray(v_, dtype=dt) for k_, v_ in drop["layers"][n].items()}
+        gb = g if ld is None else g * ld["s1"]
+        gr = linear_bwd(lc["r"], p[pre + "feed_forward.w_2.weight"], gb, grads, pre + "feed_forward.w_2")
+        if ld is not None:
+            gr = gr * ld["ff"]
         gzz = gr * ((lc["z"] > 0) if relu_masks is None else relu_masks[n])
         gxn = linear_bwd(lc["xn1"], p[pre + "feed_forward.w_1.weight"], gzz, grads, pre + "feed_forward.w_1")
         g = g + custom_ln_bwd(lc["ln1"], p[pre + "sublayer.1.norm.a_2"], gxn, grads, pre + "sublayer.1.norm")
-        goc = linear_bwd(lc["oc"], p[pre + "self_attn.linears.3.weight"], g, grads, pre + "self_attn.linears.3")
+        gb = g if ld is None else g * ld["s0"]
+        goc = linear_bwd(lc["oc"], p[pre + "self_attn.linears.3.weight"], gb, grads, pre + "self_attn.linears.3")
         go = goc.reshape(B, L, H, dk).transpose(0, 2, 1, 3)
         q, k, v = lc["qkv"]
-        gq, gk, gv = attention_bwd(q, k, v, lc["p"], go)
+        gq, gk, gv = attention_bwd(q, k, v, lc["p"], go, None if ld is None else ld["att"])
         gxn = 0
         for j, gt in enumerate((gq, gk, gv)):
             gt2 = gt.transpose(0, 2, 1, 3).reshape(B, L, d)
@@ -228,6 +254,8 @@ def backward(p, cfg, cache, gscores, relu_masks=None, fc_relu_masks=None):
     nfc = len(cfg.get("fc_sizes") or [])
     for i in reversed(range(nfc)):
         hin, z, y = cache["fc"][i]
+        if drop is not None:
+            g = g * np.asarray(drop["fc"][i], dtype=dt)
         g = act_b(z, y, g) if fc_relu_masks is None else g * fc_relu_masks[i]
         g = linear_bwd(hin, p["input_layer.layers.%d.weight" % i], g, grads, "input_layer.layers.%d" % i)
     if cfg.get("fc_input_norm"):

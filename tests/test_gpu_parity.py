@@ -919,6 +919,84 @@ def test_dropout_sites_share_one_counter_based_mask():
         assert (y.double() - yr).abs().max().item() < 2e-5
 
 
+def test_numpy_dropout_masks_equal_the_kernels_bit_for_bit():
+    """oracle/dropout_oracle.py restates the engine's counter-based masks: the element mask of the GEMM epilogues / LayerNorm residual
+    / ltrx_dropout_apply, and the attention mask -- read back from an attention call whose probabilities are uniform (q = k = 0) and
+    whose value rows are one-hot, so that O[query, key] = mask[query, key] / L -- for the resident three-product kernels (mode 1) and
+    the exact-fp32 kernels (mode 0)."""
+    from allrank_amd import _lib as LB
+    from oracle import dropout_oracle as D
+    lib = LB.lib()
+    for (shape, p, seed, word) in [((700, 192), 0.3, 0xC0FFEE, 7), ((1000, 2048), 0.1, 123456789, 1), ((33, 40), 0.5, 5, 0)]:
+        ones = torch.ones(shape, device=DEV)
+        mk = torch.empty(shape, device=DEV)
+        step = torch.tensor([word], dtype=torch.int32, device=DEV)
+        LB.check(lib.ltrx_dropout_apply(LB.ptr(ones), LB.ptr(mk), ones.numel(), p, seed, LB.ptr(step), None), "apply")
+        assert np.array_equal(mk.cpu().numpy(), D.keep_scale(p, seed, word, shape)), (shape, p)
+    B, L, h, dk, p, seed, word = 3, 64, 2, 64, 0.25, 0xABCDE, 5
+    d = h * dk
+    qkv = torch.zeros(B * L, 3 * d, device=DEV)
+    qkv[:, 2 * d:] = torch.eye(L, device=DEV).repeat(B, h)              # V[b, j, head, :] = one-hot(j)
+    mask = torch.zeros(B, L, dtype=torch.uint8, device=DEV)
+    step = torch.tensor([word], dtype=torch.int32, device=DEV)
+    ref = D.attention_keep_scale(p, seed, word, B, h, L)
+    for mode in (1, 0):
+        o, lse = torch.empty(B * L, d, device=DEV), torch.empty(B, h, L, device=DEV)
+        LB.check(lib.ltrx_mha_fwd(LB.ptr(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, LB.ptr(mask), B, L, h, dk, 3 * d, LB.ptr(o), d,
+                                  LB.ptr(lse), p, seed, LB.ptr(step), None, None, mode, None), "mha_fwd")
+        got = (o.view(B, L, h, dk).permute(0, 2, 1, 3) * L).cpu().numpy()       # [B, h, query, key]
+        assert np.array_equal(got > 0, ref > 0), mode
+        assert np.abs(got - ref).max() <= 1e-5, (mode, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("d,h,fc_act", [(64, 1, "ReLU"), (32, 2, None)])
+def test_fused_step_with_dropout_matches_the_fp64_oracle_under_the_same_masks(d, h, fc_act):
+    """training-mode parity was statistical only (the reference draws its masks from torch's generator).  The
+    engine's masks are pure functions of (site seed, step word, element index), so the fp64 oracle is handed exactly the masks each
+    step used (oracle/dropout_oracle.engine_masks) and the step -- FC dropout, attention-probability dropout, feed-forward dropout and
+    both residual-branch dropouts active -- is compared with it at the engine's weights: loss within 1e-5, scores, every parameter
+    gradient on the engine's ReLU branch; three steps (eager, eager, captured) each with its own masks."""
+    from allrank_amd.model import make_model
+    from allrank_amd.engine import FusedTrainer
+    from oracle import dropout_oracle as D
+    rng = np.random.default_rng(17)
+    B, L, F, dff = 8, 40, 20, 64
+    x = rng.standard_normal((B, L, F)).astype(np.float32)
+    y = rng.integers(0, 5, (B, L)).astype(np.float32)
+    y[3, 25:] = -1
+    x[3, 25:] = 0
+    mask = y == -1
+    torch.manual_seed(33)
+    model = make_model(dict(sizes=[48, d], input_norm=False, activation=fc_act, dropout=0.1),
+                       dict(N=2, d_ff=dff, h=h, positional_encoding=None, dropout=0.2),
+                       dict(d_output=1, output_activation=None), F).to(DEV)
+    cfg = dict(n_features=F, fc_sizes=[48, d], fc_activation=fc_act, fc_input_norm=False, N=2, d_ff=dff, h=h, output_activation=None)
+    ft = FusedTrainer(model, "approxNDCGLoss", {}, B, L, lr=1e-3, use_graph=True, seed=77)
+    assert ft._any_dropout and ft.p_fc == 0.1 and ft.layers[0]["p_att"] == 0.2
+    named = dict(model.named_parameters())
+    xt, yt = _t(x), _t(y)
+    for step in range(3):
+        w = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in named.items()}
+        loss = float(ft.step(xt, yt).item())
+        word = int(ft.drop_step.item())
+        assert word == step + 1
+        masks = D.engine_masks(ft, word)
+        so, cache = M.forward(w, cfg, x.astype(np.float64), mask, masks)
+        lo, gs = O.approxndcg(so, y, dtype=np.float64)[:2]
+        assert abs(loss - lo) <= 1e-5 * (1 + abs(lo)), (step, loss, lo)
+        sc = ft.scores.cpu().numpy().astype(np.float64)
+        assert np.abs(sc - so)[~mask].max() <= 2e-5 * max(1.0, np.abs(so[~mask]).max()), step
+        pats = [(st["r"] > 0).view(B, L, -1).cpu().numpy() for st in ft.layers]
+        fcp = [(t > 0).view(B, L, -1).cpu().numpy() for t in ft.fc_out] if fc_act == "ReLU" else None
+        g_or = M.backward(w, cfg, cache, np.asarray(gs, dtype=np.float64), relu_masks=pats, fc_relu_masks=fcp)
+        gmax = max(float(np.abs(v).max()) for v in g_or.values())
+        for k, v in named.items():
+            ge = v.grad.detach().cpu().numpy().astype(np.float64)
+            own = float(np.abs(g_or[k]).max())
+            err = float(np.abs(ge - g_or[k]).max())
+            assert err <= 1e-3 * own + 1e-6 * gmax, (step, k, err, own)
+
+
 def _dropout_model(p, fc_act, fc_drop, N=2):
     from allrank_amd.model import make_model
     return make_model(dict(sizes=[48, 32], input_norm=False, activation=fc_act, dropout=fc_drop),

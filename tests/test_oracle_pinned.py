@@ -249,3 +249,46 @@ def test_oracle_ndcg_with_gain_function_matches_reference_golden():
             assert np.allclose(nd, g[pre + name + ".ndcg"], rtol=1e-5, atol=1e-6), (ci, name)
             assert np.allclose(dc, g[pre + name + ".dcg"], rtol=1e-5, atol=1e-5), (ci, name)
             assert np.allclose(nn, g[pre + name + ".ndcg_none"], rtol=1e-5, atol=1e-6), (ci, name)
+
+
+def test_oracle_dropout_backward_is_the_gradient_of_its_forward():
+    """oracle/model_oracle.py with injected dropout masks (model.py:43, transformer.py:105,155,227) and the numpy restatement of the
+    engine's counter-based masks (oracle/dropout_oracle.py): keep rates ~ 1 - p, multipliers 0 or 1/(1-p), and -- masks frozen -- the
+    central difference of the loss along every parameter's gradient equals the gradient norm; drop=None is the old forward."""
+    from oracle import dropout_oracle as D
+    cfg = dict(n_features=10, fc_sizes=[12, 8], fc_activation="ReLU", fc_input_norm=False, N=2, d_ff=16, h=2, output_activation=None)
+    p = {k: v.astype(np.float64) for k, v in M.init_params(cfg, seed=3).items()}
+    rng = np.random.default_rng(0)
+    B, L = 3, 7
+    x = rng.standard_normal((B, L, 10))
+    y = rng.integers(0, 5, (B, L)).astype(np.float64)
+    y[1, 5:] = -1
+    mask = y == -1
+    big = D.keep_scale(0.3, 12345, 7, (200, 300))
+    assert abs(float((big > 0).mean()) - 0.7) < 0.01 and set(np.unique(big).tolist()) == {0.0, float(np.float32(1) / (np.float32(1) - np.float32(0.3)))}
+    att = D.attention_keep_scale(0.2, 99, 3, 4, 2, 64)
+    assert att.shape == (4, 2, 64, 64) and abs(float((att > 0).mean()) - 0.8) < 0.02
+    assert not np.array_equal(D.keep_scale(0.3, 12345, 8, (200, 300)) > 0, big > 0)          # the step word re-keys the mask
+    drop = {"fc": [D.keep_scale(0.2, 11 + i, 1, (B, L, s_)) for i, s_ in enumerate([12, 8])],
+            "layers": [{"att": D.attention_keep_scale(0.25, 100 + n, 1, B, 2, L), "ff": D.keep_scale(0.2, 200 + n, 1, (B, L, 16)),
+                        "s0": D.keep_scale(0.3, 300 + n, 1, (B, L, 8)), "s1": D.keep_scale(0.1, 400 + n, 1, (B, L, 8))} for n in range(2)]}
+
+    def loss_of(pp):
+        s_, c_ = M.forward(pp, cfg, x, mask, drop)
+        return O.approxndcg(s_, y, dtype=np.float64)[0], s_, c_
+    _, s0, c0 = loss_of(p)
+    g = M.backward(p, cfg, c0, O.approxndcg(s0, y, dtype=np.float64)[1])
+    for k in p:
+        n_ = np.linalg.norm(g[k])
+        if n_ < 1e-12:
+            continue
+        d_ = g[k] / n_
+        pp = dict(p)
+        pp[k] = p[k] + 1e-6 * d_
+        lp = loss_of(pp)[0]
+        pp[k] = p[k] - 1e-6 * d_
+        lm = loss_of(pp)[0]
+        assert abs((lp - lm) / 2e-6 - n_) <= 1e-4 * n_, k
+    s_plain, _ = M.forward(p, cfg, x, mask)
+    s_none, _ = M.forward(p, cfg, x, mask, None)
+    assert np.array_equal(s_plain, s_none) and not np.allclose(s_plain, s0)
