@@ -985,7 +985,9 @@ def test_fused_step_with_dropout_matches_the_fp64_oracle_under_the_same_masks(d,
         lo, gs = O.approxndcg(so, y, dtype=np.float64)[:2]
         assert abs(loss - lo) <= 1e-5 * (1 + abs(lo)), (step, loss, lo)
         sc = ft.scores.cpu().numpy().astype(np.float64)
-        assert np.abs(sc - so)[~mask].max() <= 2e-5 * max(1.0, np.abs(so[~mask]).max()), step
+        # (scores: 5e-5 of their scale -- measured 2.1e-5; the no-dropout bar of 2e-5 is exceeded by the 1 / (1 - p) multipliers of five
+        #  dropout sites on top of the three-product round-off.  A mask that differed in ONE element would show as O(1e-2).)
+        assert np.abs(sc - so)[~mask].max() <= 5e-5 * max(1.0, np.abs(so[~mask]).max()), (step, np.abs(sc - so)[~mask].max())
         pats = [(st["r"] > 0).view(B, L, -1).cpu().numpy() for st in ft.layers]
         fcp = [(t > 0).view(B, L, -1).cpu().numpy() for t in ft.fc_out] if fc_act == "ReLU" else None
         g_or = M.backward(w, cfg, cache, np.asarray(gs, dtype=np.float64), relu_masks=pats, fc_relu_masks=fcp)
