@@ -483,6 +483,7 @@ class FusedTrainer(object):
         self.use_graph = use_graph and not compact
         self.graph_fwd, self._warm_fwd = None, 0
         self.probe = None                                     # list collecting (start, end) events of the FFN1 GEMM (eager steps only)
+        self.probe_wgrad = None                               # ... of the grouped weight-gradient launch (bench.py, eager steps only)
         # captured steps: {(batch divisor, collectives on?): [(hipGraph segment, collective to launch after it | None), ...]}
         import collections
         self._graphs = collections.OrderedDict()
@@ -829,8 +830,14 @@ class FusedTrainer(object):
         self.wgrad_group_log.append((n, bool(took)))
         del self.wgrad_group_log[:-16]
         bimg = ci(*[1 if t[4] else 0 for t in q])                 # operand B (the layer input) of a problem is an activation image
+        if self.probe_wgrad is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         self.LB.check(self.lib.ltrx_gemm_tn_group_img(n, A, lda, Bm, ldb, C, bo, self.rows, NP, KP, self._prec, self.LB.ptr(self.ws_tn),
                                                       self.ws_tn.numel(), *outs, bimg, self._st()), "gemm_tn_group(wgrad)")
+        if self.probe_wgrad is not None:
+            ev1.record()
+            self.probe_wgrad.append((ev0, ev1, n, bool(took)))
         if defer_reduce and sp.value > 0:
             for i, t in enumerate(q):
                 nw = t[0].shape[1] * t[1].shape[1]

@@ -452,16 +452,19 @@ def main():
 
     # the roofline kernel (FFN-1 GEMM) timed where it runs: HIP events around its launches inside eager training steps that
     # follow the timed region (same stream, same neighbours, same clocks as the step; a replayed hipGraph has no place for them)
-    probe_us = None
+    probe_us, wgrad_us = None, None
     if args.engine == "fused" and w["N"]:
         use_graph = trainer.use_graph
-        trainer.use_graph, trainer.probe = False, []
+        trainer.use_graph, trainer.probe, trainer.probe_wgrad = False, [], []
         for i in range(6):
             one_step(args.warmup + args.steps + i)
         torch.cuda.synchronize()
         ts = [a.elapsed_time(b) for a, b in trainer.probe[w["N"]:]]          # first probed step dropped
         probe_us = 1e3 * sum(ts) / len(ts)
-        trainer.use_graph, trainer.probe = use_graph, None
+        # the single longest launch of the step: the grouped weight gradient of an encoder layer (four dW = dY^T X over the same rows)
+        tw = [a.elapsed_time(b) for a, b, n_, took_ in trainer.probe_wgrad[w["N"]:] if n_ == 4 and took_]
+        wgrad_us = (1e3 * sum(tw) / len(tw)) if tw else None
+        trainer.use_graph, trainer.probe, trainer.probe_wgrad = use_graph, None, None
 
     # multi-rank: how much of the gradient all-reduce is exposed = timed step - the same step with the collective skipped
     comm = None
@@ -552,6 +555,17 @@ def main():
                         traffic=traffic, traffic_detail=traffic_detail, algorithmic_bytes_per_launch=by, avg_launch_us=round(step_us, 1),
                         timing="HIP events around 20 training steps after the timed region (both launches of a step)",
                         host_bound_note="wall-clock per step in the timed region: %.1f us" % (dt / args.steps * 1e6))
+        wg_roof = None
+        if wgrad_us:
+            d_, dff_ = w["fc_sizes"][-1], w["d_ff"]
+            flw = 2.0 * B * L * (3 * d_ * d_ + d_ * d_ + 2 * d_ * dff_)          # 2 M (N K) summed over the four projections of a layer
+            tfw = flw / (wgrad_us * 1e-6) / 1e12
+            wg_roof = dict(kernel="ltrx_gemm_tn256_kernel (ltrx_gemm_tn_group: the four weight gradients of an encoder layer in one launch)",
+                           bound="mfma", achieved=round(tfw, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s", frac=round(tfw / PEAK_BF16_MFMA_TFLOPS, 4),
+                           executed_mfma_tflops=round(3 * tfw, 1), executed_frac=round(3 * tfw / PEAK_BF16_MFMA_TFLOPS, 4),
+                           avg_launch_us=round(wgrad_us, 1), launches_per_step=w["N"], algorithmic_flops_per_launch=flw,
+                           algorithmic_bytes_per_launch=4.0 * B * L * (8 * d_ + 2 * dff_),     # dY and X of the four problems, read once
+                           timing="HIP events around the grouped launch inside 5 eager training steps after the timed region")
         att_roof = None
         if w["N"] and "ltrx_mha_fwd (res split-bf16)" in kern:
             # the attention kernels against the matrix-core roof: algorithmic flops 4 L^2 d_k per (slate, head)
@@ -606,6 +620,7 @@ def main():
             "last_loss": last_loss,
             "valid_items_per_s": (round(value * float((y != -1).float().mean().item()), 1) if args.ragged else None),
             "roofline": roof,
+            "roofline_weight_gradient": wg_roof,
             "roofline_attention": att_roof,
             "roofline_loss_kernels": loss_roof,
             "kernel_times_us": {n: round(v["sec"] * 1e6, 1) for n, v in kern.items()},
