@@ -1915,6 +1915,34 @@ def test_activation_image_step_is_bit_identical_to_the_fp32_hand_over_step(B, d,
     assert small.images_active is False
 
 
+def test_overlap_wgrad_and_act_images_together_equal_the_default_step():
+    """both opt-in step forms at once (fork / join of the weight-gradient launches + activation operand images), with and without dropout
+    on one sublayer: bit-identical to the default step over eager warm-up, capture and replay"""
+    import copy
+    from allrank_amd.model import make_model
+    from allrank_amd.engine import FusedTrainer
+    rng = np.random.default_rng(99)
+    B, L, F = 64, 240, 40
+    x = _t(rng.standard_normal((B, L, F)).astype(np.float32))
+    yt = _t(rng.integers(0, 5, (B, L)).astype(np.float32))
+    for p in (0.0, 0.1):
+        torch.manual_seed(26)
+        base = make_model(dict(sizes=[256], input_norm=False, activation=None, dropout=0.0),
+                          dict(N=3, d_ff=2048, h=4, positional_encoding=None, dropout=p),
+                          dict(d_output=1, output_activation=None), F).to(DEV)
+        res = {}
+        for both in (True, False):
+            ft = FusedTrainer(copy.deepcopy(base), "approxNDCGLoss", {}, B, L, lr=1e-3, use_graph=True, seed=5, overlap_wgrad=both, act_images=both)
+            if p:                                       # (with BOTH sublayer dropouts the serial step groups 2 + 2: keep one of them off)
+                for st in ft.layers:
+                    st["p_s0"] = 0.0
+            losses = [ft.step(x, yt).item() for _ in range(4)]
+            assert ft.images_active == both and ft.overlap_wgrad == both
+            res[both] = (losses, ft.flat_g.clone(), ft.flat_p.clone())
+        assert res[True][0] == res[False][0], (p, res[True][0], res[False][0])
+        assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2]), p
+
+
 def test_64_row_tile_gemm_equals_the_other_large_tile_forms_bit_for_bit():
     """ltrx_gemm_nt tile 8 (64 x 256 tiles, two workgroups per CU: the automatic choice for small batches) == tiles 7 and 6, bits,
     through every epilogue (bias, ReLU, ReLU mask, residual, dropout), exact and ragged row counts, with and without the image."""

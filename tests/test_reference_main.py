@@ -12,6 +12,11 @@ loss through ``getattr(losses, name)`` + functools.partial, torch.optim.Adam and
     the reference's own dump_experiment_result / assert_expected_metrics;
   * on a machine that has BOTH a GPU and a checkout (ALLRANK_REFERENCE=/path/to/allRank): the same with the real fit -- the
     ``-m gpu`` test below (skipped on the GPU box of this build, where the reference is absent).
+
+Several GPUs (round 5): the same unmodified main.run() as TWO ranks under ``python -m allrank_amd.launch`` -- process group, rank devices,
+no DataParallel wrapper, global batch = world x batch_size, identical batches on both ranks, rank 0 owning the job directory -- is
+tests/test_launch_cpu.py (CPU half, gloo); its in-tree GPU twin (training under the launcher == the one-rank run) is
+tests/test_gpu_main_sequence.py::test_main_call_sequence_under_the_launcher_equals_the_one_rank_run.
 """
 import json
 import os
