@@ -280,15 +280,12 @@ def main(argv=None):
     rest = a.main_args[1:] if a.main_args[:1] == ["--"] else a.main_args
     devices = [d for d in a.devices.split(",")] if a.devices else None
     logging.basicConfig(level=logging.INFO)
-    if distributed_env() is not None or (a.nproc or 0) == 1:      # already one rank of a job (torchrun / our own spawn): work
+    nproc = a.nproc or max(1, torch.cuda.device_count())
+    if distributed_env() is not None or nproc == 1:               # one rank of a job (torchrun / our own spawn), or a one-GPU run: work
         try:
             run_main(rest, a.backend, devices, fit=not a.no_fit)
         finally:
             shutdown()
-        return 0
-    nproc = a.nproc or max(1, torch.cuda.device_count())
-    if nproc == 1:
-        run_main(rest, a.backend, devices, fit=not a.no_fit)
         return 0
     cmd = [sys.executable, "-m", "allrank_amd.launch"]
     if a.no_fit:
