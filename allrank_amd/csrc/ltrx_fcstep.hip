@@ -24,7 +24,7 @@
 // algorithmic bytes; plus one partial gradient (4 (H F + 2 H + 8) B) per WORKGROUP.
 //
 // Register budget (168 per thread at 12 waves): dW1 tile 36 + h tiles 32 + the forward's W1 fragments 40 (re-read per slate) or the
-// backward's working set ~45, + 24 for the half-slate prefetch.  Requesting the WHOLE next slate a slate ahead (48 registers through
+// backward's working set ~45, + 16 for the prefetch of a third of the next slate (FC_NPRE).  Requesting the WHOLE next slate a slate ahead (48 registers through
 // the backward; forward reordered K-step-outer so that the W1 fragments stream) was built in round 4 and spills 120-330 registers --
 // the second half of a slate's loads stays exposed at the top of its iteration.
 //
@@ -53,9 +53,13 @@ constexpr int FC_NKS = 5;                             // K-steps of 32 features 
 constexpr int FC_NFB = 9;                             // 16-feature blocks (weight gradient)
 constexpr int FC_NLD = 12;                            // float4 loads per thread and slate at the largest shape (768 threads)
 #ifndef LTRX_FC_NPRE
-#define LTRX_FC_NPRE 6
+#define LTRX_FC_NPRE 4
 #endif
-constexpr int FC_NPRE = LTRX_FC_NPRE;                 // ... of which this many are requested one slate ahead
+// ... of which this many are requested one slate ahead.  Round 5 sweep (tools/lab/lib_variant.sh -DLTRX_FC_NPRE=n, tools/fcstep_check.py
+// --timing-only, two interleaved rounds on one box; us per step at 256 / 2048 slates): n = 1: 35.4 / 169, 2: 34.8 / 167, 3: 34.3 / 167,
+// 4: 35.0 / 164, 5: 36.6 / 171, 6 (rounds 4): 38.1 / 174, 8: 38.6 / 178, 9: 39.8 / 181 -- every float4 held across the slate costs four of the
+// 168 registers, and beyond a third of the slate the spills it causes (13-54 VGPRs at n = 8) cost more than the latency it hides.
+constexpr int FC_NPRE = LTRX_FC_NPRE;
 constexpr size_t FC_SMEM = 2 * (size_t)FC_PLANE + (size_t)(FC_MAXHB + 3) * FC_ROWS * sizeof(float);
 
 #define FC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
