@@ -14,12 +14,12 @@ mask = torch.zeros(B, L, dtype=torch.uint8, device="cuda")
 P = LB.ptr
 for _ in range(3):
     LB.check(lib.ltrx_mha_fwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(mask), B, L, h, dk, 3 * d, P(o), d, P(lse), 0.0, 0,
-                              None, None, None, None), "fwd")
+                              None, None, None, 1, None), "fwd")
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * (8 * 40 * 6))()
+buf = (ctypes.c_ulonglong * (8 * 40 * 8))()
 raw.ltrx_debug_mha_stamps.argtypes = [ctypes.c_void_p]
 assert raw.ltrx_debug_mha_stamps(buf) == 0
-s = [[[buf[(w * 40 + k) * 6 + p] for p in range(6)] for k in range(40)] for w in range(8)]
+s = [[[buf[(w * 40 + k) * 8 + p] for p in range(8)] for k in range(40)] for w in range(8)]
 t0 = min(s[w][32][0] for w in range(8))
 for w in (0, 3, 4, 7):
     print("wave %d: start +%d, end(before stores) +%d, end +%d cycles" % (w, s[w][32][0] - t0, s[w][33][0] - t0, s[w][34][0] - t0))
