@@ -1,7 +1,7 @@
 """worker of test_sharded_fit_with_uneven_last_batch_equals_one_rank (2 ranks on one GPU, gloo): the drop-in epoch loop
 ``allrank_amd.fit.fit`` (reference signature, allrank/training/train_utils.py:78-147) on 33 slates with a global batch of 16 --
 batches of 16 / 16 / 1 slates, i.e. the last batch gives rank 0 one slate and rank 1 none (DataLoader drop_last=False,
-allrank/data/dataset_loading.py:245) -- against the same loop on one rank (``--ref``: a plain single process, run first by the test):
+allrank/data/dataset_loading.py:245); the validation pass is sharded the same way (17 slates: 16 + 1, round 5) -- against the same loop on one rank (``--ref``: a plain single process, run first by the test):
 same per-epoch training loss (the reference's loss on the gathered batch) and the same trained weights."""
 import os
 import sys
@@ -69,7 +69,7 @@ def main():
     mode, path = sys.argv[1], sys.argv[2]
     torch.cuda.set_device(0)
     L, F = 30, 20
-    tr, va = data(33, L, F, 1), data(16, L, F, 2)
+    tr, va = data(33, L, F, 1), data(17, L, F, 2)     # validation: batches of 16 / 1 -> the sharded pass gives rank 1 an EMPTY block of the last one
     jobs = ("approxNDCGLoss", "neuralNDCG")
     if mode == "--ref":
         out = {}
