@@ -326,8 +326,13 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
                 loss = trainer.step(xs, ys, ids, global_batch=real_glob)
                 scores, labels = trainer.scores[:real], trainer.y_cur[:real]
             else:
+                if real == 0:
+                    # (sharded: this rank's block of a short last batch is empty -- the step still has to run, its gradient all-reduce
+                    #  is a collective: one fully padded slate, i.e. zero loss and zero gradients.  Found by the 2-rank autograd job of
+                    #  tests/dist_fit_worker.py in round 5: the nn.Module forward raised on 0 rows while the peer sat in the all-reduce.)
+                    xb, yb, idx = _pad_batch(xb, yb, idx, 1)
                 loss = trainer.step(xb, yb, idx, global_batch=real_glob)
-                scores, labels = trainer.last_scores, yb
+                scores, labels = trainer.last_scores[:real], yb[:real]
             tot += loss.detach().float().reshape(()) * real_glob          # (sharded: this rank's share of the global-batch loss)
             num += real
             for name, ats in metrics.items():

@@ -185,6 +185,11 @@ def run_main(main_args, backend=None, devices=None, fit=True):
     import importlib
     from .install import install
     dev = setup(backend, devices)
+    if not fit and _state["world"] > 1:
+        # the reference's own epoch loop (train_utils.py:78-147) has no gradient exchange: N ranks would train N identical replicas on the
+        # whole global batch each -- N times the work for the result of one GPU
+        raise RuntimeError("allrank_amd.launch: --no-fit keeps the reference's epoch loop, which cannot shard a batch over %d ranks; "
+                           "drop --no-fit (allrank_amd.fit.fit shards every batch and all-reduces the gradients) or run one rank" % _state["world"])
     done = install(fit=fit)
     main = importlib.import_module("allrank.main")
     done = install(fit=fit)                          # (main's own `from ... import` names, now that the module exists)

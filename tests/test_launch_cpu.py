@@ -125,3 +125,14 @@ def test_unmodified_main_under_the_launcher_two_ranks(tmp_path):
     one = json.load(open(out1 / "rank0.json"))
     assert one["world"] == 1 and one["train_batch"] == 32 and not one["loaders_rebound"]
     assert one["sums"] == r[0]["sums"]
+
+
+def test_no_fit_is_refused_under_several_ranks():
+    """the reference's epoch loop has no gradient exchange: --no-fit with more than one rank would train N identical replicas"""
+    from allrank_amd import launch
+    launch._state.update(world=2, device=__import__("torch").device("cpu"))
+    try:
+        with pytest.raises(RuntimeError, match="no-fit"):
+            launch.run_main(["--job-dir", "x"], fit=False)
+    finally:
+        launch._state.update(world=1, device=None)
