@@ -6,7 +6,7 @@ exactly the objects ``allrank_amd.install(fit=True)`` binds into an unmodified m
 (main.py:66-67: global batch = world x batch_size, sampler on torch's global generator as in dataset_loading.py:245),
 ``launch.CustomDataParallel`` (main.py:76-78, taken when FORCE_WRAP) and ``allrank_amd.fit.fit`` (main.py:90).
 
-    dist_main_worker.py OUT.pt BATCH_SIZE LOSS FORCE_WRAP
+    dist_main_worker.py OUT.pt BATCH_SIZE LOSS FORCE_WRAP [fc_only]
 Under the launcher's environment (2 ranks, gloo, both on GPU 0): the sharded run; rank 0 writes OUT.pt.  Without: the 1-rank run.
 """
 import json
@@ -25,12 +25,15 @@ import torch  # noqa: E402
 
 def main():
     out_path, batch_size, loss_name, force_wrap = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    fc_only = len(sys.argv) > 5 and sys.argv[5] == "fc_only"         # BASELINE configs[0]: transformer null -> the slate-resident FC step
     from torch import optim
     from allrank_amd import fit as EF, launch, losses
     from allrank_amd.model import make_model
     from tests.test_gpu_main_sequence import CONFIG, _dummy_libsvm, _load
     cfg = json.loads(json.dumps(CONFIG))
     cfg["training"]["epochs"] = 3
+    if fc_only:
+        cfg["model"]["transformer"] = None
     launch.setup()                                                     # install(fit=True) does this first
     try:
         torch.manual_seed(42)                                          # main.py:36-38
@@ -66,7 +69,7 @@ def main():
                                 **cfg["training"])
             finally:
                 EF.log.info = orig
-            assert EF.last_run["engine"] == "fused", EF.last_run
+            assert EF.last_run["engine"] == "fused" and bool(EF.last_run["fcstep"]) == fc_only, EF.last_run
             saved = torch.load(os.path.join(tmp, "model.pkl"), map_location="cpu") if launch.rank() == 0 else None
         if launch.rank() == 0:
             torch.save(dict(losses=epoch_losses, weights=saved, world=launch.world_size(), device=str(dev),
