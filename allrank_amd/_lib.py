@@ -56,6 +56,7 @@ SIGNATURES = {
     "ltrx_relu_bwd": (_i, [_vp, _vp, _sz, _f, _vp]),
     "ltrx_dropout_apply": (_i, [_vp, _vp, _sz, _f, ctypes.c_uint32, _vp, _vp]),
     "ltrx_bump_u32": (_i, [_vp, _vp]),
+    "ltrx_first_nonfinite": (_i, [_vp, _sz, _vp, _i, _vp, _vp]),
     "ltrx_gather_rows": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp]),
     "ltrx_packed_row_index": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ltrx_scatter_rows": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp]),

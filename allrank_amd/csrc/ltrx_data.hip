@@ -6,7 +6,9 @@
 //       len >= L : L distinct positions, uniformly at random, in random order   (np.random.choice(len, L, replace=False), :70)
 //                  if the sample holds no relevant item (label sum 0) and the slate's label sum is exactly 1, the last slot
 //                  is replaced by argmax(labels) (:72-74); if the slate has other relevance, the draw is repeated (:75-76)
-//     One workgroup per slate: a counter-based key per item (hash of seed, slate, attempt, position), the rank of every key by
+//     One workgroup per slate: a counter-based key per item (hash of seed, slate ID IN THE DATASET, attempt, position -- round 6:
+//     not the row inside the batch, so a rank that assembles only its block of a global batch draws what a one-rank run draws
+//     for the same slate), the rank of every key by
 //     counting in LDS (ties by position) -- the L largest keys in descending order are a uniform random L-subset in uniform
 //     random order -- label sums by workgroup reductions.  No host round trip, no data-dependent launch sizes.
 //   ltrx_assemble_batch : xb[b][l][:] = x_items[offsets[slate_b] + pos] (zeros for pos = -1), yb = label or -1,
@@ -78,7 +80,7 @@ __global__ void __launch_bounds__(256) ltrx_fixlength_positions_kernel(const int
   }
   const int argmax_pos = sh_arg;
   for (int attempt = 0; attempt < 64; ++attempt) {
-    const uint32_t sd = mix32(seed_lo ^ mix32(seed_hi + 0x9E3779B9u * (uint32_t)(b + 1)) ^ (0x85EBCA6Bu * (uint32_t)attempt));
+    const uint32_t sd = mix32(seed_lo ^ mix32(seed_hi + 0x9E3779B9u * (uint32_t)(s + 1) + 0x7F4A7C15u * (uint32_t)((uint64_t)s >> 32)) ^ (0x85EBCA6Bu * (uint32_t)attempt));
     for (int i = threadIdx.x; i < len; i += blockDim.x) keys[i] = mix32(sd ^ (0xC2B2AE35u * (uint32_t)(i + 1)));
     __syncthreads();
     float ysel = 0.f;

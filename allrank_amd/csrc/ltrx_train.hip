@@ -695,3 +695,62 @@ extern "C" int ltrx_clip_grad_norm_scale(const float* grads, size_t n, float max
   LTRX_LAUNCH_CHECK();
   return LTRX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Finiteness check of the explicit step (round 6).  main.py:89 wraps fit() in torch.autograd.detect_anomaly() when
+// config.detect_anomaly is set; the explicit step has no autograd graph for that mode to watch, so allrank_amd.fit checks the loss
+// and the flat gradient buffer itself: ONE launch over the buffer, result = (index of the first segment -- parameter tensor, in
+// flat-buffer order -- that holds a NaN / Inf, 0x7fffffff if none; number of non-finite elements), read back with one host sync.
+// HBM-bound: 4 B per element read once with 16-byte loads (25.5 MB at config 3: ~5 us).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ltrx_first_nonfinite_kernel(const float* __restrict__ buf, size_t n,
+                                                                   const int64_t* __restrict__ seg_start, int n_seg,
+                                                                   int* __restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  int first = 0x7fffffff, count = 0;
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i + 4 <= n) {
+      const float4 q = *reinterpret_cast<const float4*>(buf + i);
+      v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+    } else {
+      for (size_t k = 0; i + k < n; ++k) v[k] = buf[i + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // NaN / Inf: exponent field all ones
+      if ((__float_as_uint(v[k]) & 0x7F800000u) == 0x7F800000u) {
+        ++count;
+        // the segment of element i + k: the last start <= i + k (binary search over the sorted starts)
+        int lo = 0, hi = n_seg - 1;
+        const int64_t e = (int64_t)(i + k);
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (seg_start[mid] <= e) lo = mid;
+          else hi = mid - 1;
+        }
+        first = min(first, lo);
+      }
+    }
+  }
+  if (count) {
+    atomicMin(&out[0], first);
+    atomicAdd(&out[1], count);
+  }
+}
+
+__global__ void ltrx_first_nonfinite_init_kernel(int* __restrict__ out) {
+  out[0] = 0x7fffffff;
+  out[1] = 0;
+}
+
+extern "C" int ltrx_first_nonfinite(const float* buf, size_t n, const int64_t* seg_start, int n_seg, int* out, ltrx_stream_t stream) {
+  if (!buf || !seg_start || !out || n == 0 || n_seg <= 0) return LTRX_EINVAL;
+  if ((uintptr_t)buf & 15) return LTRX_EINVAL;
+  hipLaunchKernelGGL(ltrx_first_nonfinite_init_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, out);
+  const size_t quads = (n + 3) / 4;
+  const unsigned grid = (unsigned)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048);
+  hipLaunchKernelGGL(ltrx_first_nonfinite_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, buf, n, seg_start, n_seg, out);
+  LTRX_LAUNCH_CHECK();
+  return LTRX_OK;
+}

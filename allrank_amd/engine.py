@@ -87,7 +87,7 @@ class FusedTrainer(object):
                  optimizer="Adam", weight_decay=0.0, momentum=0.0, nesterov=False,
                  use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None, compact=False,
                  weight_images=True, fc_step=True, group_wgrad=True, relu_bits=True, pad_input=True, overlap_wgrad=False,
-                 act_images=False):
+                 act_images=False, force_dist=False):
         """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
         products), "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs), or "bf16" -- the THROUGHPUT mode: one bf16
         product per contraction in the dense projections AND in attention (fp32 storage, accumulation, LayerNorm, softmax,
@@ -169,6 +169,11 @@ class FusedTrainer(object):
         self.optimizer, self.weight_decay = optimizer, float(weight_decay)
         self.momentum, self.nesterov = float(momentum), bool(nesterov)
         self.world, self.group = world_size, group
+        # the step takes its SHARDED form (global divisor through shard_context, bucketed all-reduce of the flat gradient behind the
+        # backward, normaliser all-reduces, hipGraph segments cut at every collective) when there is more than one rank -- or when
+        # ``force_dist`` asks for it on a one-rank group: the whole collective path, RCCL included, on the one GPU a build box has
+        # (bench.py --force-dist, tests/test_gpu_rccl.py).  Needs an initialised process group.
+        self.sharded = bool(world_size > 1 or force_dist)
         if not isinstance(model, LTRModel) or not isinstance(model.input_layer, FCModel):
             raise NotImplementedError("FusedTrainer needs an allrank_amd LTRModel with an FCModel input block")
         fc = model.input_layer
@@ -701,7 +706,7 @@ class FusedTrainer(object):
         on the process group's own stream; ``_full`` waits for all of them before the optimizer step).  While a step is being
         captured the collective is not issued but handed to ``_seg_break``: it ends the hipGraph segment recorded so far and
         is launched between that segment's replay and the next one's."""
-        if self.world > 1 and self.comm_enabled:
+        if self.sharded and self.comm_enabled:
             import torch.distributed as dist
             lo, hi = self._buckets[k]
             if hi > lo:
@@ -717,7 +722,7 @@ class FusedTrainer(object):
             for w_ in self._works:                               # bucketed gradient all-reduces launched during the backward
                 w_.wait()
             self._works = []
-        if self._seg_break is not None and self.world > 1 and self.comm_enabled:
+        if self._seg_break is not None and self.sharded and self.comm_enabled:
             self._seg_break(wait)
         else:
             wait()
@@ -1121,6 +1126,21 @@ class FusedTrainer(object):
         self._refresh_transposes()
         return loss
 
+    def first_nonfinite(self):
+        """(name of the first parameter tensor -- flat-buffer order -- whose gradient of the LAST step holds a NaN / Inf, number of
+        non-finite gradient elements), or (None, 0): the finiteness check that stands in for torch.autograd.detect_anomaly() on a
+        step without an autograd graph (main.py:89).  One launch over the flat gradient buffer, one host sync."""
+        if getattr(self, "_nf_seg", None) is None:
+            names = {id(p): n for n, p in self.model.named_parameters()}
+            self._nf_names = [names.get(id(p), "?") for p in self._order]
+            self._nf_seg = torch.tensor([self._pv[id(p)][0] for p in self._order], dtype=torch.int64, device=self.dev)
+            self._nf_out = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        P = self.LB.ptr
+        self.LB.check(self.lib.ltrx_first_nonfinite(P(self.flat_g), self.nflat, P(self._nf_seg), len(self._order), P(self._nf_out),
+                                                    self._st()), "first_nonfinite")
+        first, count = (int(v) for v in self._nf_out.cpu())
+        return (self._nf_names[first], count) if count else (None, 0)
+
     def set_lr(self, lr):
         """change the learning rate (per-epoch scheduler step): the rate is a launch argument of the Adam kernel, so a
         captured graph is dropped and re-captured on the next step"""
@@ -1161,7 +1181,7 @@ class FusedTrainer(object):
             idx = torch.nonzero(valid.reshape(-1)).reshape(-1)    # (host sync: the row count sizes every launch)
             n = int(idx.numel())
             self.idx[:n] = idx
-        if n == 0 and self.world <= 1:
+        if n == 0 and not self.sharded:
             raise ValueError("FusedTrainer(compact=True): the batch has no valid item")
         # (sharded: a rank whose block of a short last batch is empty -- 1 slate on 2 ranks -- still runs the step on 32 all-zero
         #  alignment rows: zero loss, zero gradient, and every collective of the step is entered by every rank)
@@ -1248,7 +1268,7 @@ class FusedTrainer(object):
                 # stream capture): the eager step is the same arithmetic (tests/dist_equiv_worker.py), only with launch overhead.  Any
                 # other error -- a failed LB.check, a shape error, out of memory -- is a bug in the captured path and is raised.
                 msg = str(exc)
-                if self.world == 1 or not any(t in msg for t in ("capture", "Capture", "hipErrorStreamCapture", "cudaErrorStreamCapture")):
+                if not self.sharded or not any(t in msg for t in ("capture", "Capture", "hipErrorStreamCapture", "cudaErrorStreamCapture")):
                     raise
                 import warnings
                 warnings.warn("allrank_amd: hipGraph capture of the sharded step failed (%r); running eagerly" % (exc,))
@@ -1286,7 +1306,7 @@ class FusedTrainer(object):
         LB.require_device(xb, yb)
         self.y_cur = yb
         div = float(global_batch if global_batch is not None else self.B * self.world)
-        fused_adam = self.world == 1 and not self.clip
+        fused_adam = not self.sharded and not self.clip
         hid = P(self.fc_out[0]) if self.keep_fc_out else None
         if fused_adam:
             opt = (P(self.flat_m), P(self.flat_v), P(self.step_count), float(self.lr), float(self.betas[0]), float(self.betas[1]),
@@ -1301,7 +1321,7 @@ class FusedTrainer(object):
             LB.check(self.lib.ltrx_fc_listnet_step(P(xb), P(yb), *self._fc_a, div, self._fc_b[0], dsc, hid, P(self.loss.loss), P(self.flat_g),
                                                    *opt, P(self._fc_ws), self._st()), "fc_listnet_step")
         if not fused_adam:
-            if self.world > 1 and self.comm_enabled:
+            if self.sharded and self.comm_enabled:
                 import torch.distributed as dist
                 dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
             self._adam()
@@ -1309,7 +1329,7 @@ class FusedTrainer(object):
         return self.loss.loss
 
     def _eager(self):
-        with sharding.shard_context(int(self._divisor), self.group) if self.world > 1 else _null():
+        with sharding.shard_context(int(self._divisor), self.group) if self.sharded else _null():
             return self._full()
 
     @property
@@ -1345,7 +1365,7 @@ class FusedTrainer(object):
             self._seg_break = seg_break
             ok = False
             try:
-                with sharding.shard_context(int(self._divisor), self.group, deferred=seg_break) if self.world > 1 else _null():
+                with sharding.shard_context(int(self._divisor), self.group, deferred=seg_break) if self.sharded else _null():
                     self._graph_loss = self._full()
                 ok = True
             finally:

@@ -20,7 +20,20 @@ What changes (all outside the arithmetic of a step):
   * the validation pass runs through ``FusedTrainer.score`` (the forward half of the explicit step, dropout off, its own hipGraph)
     instead of the nn.Module forward;
   * train metrics come from the scores of the training forward itself instead of a second full pass over ``train_dl`` in train()
-    mode (train_utils.py:99; same mode, same data, SURVEY.md §8f row 2);
+    mode (train_utils.py:99; same mode, same data).  ``train_metrics="reference"`` (or the environment variable
+    ALLRANK_AMD_TRAIN_METRICS=reference -- main.py passes only config.training's keys) runs the reference's second pass instead: one
+    pass over ``train_dl`` per metric name with the END-of-epoch weights, so ``experiment_result.json``'s ``train_metrics/*`` are the
+    reference's numbers (dropout is off in that pass; the reference leaves it on, so with dropout > 0 its numbers carry that noise);
+  * the loaders' draws from torch's global generator stay in step with the reference's loop: the reference iterates ``train_dl``
+    1 + (number of metric names) times and ``valid_dl`` 1 + (number of metric names) times per epoch (train_utils.py:95-107, :36-43),
+    each iteration drawing a worker base seed and -- shuffled -- a sampler seed; the passes skipped here are replaced by ``_burn``, so
+    under main.py:36-38's seeds epoch e trains on the reference's batches in the reference's order;
+  * batches that are already on the device pass straight through (``allrank_amd.data.DeviceLoader``: the training set lives in HBM,
+    install() binds it behind main.py:57-68); under a process group such a loader yields only this rank's block of each global
+    batch (``ShardBatch``) and nothing is sliced here;
+  * ``config.detect_anomaly`` (main.py:89; the explicit step has no autograd graph for torch's anomaly mode to watch) or
+    LTRX_CHECK_FINITE=1: every step's loss and flat gradient buffer are checked for non-finite values (one fused reduction, one
+    host sync per step) and the first offending parameter tensor is named in the error;
   * the last, short batch of an epoch (DataLoader drop_last=False) is topped up with fully padded slates for the static-shape step
     and its loss is normalised by the real slate count;
   * under an initialised ``torch.distributed`` group every rank takes its contiguous block of each global batch -- training AND
@@ -30,12 +43,14 @@ What changes (all outside the arithmetic of a step):
 import functools
 import logging
 import os
+import time
 
 import numpy as np
 import torch
 
 from . import losses as E
 from . import metrics as EM
+from .data import ShardBatch
 from .engine import FusedTrainer, Trainer, PADDED_Y_VALUE
 from .parallel import shard_slates
 
@@ -172,6 +187,8 @@ def _batch_shape(dl):
     """(slates per batch, slate length) of a loader without consuming a batch: DataLoader.batch_size and the shape of one dataset
     item ([L, F] features, dataset_loading.py:19-29); loaders that do not expose them are asked for their first batch instead.
     Also returns the fraction of valid (non-padded) slots over a sample of the set (the auto choice of variable-length execution)."""
+    if hasattr(dl, "batch_shape"):                  # allrank_amd.data.DeviceLoader knows all three without touching a batch
+        return dl.batch_shape()
     try:
         bsz, ds = int(dl.batch_size), dl.dataset
         # The probe indexes dataset items; the reference's FixLength transform draws from the GLOBAL numpy generator when it
@@ -189,17 +206,60 @@ def _batch_shape(dl):
         return int(first[0].shape[0]), int(first[0].shape[1]), float((first[1] != PADDED_Y_VALUE).float().mean())
 
 
-def _check_same_batch(xb, yb, world):
+def _check_same_batch(xb, yb, world, batch=None):
     """sharded runs: every rank must see the SAME global batch for shard_slates to partition it (the reference's DataLoader
-    shuffles per process; give the ranks one sampler seed) -- checked on the first batch with an all-gathered checksum"""
+    shuffles per process; give the ranks one sampler seed) -- checked on the first batch with an all-gathered checksum.  A
+    ``ShardBatch`` that is already this rank's block carries the checksum of the global batch's slate ids instead."""
     import torch.distributed as dist
-    chk = torch.stack([xb.double().sum(), yb.double().sum(), torch.tensor(float(xb.shape[0]), device=xb.device, dtype=torch.float64)])
+    if batch is not None:
+        chk = torch.tensor([float(batch.order_tag & 0xFFFFFF), float(batch.order_tag >> 24), float(batch.global_slates)], device=xb.device,
+                           dtype=torch.float64)
+    else:
+        chk = torch.stack([xb.double().sum(), yb.double().sum(), torch.tensor(float(xb.shape[0]), device=xb.device, dtype=torch.float64)])
     allc = [torch.empty_like(chk) for _ in range(world)]
     dist.all_gather(allc, chk)
     if any(not torch.equal(c, allc[0]) for c in allc):
         raise RuntimeError("allrank_amd.fit: the ranks received different first batches -- under torch.distributed every rank must "
                            "iterate the same global batches (same DataLoader sampler seed / shuffle order); rank r trains on its "
                            "contiguous block of each of them")
+
+
+def _my_block(batch, loader, rank, world):
+    """(xb, yb, idx, slates in the global batch, the ShardBatch if the loader has already cut this rank's block) of one loader item"""
+    xb, yb, idx = batch
+    pre = isinstance(batch, ShardBatch) and world > 1 and getattr(loader, "world", 1) == world
+    n_glob = batch.global_slates if isinstance(batch, ShardBatch) else int(xb.shape[0])
+    if world > 1 and not pre:
+        a, b = shard_slates(n_glob, rank, world)
+        xb, yb, idx = xb[a:b], yb[a:b], idx[a:b]
+    return xb, yb, idx, n_glob, (batch if pre else None)
+
+
+def _host_lengths(batch, trainer, real, pre, world):
+    """valid items per slate of this rank's block as HOST integers, topped up to the trainer's batch -- what variable-length
+    execution needs to size its launches without a device round trip (FusedTrainer._pack).  A DeviceLoader knows them (the slate
+    lengths of the resident set); any other loader: None (the step counts the valid items on the device, one host sync)."""
+    lens = getattr(batch, "lengths", None)
+    if lens is None or not trainer.compact or not (pre is not None or world == 1) or int(lens.numel()) != real:
+        return None
+    return torch.cat([lens, lens.new_zeros(trainer.B - real)]) if real < trainer.B else lens
+
+
+def _burn(dl, times=1):
+    """Consume what ``times`` iterations over ``dl`` draw from torch's global generator without loading a batch: the worker base
+    seed every ``iter(DataLoader)`` draws and the seed a RandomSampler draws at its first index (torch/utils/data/dataloader.py,
+    sampler.py) -- the passes of the reference's epoch loop that this loop does not make (module docstring)."""
+    from torch.utils.data import DataLoader
+    for _ in range(times):
+        if hasattr(dl, "burn"):
+            dl.burn()
+        elif isinstance(dl, DataLoader) and dl.batch_sampler is not None:
+            iter(DataLoader(dl.dataset, batch_sampler=dl.batch_sampler, num_workers=0, generator=dl.generator))   # the base seed (no
+            #                                                                                   worker is started, no item is loaded)
+            next(iter(dl.sampler), None)                                                     # the sampler's seed / permutation draw
+        else:
+            return False
+    return True
 
 
 def _evaluate(model, loss_func, dl, device, metrics, trainer=None, world=1, rank=0):
@@ -214,16 +274,14 @@ def _evaluate(model, loss_func, dl, device, metrics, trainer=None, world=1, rank
     from . import sharding
     tot, num = torch.zeros((), device=device), 0
     acc = {name: None for name in metrics}
+    pf = dl if isinstance(dl, _Prefetcher) else _Prefetcher(dl, device)
     with torch.no_grad():
-        for xb, yb, idx in (dl if isinstance(dl, _Prefetcher) else _Prefetcher(dl, device)):
-            n_glob = int(xb.shape[0])
-            if world > 1:
-                a, b = shard_slates(n_glob, rank, world)
-                xb, yb, idx = xb[a:b], yb[a:b], idx[a:b]
+        for batch in pf:
+            xb, yb, idx, n_glob, pre = _my_block(batch, pf.loader, rank, world)
             n = int(xb.shape[0])
             if trainer is not None and n <= trainer.B and tuple(xb.shape[1:2]) == (trainer.L,):
                 xs, ys, ids = _pad_batch(xb, yb, idx, trainer.B)
-                sc = trainer.score(xs, ys, ids)[:n]
+                sc = trainer.score(xs, ys, ids, lengths=_host_lengths(batch, trainer, n, pre, world))[:n]
                 # (an empty shard of a short last batch still enters the loss -- its normaliser all-reduce is a collective -- with
                 #  one fully padded slate: value 0, count 0)
                 out, yl = trainer.scores_raw[:max(n, 1)], ys[:max(n, 1)]
@@ -234,7 +292,9 @@ def _evaluate(model, loss_func, dl, device, metrics, trainer=None, world=1, rank
                 out = model(xb, mask, idx)
                 sc = (out if out.dim() == 2 else model.score(xb, mask, idx))[:n]
                 yl = yb
-            if world > 1:
+            if loss_func is None:                                     # (metrics only: the reference's compute_metrics pass)
+                share = tot.new_zeros(())
+            elif world > 1:
                 with sharding.shard_context(n_glob):
                     share = loss_func(out, yl).detach().float()
             else:
@@ -259,11 +319,37 @@ def _evaluate(model, loss_func, dl, device, metrics, trainer=None, world=1, rank
     return float(stats[0]) / n_all, out
 
 
+def _assert_finite(trainer, fused, loss, epoch, step, model):
+    """the anomaly switch of the explicit step (main.py:89): raise on the first step whose loss or gradients are not finite and
+    name the first offending parameter tensor.  The fused step has already applied the update when this runs (the check reads the
+    gradient buffer the step left behind) -- the run stops here either way."""
+    if fused:
+        name, count = trainer.first_nonfinite()
+    else:
+        name, count = None, 0
+        for n, p in model.named_parameters():                      # (autograd step: flat.zero() has run; check the weights it left)
+            bad = int((~torch.isfinite(p.detach())).sum().item())
+            if bad and name is None:
+                name = n
+            count += bad
+    loss_ok = bool(torch.isfinite(loss.detach()).all().item())
+    if name is not None or not loss_ok:
+        raise FloatingPointError(
+            "allrank_amd.fit (detect_anomaly / LTRX_CHECK_FINITE): step %d of epoch %d produced %s%s -- first offending parameter "
+            "tensor: %s (%d non-finite %s element(s) in all).  Usual causes: non-finite input features, a learning rate that "
+            "diverged, a slate with no valid item in a loss that divides by its normaliser."
+            % (step, epoch, "a non-finite loss" if not loss_ok else "a finite loss", "" if name is None else " and non-finite values",
+               name, count, "gradient" if fused else "weight"))
+
+
 def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, config, gradient_clipping_norm, early_stopping_patience,
-        device, output_dir, tensorboard_output_path, use_fused=True, compact=None, gemm="split_bf16"):
-    """Same positional / keyword arguments as the reference ``fit``; ``use_fused`` / ``compact`` / ``gemm`` are extensions
-    (compact=None: variable-length execution when less than 80 % of the first batch's slots are valid items; gemm: the arithmetic
-    of the fused step, "split_bf16" = fp32-class parity arithmetic, "bf16" = the one-product throughput mode, see FusedTrainer)."""
+        device, output_dir, tensorboard_output_path, use_fused=True, compact=None, gemm="split_bf16", train_metrics=None,
+        check_finite=None):
+    """Same positional / keyword arguments as the reference ``fit``; ``use_fused`` / ``compact`` / ``gemm`` / ``train_metrics`` /
+    ``check_finite`` are extensions (compact=None: variable-length execution when less than 80 % of the first batch's slots are valid
+    items; gemm: the arithmetic of the fused step, "split_bf16" = fp32-class parity arithmetic, "bf16" = the one-product throughput
+    mode, see FusedTrainer; train_metrics: "fused" (default) = from the training forward, "reference" = the reference's second pass,
+    train_utils.py:99; check_finite: None = ``config.detect_anomaly`` or LTRX_CHECK_FINITE=1, see the module docstring)."""
     import torch.distributed as dist
     device = torch.device(device)
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
@@ -280,6 +366,11 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
                         n_vis, device, max(n_vis, 2))
     metrics = dict(config.metrics)
     val_metric = getattr(config, "val_metric", None)
+    train_metrics_mode = (train_metrics or os.environ.get("ALLRANK_AMD_TRAIN_METRICS") or "fused").lower()
+    if train_metrics_mode not in ("fused", "reference"):
+        raise ValueError("train_metrics must be 'fused' or 'reference', got %r" % (train_metrics_mode,))
+    if check_finite is None:
+        check_finite = bool(getattr(config, "detect_anomaly", False)) or os.environ.get("LTRX_CHECK_FINITE", "0") not in ("", "0")
     writer = _tensorboard(tensorboard_output_path) if tensorboard_output_path else None
     num_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
     early_stop = _EarlyStop(early_stopping_patience)
@@ -308,22 +399,22 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
     epoch, train_metrics, val_metrics = -1, {}, {}
     train_pf, valid_pf = _Prefetcher(train_dl, device), _Prefetcher(valid_dl, device)     # one per loader: stream and staging sets persist
     checked = world == 1
+    last_run["epoch_log"] = []            # per epoch: wall seconds of the training / validation pass, slates and slots trained on
+    n_steps = 0
     for epoch in range(epochs):
         model.train()
-        tot, num = torch.zeros((), device=device), 0
+        t_epoch = time.perf_counter()
+        tot, num, slots = torch.zeros((), device=device), 0, 0
         tm = {name: None for name in metrics}
-        for xb, yb, idx in train_pf:
-            real_glob = int(xb.shape[0])
+        for batch in train_pf:
+            xb, yb, idx, real_glob, pre = _my_block(batch, train_dl, rank, world)
             if not checked:
-                _check_same_batch(xb, yb, world)
+                _check_same_batch(batch[0], batch[1], world, pre)
                 checked = True
-            if world > 1:
-                a, b = shard_slates(real_glob, rank, world)
-                xb, yb, idx = xb[a:b], yb[a:b], idx[a:b]
             real = int(xb.shape[0])
             if fused:
                 xs, ys, ids = _pad_batch(xb, yb, idx, trainer.B)
-                loss = trainer.step(xs, ys, ids, global_batch=real_glob)
+                loss = trainer.step(xs, ys, ids, global_batch=real_glob, lengths=_host_lengths(batch, trainer, real, pre, world))
                 scores, labels = trainer.scores[:real], trainer.y_cur[:real]
             else:
                 if real == 0:
@@ -333,16 +424,22 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
                     xb, yb, idx = _pad_batch(xb, yb, idx, 1)
                 loss = trainer.step(xb, yb, idx, global_batch=real_glob)
                 scores, labels = trainer.last_scores[:real], yb[:real]
+            n_steps += 1
+            if check_finite:
+                _assert_finite(trainer, fused, loss, epoch, n_steps, model)
             tot += loss.detach().float().reshape(()) * real_glob          # (sharded: this rank's share of the global-batch loss)
             num += real
-            for name, ats in metrics.items():
-                # (a rank whose shard of a short last batch is empty contributes zeros -- every rank keeps the same stats layout)
-                v = getattr(EM, name)(scores, labels, ats=ats).sum(0) if real > 0 else torch.zeros(len(ats), device=device)
-                tm[name] = v if tm[name] is None else tm[name] + v
+            slots += real * int(yb.shape[1])
+            if train_metrics_mode == "fused":
+                for name, ats in metrics.items():
+                    # (a rank whose shard of a short last batch is empty contributes zeros -- every rank keeps the same stats layout)
+                    v = getattr(EM, name)(scores, labels, ats=ats).sum(0) if real > 0 else torch.zeros(len(ats), device=device)
+                    tm[name] = v if tm[name] is None else tm[name] + v
         stats = torch.cat([tot.reshape(1), torch.tensor([float(num)], device=device)] + [tm[n].float() for n in metrics if tm[n] is not None])
         if world > 1:
             dist.all_reduce(stats)
         stats = stats.cpu().numpy()
+        t_train = time.perf_counter() - t_epoch
         n_all = max(stats[1], 1.0)
         train_loss = float(stats[0]) / n_all
         train_metrics, off = {}, 2
@@ -352,9 +449,22 @@ def fit(epochs, model, loss_func, optimizer, scheduler, train_dl, valid_dl, conf
             for at in ats:
                 train_metrics["%s_%d" % (name, at)] = float(stats[off]) / n_all
                 off += 1
+        if train_metrics_mode == "reference":
+            # train_utils.py:99: compute_metrics(config.metrics, model, train_dl, device) -- one more pass over train_dl per metric
+            # name (:46-54), with the end-of-epoch weights, the model still in train() mode
+            train_metrics = {}
+            for name, ats in metrics.items():
+                _, one = _evaluate(model, None, train_pf, device, {name: ats}, trainer if fused else None, world, rank)
+                train_metrics.update({k: float(v) for k, v in one.items()})
+        else:
+            _burn(train_dl, len(metrics))                          # the generator draws of the passes not made (module docstring)
 
         model.eval()
+        t_val = time.perf_counter()
         val_loss, val_metrics = _evaluate(model, loss_func, valid_pf, device, metrics, trainer if fused else None, world, rank)
+        _burn(valid_dl, len(metrics))                              # train_utils.py:107 iterates valid_dl once more per metric name
+        last_run["epoch_log"].append({"train_s": t_train, "val_s": time.perf_counter() - t_val, "slates": int(stats[1]),
+                                      "slots": int(slots)})
 
         lr_now = optimizer.param_groups[0]["lr"]
         if writer is not None:

@@ -57,28 +57,44 @@ def distributed_env(env=None):
     return rank, int(env.get("LOCAL_RANK", rank)), world
 
 
+def _one_gpu_per_rank_view(local_rank, n_visible):
+    """True when this rank sees only ITS OWN GPU: the launcher gave every rank a private HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES
+    (one visible device, several local ranks) -- the rank's GPU is then index 0 whatever its local rank."""
+    try:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    except ValueError:
+        local_world = 1
+    masked = any(os.environ.get(k) not in (None, "") for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"))
+    return n_visible == 1 and masked and (local_world > 1 or local_rank > 0)
+
+
 def _device_of(local_rank, backend, devices=None):
-    """the device of a local rank.  ``devices`` (``--devices 0,0`` / ALLRANK_AMD_DEVICES): explicit GPU index per local rank --
-    several ranks may share one GPU under gloo (RCCL refuses duplicate devices, so that is rejected here with a clear message)."""
+    """the device of a local rank: GPU ``local_rank`` of the visible set; GPU 0 when the launcher masked the set down to this rank's
+    own GPU (per-rank HIP_VISIBLE_DEVICES).  ``devices`` (``--devices 0,0`` / ALLRANK_AMD_DEVICES): explicit GPU index per local rank
+    -- several ranks may share one GPU under gloo (RCCL refuses duplicate devices of one shared visible set, so that is rejected
+    here with a clear message)."""
     if not torch.cuda.is_available():
         return torch.device("cpu")
     n = torch.cuda.device_count()
+    private = _one_gpu_per_rank_view(local_rank, n)
     if devices:
         idx = int(devices[local_rank % len(devices)])
     else:
-        idx = local_rank
+        idx = 0 if private else local_rank
     if idx >= n:
         raise RuntimeError("allrank_amd.launch: local rank %d wants GPU %d but only %d device(s) are visible -- start at most one "
                            "rank per visible GPU, or name the device of every local rank with --devices" % (local_rank, idx, n))
-    if backend == "nccl" and devices and len(set(int(d) for d in devices)) < len(devices):
+    if backend == "nccl" and devices and not private and len(set(int(d) for d in devices)) < len(devices):
         raise RuntimeError("allrank_amd.launch: --devices %s puts several ranks on one GPU; RCCL needs one GPU per rank "
                            "(use --backend gloo for a shared-GPU test run)" % (",".join(str(d) for d in devices),))
     return torch.device("cuda", idx)
 
 
-def setup(backend=None, devices=None, timeout_s=1800):
+def setup(backend=None, devices=None, timeout_s=1800, init=True):
     """Bind this rank's GPU and join the process group the environment announces.  Idempotent; returns the rank's device.
-    With no launcher environment (WORLD_SIZE unset or 1) nothing is initialised and the reference's own device rule applies."""
+    With no launcher environment (WORLD_SIZE unset or 1) nothing is initialised and the reference's own device rule applies.
+    ``init=False`` (what a bare ``install()`` uses): never call ``init_process_group`` -- only ADOPT a group somebody
+    has already initialised with more than one rank (its backend, the current device); returns None otherwise."""
     import datetime
     import torch.distributed as dist
     if _state["device"] is not None:
@@ -87,7 +103,7 @@ def setup(backend=None, devices=None, timeout_s=1800):
     backend = backend or os.environ.get("ALLRANK_AMD_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if devices is None and os.environ.get("ALLRANK_AMD_DEVICES"):
         devices = [d for d in os.environ["ALLRANK_AMD_DEVICES"].split(",") if d != ""]
-    if envd is None:
+    if envd is None or not init:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             # a group somebody else initialised (a host program embedding the engine): adopt it, current device as it is
             rank, world = dist.get_rank(), dist.get_world_size()
@@ -143,16 +159,14 @@ def CustomDataParallel(model, *args, **kwargs):
 
 
 def create_data_loaders(train_ds, val_ds, num_workers, batch_size):
-    """allrank/data/dataset_loading.py:230-248 with the number of processing units = the world size: train loader shuffled,
-    validation loader not, drop_last False, both with ``world x batch_size`` slates per (global) batch.  The sampler draws from
-    torch's global generator exactly as the reference's loader does, so identically seeded ranks (main.py:36-38) iterate the
-    same global batches, and an N-rank run sees the batches a 1-rank run with ``batch_size = N x batch_size`` sees."""
-    from torch.utils.data import DataLoader
-    total = max(1, _state["world"]) * int(batch_size)
-    log.info("allrank_amd.launch: total batch size is %d (%d rank(s) x %d)", total, _state["world"], batch_size)
-    train_dl = DataLoader(train_ds, batch_size=total, num_workers=num_workers, shuffle=True)
-    val_dl = DataLoader(val_ds, batch_size=total, num_workers=num_workers, shuffle=False)
-    return train_dl, val_dl
+    """allrank/data/dataset_loading.py:230-248 with the number of processing units = the world size (``allrank_amd.data``'s rule):
+    train loader shuffled, validation loader not, drop_last False, ``world x batch_size`` slates per GLOBAL batch.  Device-resident
+    datasets (``allrank_amd.data.load_libsvm_dataset``, bound by install() when a GPU is present) get a DeviceLoader: the batch order of
+    the reference's loader under the same seeds, each rank assembling only ITS block of every global batch in HBM.  Host datasets keep
+    the reference's torch DataLoader: its sampler draws from torch's global generator exactly as the reference's does, so identically
+    seeded ranks (main.py:36-38) iterate the same global batches and ``fit`` slices each rank's block out of them."""
+    from . import data as ED
+    return ED.create_data_loaders(train_ds, val_ds, num_workers, batch_size)
 
 
 def _private_job_dir(argv):
@@ -190,9 +204,8 @@ def run_main(main_args, backend=None, devices=None, fit=True):
         # whole global batch each -- N times the work for the result of one GPU
         raise RuntimeError("allrank_amd.launch: --no-fit keeps the reference's epoch loop, which cannot shard a batch over %d ranks; "
                            "drop --no-fit (allrank_amd.fit.fit shards every batch and all-reduces the gradients) or run one rank" % _state["world"])
-    done = install(fit=fit)
-    main = importlib.import_module("allrank.main")
-    done = install(fit=fit)                          # (main's own `from ... import` names, now that the module exists)
+    main = importlib.import_module("allrank.main")      # first: install() then finds main's own `from ... import` copies and records the
+    done = install(fit=fit)                             # TRUE originals for uninstall()
     argv = list(main_args)
     if dev is not None and _state["rank"] > 0:
         argv = _private_job_dir(argv)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LTRX_VERSION 122 /* 0.2.1 (round 5): ltrx_ndcg_at_gains, operand images of activations (ltrx_gemm_nt_img, ltrx_gemm_tn_group_img, ltrx_layernorm_fwd_image), ltrx_gemm_nt_relu_bits_bytes(M, N, K) */
+#define LTRX_VERSION 130 /* 0.3.0 (round 6): ltrx_first_nonfinite; ltrx_fixlength_positions keys its draw by the slate id (not the batch row) */
 
 #define LTRX_OK 0
 #define LTRX_EINVAL (-1)
@@ -284,6 +284,13 @@ int ltrx_dropout_apply(const float* src, float* dst, size_t n, float p, uint32_t
                        ltrx_stream_t stream);
 int ltrx_bump_u32(uint32_t* word, ltrx_stream_t stream);
 
+/* Finiteness check of the explicit step -- the replacement of torch.autograd.detect_anomaly() (allrank/main.py:89,
+ * config.detect_anomaly, config.py:77) for a step that has no autograd graph: scans buf[0..n) (the flat gradient buffer; 16-byte
+ * aligned) once and writes out[0] = index of the first segment that holds a NaN / Inf (segment s = [seg_start[s], seg_start[s+1]),
+ * seg_start sorted ascending, seg_start[0] = 0: the parameter tensors in flat-buffer order), 0x7fffffff if every element is finite;
+ * out[1] = number of non-finite elements.  HBM-bound, 4 B per element.  allrank_amd/csrc/ltrx_train.hip. */
+int ltrx_first_nonfinite(const float* buf, size_t n, const int64_t* seg_start, int n_seg, int* out, ltrx_stream_t stream);
+
 /* all transposed weight copies of the explicit step in one launch: matrix m = rows x cols floats at src_base + desc[4m],
  * written transposed (cols x rows) at dst_base + desc[4m+1]; desc[4m+2..3] = rows, cols; tile_start[n+1] = prefix sums of
  * ceil(rows/32)*ceil(cols/32) (all arrays in DEVICE memory except the scalars). */
@@ -486,7 +493,9 @@ int ltrx_fc_linear_listnet_step(const float* x, const float* y, int B, int L, in
  *   ltrx_fixlength_positions: FixLength (dataset_loading.py:32-93) for the B slates `slates` of a batch: positions[b][l] = the
  *       position inside slate b that fills slot l, -1 = padding.  Short slates are padded (:81-93); slates of >= L items are
  *       sampled without replacement in random order (:70) with the reference's relevance rule (:72-76).  Counter-based
- *       randomness from `seed` (same seed, same batch -> same sample); max_slate_len <= 12288.
+ *       randomness keyed by (`seed`, the slate's id in the dataset): the same seed draws the same sample for a slate whichever
+ *       batch or batch row it arrives in (a rank assembling only its block of a global batch == the one-rank run);
+ *       max_slate_len <= 12288.
  *   ltrx_assemble_batch: xb[B,L,F], yb[B,L] (-1 on padding), indices[B,L] (= positions) from the CSR arrays (ToTensor +
  *       collate, :19-29). */
 int ltrx_fixlength_positions(const int64_t* offsets, const float* y_items, const int64_t* slates, int B, int L, int max_slate_len,

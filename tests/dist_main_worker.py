@@ -6,7 +6,9 @@ exactly the objects ``allrank_amd.install(fit=True)`` binds into an unmodified m
 (main.py:66-67: global batch = world x batch_size, sampler on torch's global generator as in dataset_loading.py:245),
 ``launch.CustomDataParallel`` (main.py:76-78, taken when FORCE_WRAP) and ``allrank_amd.fit.fit`` (main.py:90).
 
-    dist_main_worker.py OUT.pt BATCH_SIZE LOSS FORCE_WRAP [fc_only]
+    dist_main_worker.py OUT.pt BATCH_SIZE LOSS FORCE_WRAP [fc_only] [devloader]
+``devloader``: the datasets / loaders are the ones install() binds to main.py:57-68 since round 6 (``allrank_amd.data.load_libsvm_dataset``
+-> HBM-resident slates, ``launch.create_data_loaders`` -> DeviceLoader: every rank assembles only its block of each global batch).
 Under the launcher's environment (2 ranks, gloo, both on GPU 0): the sharded run; rank 0 writes OUT.pt.  Without: the 1-rank run.
 """
 import json
@@ -25,7 +27,8 @@ import torch  # noqa: E402
 
 def main():
     out_path, batch_size, loss_name, force_wrap = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
-    fc_only = len(sys.argv) > 5 and sys.argv[5] == "fc_only"         # BASELINE configs[0]: transformer null -> the slate-resident FC step
+    fc_only = "fc_only" in sys.argv[5:]                              # BASELINE configs[0]: transformer null -> the slate-resident FC step
+    devloader = "devloader" in sys.argv[5:]
     from torch import optim
     from allrank_amd import fit as EF, launch, losses
     from allrank_amd.model import make_model
@@ -43,10 +46,18 @@ def main():
         with tempfile.TemporaryDirectory() as tmp:
             for role in ("train", "vali"):
                 _dummy_libsvm(os.path.join(tmp, "%s.txt" % role), rng)
-            train_ds = _load(os.path.join(tmp, "train.txt"), cfg["data"]["slate_length"])
-            val_ds = _load(os.path.join(tmp, "vali.txt"), cfg["data"]["slate_length"])
-            n_features = train_ds.tensors[0].shape[-1]
+            if devloader:
+                from allrank_amd import data as ED
+                train_ds, val_ds = ED.load_libsvm_dataset(tmp, cfg["data"]["slate_length"], "vali")                     # main.py:57-61
+                val_ds.slate_length = cfg["data"]["slate_length"]      # (the host twin `_load` pads the validation role to slate_length too)
+                n_features = train_ds.shape[-1]
+            else:
+                train_ds = _load(os.path.join(tmp, "train.txt"), cfg["data"]["slate_length"])
+                val_ds = _load(os.path.join(tmp, "vali.txt"), cfg["data"]["slate_length"])
+                n_features = train_ds.tensors[0].shape[-1]
             train_dl, val_dl = launch.create_data_loaders(train_ds, val_ds, num_workers=0, batch_size=batch_size)      # main.py:66-67
+            if devloader:
+                assert isinstance(train_dl, ED.DeviceLoader) and (train_dl.rank, train_dl.world) == (launch.rank(), launch.world_size())
             dev = launch.get_torch_device()                            # main.py:71
             model = make_model(n_features=n_features, **json.loads(json.dumps(cfg["model"])))
             if force_wrap:                                             # main.py:76-78 on a node with several visible GPUs

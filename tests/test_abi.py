@@ -29,13 +29,13 @@ def test_header_symbols_are_exported(libpath):
     for n in names:
         assert hasattr(h, n), "libltrx.so does not export %s declared in include/ltrx.h" % n
     h.ltrx_version.restype = ctypes.c_int
-    assert h.ltrx_version() == 122
+    assert h.ltrx_version() == 130
 
 
 def test_binding_table_matches_header(libpath):
     from allrank_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
-    assert _lib.lib().ltrx_version() == 122
+    assert _lib.lib().ltrx_version() == 130
 
 
 def test_slate_length_limits_are_stated_once_and_reported(libpath):

@@ -135,7 +135,7 @@ def test_main_call_sequence_trains_on_the_fused_step(tmp_path, job):
         assert torch.equal(saved[k], v.detach().cpu())
 
 
-@pytest.mark.parametrize("loss_name,model", [("listNet", "attn"), ("neuralNDCG", "attn"), ("listNet", "fc_only")])
+@pytest.mark.parametrize("loss_name,model", [("listNet", "attn"), ("neuralNDCG", "attn"), ("listNet", "fc_only"), ("neuralNDCG", "attn+devloader")])
 def test_main_call_sequence_under_the_launcher_equals_the_one_rank_run(tmp_path, loss_name, model):
     """VERDICT r4 missing #1: N > 1 GPUs through main.py's own call sequence.  ``allrank_amd.launch.spawn`` starts two ranks (gloo,
     both on this box's one GPU); each runs tests/dist_main_worker.py -- the sequence above with the objects install() binds under a
@@ -148,9 +148,12 @@ def test_main_call_sequence_under_the_launcher_equals_the_one_rank_run(tmp_path,
     worker = os.path.join(root, "tests", "dist_main_worker.py")
     one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
     extra = ["fc_only"] if model == "fc_only" else []        # (BASELINE configs[0]: the slate-resident FC + ListNet step, sharded)
+    # "+devloader" (round 6): the two ranks read their blocks from the HBM-resident dataset through the DeviceLoader install() binds to
+    # main.py:57-68; the one-rank run keeps the HOST loader -- same seeds, so the same global batches in the same order
+    extra2 = extra + (["devloader"] if model.endswith("+devloader") else [])
     rc = launch.spawn(1, [sys.executable, worker, one, "32", loss_name, "0"] + extra, timeout=600, log_dir=str(tmp_path / "log1"))
     assert rc == 0, open(tmp_path / "log1" / "rank0.log").read()[-4000:]
-    rc = launch.spawn(2, [sys.executable, worker, two, "16", loss_name, "1"] + extra, backend="gloo", devices=[0, 0], timeout=600,
+    rc = launch.spawn(2, [sys.executable, worker, two, "16", loss_name, "1"] + extra2, backend="gloo", devices=[0, 0], timeout=600,
                       log_dir=str(tmp_path / "log2"))
     logs = "".join(open(tmp_path / "log2" / f).read()[-4000:] for f in sorted(os.listdir(tmp_path / "log2")))
     assert rc == 0, logs
