@@ -1284,6 +1284,27 @@ class FusedTrainer(object):
                 after()
         return self._graph_loss
 
+    def ensure_captured(self, global_batch=None):
+        """Capture the step for this batch divisor NOW -- recording only: nothing executes and no collective is issued -- and say
+        whether that worked.  For callers that must agree ACROSS RANKS on captured-vs-eager before any rank runs a step in either form
+        (bench.py): each rank calls this after its eager warm-up steps, the ranks all-reduce the answers, and a rank whose
+        peers could not capture switches to eager with them (``use_graph = False``).  A failed capture is closed before returning
+        (``_capture``) and its error kept in ``capture_fallback``.  (``step()`` itself also survives a capture failure of ONE rank:
+        the eager step issues the same collectives in the same order as a captured one.)"""
+        if not self.use_graph or self.fcstep:
+            return True
+        self._divisor = float(global_batch if global_batch is not None else self.B * self.world)
+        key = (self._divisor, bool(self.comm_enabled))
+        if key in self._graphs:
+            return True
+        try:
+            self._graphs[key] = self._capture()
+            return True
+        except RuntimeError as exc:
+            self.capture_fallback = repr(exc)
+            self._graphs.pop(key, None)
+            return False
+
     def _fc_step(self, xb, yb, global_batch):
         """the slate-resident step (ltrx_fc_listnet_step): reads the caller's batch in place -- x once -- and leaves scores in
         ``self.scores``, d loss / d scores in ``self.loss.grad`` (with ``keep_loss_grad``), gradients in the flat buffer, the loss in ``self.loss.loss``.  One

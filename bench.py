@@ -159,6 +159,107 @@ def time_kernels(w, B, L, device):
     return res
 
 
+def write_synth_libsvm(path, lengths, F, seed):
+    """A WEB30K-shaped libsvm text file, written with vectorised numpy (one byte matrix, no per-line Python): line
+    ``<label> qid:<6 digits> 1:0.dddd 2:0.dddd ... F:0.dddd``; labels ~ Cat(.52,.32,.13,.02,.01), features uniform on
+    the 4-decimal grid of [0, 1) (WEB30K's features are min-max scaled, normalize_features.py), ``lengths[q]`` lines per query.
+    Returns (X f32[n, F], y f32[n], qid i64[n]) -- the arrays the text encodes exactly (both parsers read them back bit for bit)."""
+    rng = np.random.default_rng(seed)
+    lengths = np.asarray(lengths, dtype=np.int64)
+    n = int(lengths.sum())
+    vals = rng.integers(0, 10000, size=(n, F), dtype=np.int32)
+    y = rng.choice(5, size=n, p=[0.52, 0.32, 0.13, 0.02, 0.01]).astype(np.int32)
+    qid = np.repeat(np.arange(len(lengths), dtype=np.int64) + 100000, lengths)
+    head = b"0 qid:000000"
+    cols = [b" %d:0.0000" % (k + 1) for k in range(F)]
+    row = np.frombuffer(head + b"".join(cols) + b"\n", dtype=np.uint8)
+    t4 = np.arange(10000)
+    table = (48 + np.stack([t4 // 1000, t4 // 100 % 10, t4 // 10 % 10, t4 % 10], 1)).astype(np.uint8)       # value -> its four ASCII digits
+    groups, off, k = [], len(head), 0
+    while k < F:                                            # columns whose index has the same number of digits form one [m, g, width] block
+        width = len(cols[k])
+        g = 0
+        while k + g < F and len(cols[k + g]) == width:
+            g += 1
+        groups.append((k, g, width, off))
+        off += g * width
+        k += g
+    chunk = 16384                                           # one reused 24-MB byte matrix: the template row, then the digits
+    buf = np.broadcast_to(row, (chunk, row.size)).copy()
+    with open(path, "wb") as fh:
+        for a in range(0, n, chunk):
+            m = min(chunk, n - a)
+            text = buf[:m]
+            text[:, 0] = 48 + y[a:a + m]
+            for j in range(6):
+                text[:, 6 + j] = 48 + (qid[a:a + m] // 10 ** (5 - j)) % 10
+            digits = table[vals[a:a + m]]                   # [m, F, 4]
+            for (k, g, width, off) in groups:
+                text[:, off:off + g * width].reshape(m, g, width)[:, :, width - 4:] = digits[:, k:k + g]
+            text.tofile(fh)
+    return (vals.astype(np.float64) / 10000.0).astype(np.float32), y.astype(np.float32), qid
+
+
+def _web30k_lengths(n_queries, L, seed, dense=False):
+    if dense:
+        return np.full(n_queries, L, dtype=np.int64)
+    rng = np.random.default_rng(seed)                      # SURVEY 8(d): clip(round(lognormal(ln 100, 0.6)), 1, L)
+    return np.clip(np.round(np.exp(rng.standard_normal(n_queries) * 0.6 + np.log(100.0))), 1, L).astype(np.int64)
+
+
+def end_to_end_main(w, B, L, device, workdir, dense, n_queries, epochs, host_loader=None, gemm="split_bf16"):
+    """What an UNMODIFIED allrank/main.py does after ``allrank_amd.install(fit=True)`` (main.py:36-102), timed end to end on a synthetic
+    WEB30K-shaped libsvm job: seeds -> ``load_libsvm_dataset`` (files parsed on the GPU, slates resident in HBM) -> ``create_data_loaders``
+    (DeviceLoader) -> make_model -> Adam -> ``fit`` (explicit step; validation pass; metrics).  Reported: slots and valid items per
+    second over the TRAINING pass of the last epoch (wall clock inside fit(), loader + step + train metrics), and the whole epoch.
+    ``host_loader``: a module with the reference loader's interface (oracle/loader_oracle.py, handed in by the cpu_baseline leg
+    only) -> the same fit() fed by torch DataLoader + FixLength on the host, i.e. what main.py gets WITHOUT the loader rebinding."""
+    import types
+    from functools import partial
+    from allrank_amd import data as ED, fit as EF, losses as E
+    lens_tr = _web30k_lengths(n_queries, L, 11, dense)
+    lens_va = _web30k_lengths(max(B, n_queries // 8), L, 12, dense)
+    os.makedirs(workdir, exist_ok=True)
+    t0 = time.perf_counter()
+    for role, lens, sd in (("train", lens_tr, 1), ("vali", lens_va, 2)):
+        f = os.path.join(workdir, "%s.txt" % role)
+        if not os.path.exists(f):
+            write_synth_libsvm(f, lens, w["n_features"], sd)
+    t_write = time.perf_counter() - t0
+    torch.manual_seed(42)                                   # main.py:36-38
+    torch.cuda.manual_seed_all(42)
+    np.random.seed(42)
+    t0 = time.perf_counter()
+    if host_loader is None:
+        tr_ds, va_ds = ED.load_libsvm_dataset(workdir, L, "vali", device=device)             # main.py:57-61
+        tr, va = ED.DeviceLoader(tr_ds, B, shuffle=True), ED.DeviceLoader(va_ds, B, shuffle=False)     # main.py:67-68, one GPU
+    else:
+        tr_ds, va_ds = host_loader.load_libsvm_dataset(workdir, L, "vali")
+        tr, va = host_loader.create_data_loaders(tr_ds, va_ds, num_workers=1, batch_size=B)  # (num_workers 1: run_example's config)
+    torch.cuda.synchronize()
+    t_load = time.perf_counter() - t0
+    model = build_model(w, device, 0.0)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    loss_func = partial(getattr(E, w["loss"]), **w.get("loss_args", {}))
+    config = types.SimpleNamespace(metrics={"ndcg": [5]}, val_metric="ndcg_5", detect_anomaly=False)
+    res = EF.fit(epochs=epochs, model=model, loss_func=loss_func, optimizer=opt, scheduler=None, train_dl=tr, valid_dl=va, config=config,
+                 gradient_clipping_norm=None, early_stopping_patience=100, device=device, output_dir=workdir, tensorboard_output_path=None,
+                 gemm=gemm)
+    log = EF.last_run["epoch_log"]
+    last = log[-1]
+    valid = int(np.minimum(lens_tr, L).sum())
+    steady = log[1:] if len(log) > 1 else log
+    tsum = sum(e["train_s"] for e in steady)
+    return {"slots_per_s": round(sum(e["slots"] for e in steady) / tsum, 1), "valid_items_per_s": round(valid * len(steady) / tsum, 1),
+            "valid_fraction": round(valid / float(last["slots"]), 4), "train_pass_s": round(last["train_s"], 4),
+            "validation_pass_s": round(last["val_s"], 4), "first_epoch_train_pass_s": round(log[0]["train_s"], 4),
+            "epochs": len(log), "steps_per_epoch": len(tr), "queries": int(n_queries), "engine": EF.last_run["engine"],
+            "variable_length": bool(EF.last_run["compact"]), "file_mb": round(os.path.getsize(os.path.join(workdir, "train.txt")) / 1e6, 1),
+            "write_file_s": round(t_write, 2), "load_and_parse_s": round(t_load, 2),
+            "val_ndcg_5": float(res["val_metrics"]["ndcg_5"]), "loader": "allrank_amd.data.DeviceLoader (HBM-resident)" if host_loader is None
+            else "torch DataLoader + FixLength on the host (the reference's loader, restated: oracle/loader_oracle.py), num_workers=1"}
+
+
 def cpu_baseline(w, L, seconds_budget=20.0):
     """the reference training step on this box's host cores, on a bounded sample of the same workload.  For the workloads
     whose loss it covers this is oracle/torch_port.py -- the same computation stated with the torch CPU operators the
@@ -239,6 +340,36 @@ def cpu_baseline(w, L, seconds_budget=20.0):
     except Exception:
         pass
     return out
+
+
+def reference_loader_leg(w, B, L, device, gemm, e2e):
+    """cpu_baseline leg, data side: the reference's host loader (torch DataLoader + FixLength + ToTensor, restated in
+    oracle/loader_oracle.py and pinned to the reference's own loaders) on this box's host cores -- (i) its raw rate, slots per second
+    of one shuffled epoch at num_workers 0 and 1; (ii) the SAME fit() as `end_to_end_main`, fed by it: what an unmodified main.py
+    gets from install(fit=True, data=False)."""
+    import shutil
+    import tempfile
+    from oracle import loader_oracle as LO
+    d = tempfile.mkdtemp(prefix="ltrx_e2e_host_")
+    rec = {}
+    try:
+        fed = end_to_end_main(w, B, L, device, d, dense=False, n_queries=3 * B, epochs=2, host_loader=LO, gemm=gemm)
+        rec["fit_fed_by_reference_loader"] = fed
+        tr_ds, va_ds = LO.load_libsvm_dataset(d, L, "vali")
+        for nw in (0, 1):
+            tr, _ = LO.create_data_loaders(tr_ds, va_ds, num_workers=nw, batch_size=B)
+            t0 = time.perf_counter()
+            n = sum(int(xb.shape[0]) for xb, _, _ in tr)
+            rec["loader_slots_per_s_num_workers_%d" % nw] = round(n * L / (time.perf_counter() - t0), 1)
+        if isinstance(e2e, dict):
+            rec["device_loader_over_reference_loader"] = round(e2e["ragged"]["slots_per_s"] / fed["slots_per_s"], 2)
+        rec["kind"] = "port (oracle/loader_oracle.py == allrank/data/dataset_loading.py:19-248, pinned bit for bit in tests/test_loader_cpu.py)"
+        rec["host_cores"] = os.cpu_count()
+    except Exception as e:  # noqa: BLE001
+        rec["error"] = repr(e)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return rec
 
 
 def measure_hbm_traffic(M, N, K, timeout_s=90, script="gemm_one.py", env_extra=None, kernels=("nt256",)):
@@ -343,6 +474,10 @@ def main():
                          "one-product throughput mode (GEMMs and attention; outside the 1e-5 parity contract)")
     ap.add_argument("--no-weight-images", action="store_true",
                     help="A/B: split the weight operand of the GEMMs on the fly in every tile instead of once per optimizer step")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="one GPU: initialise a ONE-rank nccl (= RCCL) process group and run the SHARDED, captured step on it (bucketed "
+                         "all-reduce, normaliser all-reduces, hipGraph segments cut at every collective) -- the collective path of an "
+                         "8-GPU run exercised on the one GPU a build box has; `comm` is filled in")
     ap.add_argument("--engine", default="fused", choices=["fused", "autograd"],
                     help="fused: explicit hipGraph-captured step (engine.FusedTrainer); autograd: nn.Module + torch autograd/Adam")
     args = ap.parse_args()
@@ -362,7 +497,17 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     diag = {"rank_devices": [str(device)], "backend": None, "preflight": None}
-    if world > 1:
+    forced = bool(args.force_dist and world == 1)
+    if forced:
+        import socket
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("LTRX_DIST_BACKEND", "nccl")       # nccl == RCCL on ROCm
         diag["backend"] = backend
@@ -403,7 +548,7 @@ def main():
         args.ragged = True
     if args.engine == "fused":
         trainer = FusedTrainer(model, w["loss"], w.get("loss_args", {}), B, L, lr=1e-3, world_size=world, use_graph=True, gemm=args.gemm,
-                               compact=args.compact, weight_images=not args.no_weight_images)   # Adam 1e-3: approxndcg.json:28-33
+                               compact=args.compact, weight_images=not args.no_weight_images, force_dist=forced)   # Adam 1e-3: approxndcg.json:28-33
     else:
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         _lf, _la = getattr(E, w["loss"]), w.get("loss_args", {})
@@ -420,18 +565,27 @@ def main():
         return trainer.step(x[j:j + B], y[j:j + B], idx[j:j + B], global_batch=B * world)
 
     step_fallback = None
-    try:
-        for i in range(args.warmup):
+    if (world > 1 or forced) and args.engine == "fused" and trainer.use_graph and args.warmup >= 3:
+        # The captured sharded step -- hipGraph segments with the collectives between them -- met RCCL for the first time on whatever
+        # node runs this.  Captured-or-eager is decided by ALL ranks together, before any rank runs a step in either form (ADVICE r5:
+        # a rank that fell back on its own used to restart its warm-up while its peers sat in the all-reduces of theirs): two eager
+        # warm-up steps everywhere (a failure there is a real failure and raises), then every rank records its capture WITHOUT
+        # executing it (no collective is issued while recording; a failed capture is closed), then one MAX all-reduce of the
+        # "could not capture" flags over a CPU (gloo) side group.  If any rank failed, every rank measures the same arithmetic as
+        # eager launches and the line says why.
+        ctl = dist.new_group(backend="gloo")
+        for i in range(2):
             loss = one_step(i)
-    except RuntimeError as e:
-        # (world > 1 only) the captured sharded step -- hipGraph segments with the collectives between them -- has only ever run on
-        # gloo before its first node: if it fails here, measure the same arithmetic as eager launches and record why
-        if world == 1 or args.engine != "fused":
-            raise
-        step_fallback = repr(e)
-        torch.cuda.synchronize()
-        trainer.use_graph = False
-        trainer._graphs.clear()
+        ok = trainer.ensure_captured(B * world)
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ctl)
+        if int(flag.item()):
+            step_fallback = trainer.capture_fallback or "a peer rank could not capture the sharded step"
+            trainer.use_graph = False
+            trainer._graphs.clear()
+        for i in range(2, args.warmup):
+            loss = one_step(i)
+    else:
         for i in range(args.warmup):
             loss = one_step(i)
     if world > 1:
@@ -468,7 +622,7 @@ def main():
 
     # multi-rank: how much of the gradient all-reduce is exposed = timed step - the same step with the collective skipped
     comm = None
-    if world > 1 and args.engine == "fused":
+    if (world > 1 or forced) and args.engine == "fused":
         trainer.comm_enabled = False
         for i in range(2):
             one_step(i)
@@ -767,6 +921,31 @@ def main():
                                        "note": "pinned host memory -> HBM of one batch (features, labels, indices); `value` itself is measured with the batch resident in HBM"}
             except Exception as e:
                 out["host_batches"] = "failed: %r" % (e,)
+        if world == 1 and args.engine == "fused" and not args.no_side_pass and not args.ragged and L == 240 and w["n_features"] <= 136:
+            # VERDICT r5 item 1 / SURVEY 8(d) "time the reference's own loop once": the drop-in path END TO END -- what an unmodified
+            # main.py runs after install(fit=True): libsvm files -> device parse -> HBM-resident slates -> DeviceLoader -> fit().
+            # (i) a WEB30K-shaped ragged job (2048 queries, lognormal lengths): valid items/s over the training pass, beside
+            # `valid_items_per_s` (the same variable-length step fed from resident tensors); (ii) a dense job (every query L items):
+            # slots/s beside `value`.  The same fit() fed by the reference's host loader is measured in the cpu_baseline leg.
+            import shutil
+            import tempfile
+            e2e_dir = tempfile.mkdtemp(prefix="ltrx_e2e_")
+            try:
+                rag = end_to_end_main(w, B, L, device, os.path.join(e2e_dir, "ragged"), dense=False, n_queries=max(2048, 8 * B), epochs=3,
+                                      gemm=args.gemm)
+                den = end_to_end_main(w, B, L, device, os.path.join(e2e_dir, "dense"), dense=True, n_queries=2 * B, epochs=8, gemm=args.gemm)
+                out["end_to_end_main_items_per_s"] = den["slots_per_s"]
+                out["end_to_end_main"] = {
+                    "dense": den, "ragged": rag, "fraction_of_value": round(den["slots_per_s"] / value, 4),
+                    "ragged_fraction_of_valid_items_per_s": (round(rag["valid_items_per_s"] / out["valid_items_per_s"], 4)
+                                                             if isinstance(out.get("valid_items_per_s"), float) else None),
+                    "what": "main.py's sequence after allrank_amd.install(fit=True): seeds, load_libsvm_dataset (parsed on the GPU, resident in "
+                            "HBM), create_data_loaders (DeviceLoader, the reference loader's batch order), make_model, Adam, fit(): rate over the "
+                            "training pass of the steady epochs (loader + step + train metrics, wall clock inside fit)"}
+            except Exception as e:
+                out["end_to_end_main_items_per_s"] = "failed: %r" % (e,)
+            finally:
+                shutil.rmtree(e2e_dir, ignore_errors=True)
         if w["N"] and args.engine == "fused":
             try:                               # measured arithmetic error of the benchmarked GEMM (and of the alternatives)
                 out["gemm_max_rel_err_vs_fp64"] = {g_: gemm_error_vs_fp64(w, B, L, device, g_) for g_ in
@@ -840,10 +1019,12 @@ def main():
                 out["value_plain_dropin_autograd"] = "failed: %r" % (e,)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, L)
+            if args.engine == "fused" and not args.no_side_pass and not args.ragged and L == 240 and w["n_features"] <= 136:
+                out["cpu_baseline"]["reference_loader"] = reference_loader_leg(w, B, L, device, args.gemm, out.get("end_to_end_main"))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

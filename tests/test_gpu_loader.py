@@ -157,7 +157,7 @@ def test_fit_from_the_device_loader_equals_fit_from_the_host_loader(tmp_path):
     """same seeds: the device loader hands fit() the batches the reference's loader would -- every epoch's training loss and the
     weights after every epoch are IDENTICAL (deterministic kernels on identical inputs); the validation numbers agree to round-off
     (FixLength permutes the longest validation slates at random; loss and NDCG do not depend on item order beyond that)"""
-    path = _write(tmp_path, n_q=50)
+    path = _write(tmp_path, n_q=50, F=12)
     r_h, log_h, _, _, _ = _fit_job(path, "host", tmp_path)
     r_d, log_d, _, _, run = _fit_job(path, "device", tmp_path)
     assert len(log_h) == len(log_d) == 3
@@ -177,7 +177,7 @@ def test_fit_variable_length_from_the_device_loader_uses_host_lengths(tmp_path):
     """ragged data (< 80 % valid slots) -> variable-length execution; the DeviceLoader supplies the slate lengths from the host, so
     the step never counts valid items on the device (no per-step sync) -- and trains exactly what the padded step trains"""
     from allrank_amd.engine import FusedTrainer
-    path = _write(tmp_path, n_q=50)
+    path = _write(tmp_path, n_q=50, F=12)
     seen = []
     orig = FusedTrainer._pack
 
@@ -203,7 +203,7 @@ def test_train_metrics_reference_mode_is_the_second_pass(tmp_path):
     numbers of ``train_metrics="reference"`` must be what an independent evaluation of the final model gives on the training set;
     the default (metrics of the training forward, weights moving) differs from it; both modes train identical weights."""
     from allrank_amd import data as ED
-    path = _write(tmp_path, n_q=50)
+    path = _write(tmp_path, n_q=50, F=12)
     r_ref, log_ref, model, (tr_ds, _), _ = _fit_job(path, "device", tmp_path, train_metrics="reference")
     r_def, log_def, _, _, _ = _fit_job(path, "device", tmp_path)
     assert all(torch.equal(log_ref[-1][2][k], log_def[-1][2][k]) for k in log_ref[-1][2])
@@ -222,7 +222,7 @@ def test_finiteness_switch_names_the_first_offending_tensor(tmp_path):
     a NaN planted in one parameter's gradient slice is found, by name, with its count"""
     from allrank_amd.engine import FusedTrainer
     from allrank_amd.model import make_model
-    path = _write(tmp_path, n_q=50)
+    path = _write(tmp_path, n_q=50, F=12)
     with pytest.raises(FloatingPointError) as e:
         _fit_job(path, "device", tmp_path, detect_anomaly=True, poison=True)
     msg = str(e.value)
@@ -232,7 +232,7 @@ def test_finiteness_switch_names_the_first_offending_tensor(tmp_path):
     r_off, log_off, _, _, _ = _fit_job(path, "device", tmp_path)
     assert all(torch.equal(log_on[-1][2][k], log_off[-1][2][k]) for k in log_on[-1][2])
     # the kernel
-    model = make_model(n_features=9, **json.loads(json.dumps(CONFIG["model"]))).to(DEV)
+    model = make_model(n_features=12, **json.loads(json.dumps(CONFIG["model"]))).to(DEV)
     ft = FusedTrainer(model, "listNet", {}, 4, 16, use_graph=False)
     assert ft.first_nonfinite() == (None, 0)
     p = model.encoder.layers[0].feed_forward.w_2.bias
