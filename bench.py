@@ -235,7 +235,8 @@ def end_to_end_main(w, B, L, device, workdir, dense, n_queries, epochs, host_loa
         tr, va = ED.DeviceLoader(tr_ds, B, shuffle=True), ED.DeviceLoader(va_ds, B, shuffle=False)     # main.py:67-68, one GPU
     else:
         tr_ds, va_ds = host_loader.load_libsvm_dataset(workdir, L, "vali")
-        tr, va = host_loader.create_data_loaders(tr_ds, va_ds, num_workers=1, batch_size=B)  # (num_workers 1: run_example's config)
+        tr, va = host_loader.create_data_loaders(tr_ds, va_ds, num_workers=0, batch_size=B)  # (in-process: no worker start-up per pass,
+        #                                                                                       the faster setting for a short epoch)
     torch.cuda.synchronize()
     t_load = time.perf_counter() - t0
     model = build_model(w, device, 0.0)
@@ -257,7 +258,7 @@ def end_to_end_main(w, B, L, device, workdir, dense, n_queries, epochs, host_loa
             "variable_length": bool(EF.last_run["compact"]), "file_mb": round(os.path.getsize(os.path.join(workdir, "train.txt")) / 1e6, 1),
             "write_file_s": round(t_write, 2), "load_and_parse_s": round(t_load, 2),
             "val_ndcg_5": float(res["val_metrics"]["ndcg_5"]), "loader": "allrank_amd.data.DeviceLoader (HBM-resident)" if host_loader is None
-            else "torch DataLoader + FixLength on the host (the reference's loader, restated: oracle/loader_oracle.py), num_workers=1"}
+            else "torch DataLoader + FixLength on the host (the reference's loader, restated: oracle/loader_oracle.py), num_workers=0"}
 
 
 def cpu_baseline(w, L, seconds_budget=20.0):
@@ -353,7 +354,7 @@ def reference_loader_leg(w, B, L, device, gemm, e2e):
     d = tempfile.mkdtemp(prefix="ltrx_e2e_host_")
     rec = {}
     try:
-        fed = end_to_end_main(w, B, L, device, d, dense=False, n_queries=3 * B, epochs=2, host_loader=LO, gemm=gemm)
+        fed = end_to_end_main(w, B, L, device, d, dense=False, n_queries=6 * B, epochs=2, host_loader=LO, gemm=gemm)
         rec["fit_fed_by_reference_loader"] = fed
         tr_ds, va_ds = LO.load_libsvm_dataset(d, L, "vali")
         for nw in (0, 1):

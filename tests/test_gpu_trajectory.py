@@ -1,0 +1,164 @@
+"""-m gpu: END-TO-END parity with the reference's own training run (BASELINE metric: "... NDCG@5 parity").
+
+tests/golden/trajectory_golden.npz holds what ``allrank.main.run()`` -- the reference's entry point with the reference's own fit,
+loaders, losses, metrics and torch Adam, on CPU -- produced on three small jobs (generator: tests/golden/make_golden_trajectory.py;
+regenerated and compared by the drift guard whenever the reference is present).  Here the SAME job runs through the engine's
+drop-in path, in main.py's order (main.py:36-102): seeds -> ``load_libsvm_dataset`` (device-resident) -> ``create_data_loaders`` ->
+``make_model`` -> torch.optim.Adam -> ``partial(loss)`` -> scheduler -> ``allrank_amd.fit.fit`` -- what ``install(fit=True)`` binds.
+
+Checked, per job:
+  * identical initial weights (same generator consumption up to make_model) and IDENTICAL batch composition in every epoch (label
+    sum and size of every training batch: the device loader draws the reference loader's permutations, fit() burns the draws of the
+    passes it skips);
+  * epoch-0 training loss to 1e-5 relative (the mean over one epoch of per-batch losses; the weights start identical);
+  * every later epoch's training / validation loss, train metrics (``train_metrics="reference"``: the reference's second pass),
+    validation NDCG and the weights after every epoch within the drift bounds below -- two fp32 trajectories (torch CPU kernels vs
+    the split-bf16 MFMA kernels) of up to 28 Adam steps; the bounds are a few times what was measured on the MI355X
+    (profiles/r06_trajectory_drift.md) and far below the epoch-to-epoch movement of the quantities they guard.
+"""
+import json
+import os
+import types
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+
+# relative to 1 + |reference value|; weights: absolute, per Adam step of lr 1e-3 an entry may move by ~lr in either direction only
+# where its gradient is below round-off, so the bound on the LARGEST deviation is a small multiple of lr, the rms bound much tighter
+BOUNDS = {"train_loss_epoch0": 1e-5, "train_loss": 2e-4, "val_loss": 2e-4, "metric": 5e-3, "weights_max": 3e-3, "weights_rms": 5e-5}
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "trajectory_golden.npz"), allow_pickle=False)
+
+
+def _run(golden, name, tmp_path, train_metrics):
+    from torch import optim
+    from tests.golden.make_golden_trajectory import write_job_files
+    from allrank_amd import data as ED, fit as EF, losses
+    from allrank_amd.model import make_model
+    cfg = json.loads(str(golden[name + "/config"]))
+    data = {role: tuple(golden["%s/data/%s/%s" % (name, role, k)] for k in ("X", "y", "qid")) for role in ("train", "vali")}
+    folder = str(tmp_path / name)
+    write_job_files(data, folder)
+    torch.manual_seed(42)                                            # main.py:36-38
+    torch.cuda.manual_seed_all(42)
+    np.random.seed(42)
+    tr_ds, va_ds = ED.load_libsvm_dataset(folder, cfg["data"]["slate_length"], cfg["data"]["validation_ds_role"], device=DEV)   # :57
+    n_features = tr_ds.shape[-1]
+    assert n_features == va_ds.shape[-1]
+    # main.py:67 -- on this one-GPU box the processing-unit count is 1, as it was (0 GPUs -> 1) where the fixture was generated
+    tr, va = ED.DeviceLoader(tr_ds, cfg["data"]["batch_size"], shuffle=True), ED.DeviceLoader(va_ds, cfg["data"]["batch_size"], shuffle=False)
+    model = make_model(n_features=n_features, **json.loads(json.dumps(cfg["model"])))                                            # :75
+    model.to(DEV)
+    init = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    optimizer = getattr(optim, cfg["optimizer"]["name"])(params=model.parameters(), **cfg["optimizer"]["args"])                 # :82
+    loss_func = partial(getattr(losses, cfg["loss"]["name"]), **cfg["loss"]["args"])                                            # :83
+    scheduler = (getattr(optim.lr_scheduler, cfg["lr_scheduler"]["name"])(optimizer, **cfg["lr_scheduler"]["args"])
+                 if cfg["lr_scheduler"]["name"] else None)
+    metrics = {}
+    for m in cfg["metrics"]:
+        n, at = m.split("_")
+        metrics.setdefault(n, []).append(int(at))
+    config = types.SimpleNamespace(metrics=metrics, val_metric=cfg["val_metric"], detect_anomaly=False)
+    out = tmp_path / (name + "_out")
+    out.mkdir(exist_ok=True)
+    epochs, batches, cur = [], [], []
+    orig_info = EF.log.info
+    from allrank_amd.engine import FusedTrainer
+    orig_step = FusedTrainer.step
+
+    def step(self, xb, yb, indices=None, global_batch=None, lengths=None):
+        cur.append((float(yb[yb != -1].double().sum()), int(global_batch)))
+        return orig_step(self, xb, yb, indices, global_batch=global_batch, lengths=lengths)
+
+    def spy(msg, *a):
+        if isinstance(msg, str) and msg.startswith("Epoch :"):
+            epochs.append(dict(train_loss=float(a[1]), val_loss=float(a[2]),
+                               weights={k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}))
+            batches.append(list(cur))
+            del cur[:]
+        return orig_info(msg, *a)
+    EF.log.info, FusedTrainer.step = spy, step
+    hist = []
+    try:
+        # per-epoch metric values: the returned dict only has the last epoch's; every epoch's are the arguments of fit()'s "Epoch :" line
+        def spy2(msg, *a):
+            if isinstance(msg, str) and msg.startswith("Epoch :"):
+                def parse(s_):
+                    t = s_.split()
+                    return {t[i + 1]: float(t[i + 2]) for i in range(0, len(t), 3)} if t else {}
+                hist.append((parse(a[3]), parse(a[4])))
+            return spy(msg, *a)
+        EF.log.info = spy2
+        result = EF.fit(model=model, loss_func=loss_func, optimizer=optimizer, scheduler=scheduler, train_dl=tr, valid_dl=va, config=config,
+                        device=torch.device(DEV), output_dir=str(out), tensorboard_output_path=None, train_metrics=train_metrics,
+                        **cfg["training"])
+    finally:
+        EF.log.info, FusedTrainer.step = orig_info, orig_step
+    assert EF.last_run["engine"] == "fused", EF.last_run
+    return dict(cfg=cfg, init=init, epochs=epochs, batches=batches, hist=hist, result=result, run=dict(EF.last_run))
+
+
+@pytest.mark.parametrize("name", ["dummy_fc_listnet", "dummy_attn_listnet", "ragged_attn_approx"])
+def test_fit_trajectory_equals_the_reference_run(golden, name, tmp_path):
+    got = _run(golden, name, tmp_path, "reference")
+    names = [str(m) for m in golden[name + "/metric_names"]]
+    E = len(golden[name + "/train_loss"])
+    assert len(got["epochs"]) == E
+    # same initial weights: the generator was consumed identically up to and including make_model
+    for k, v in got["init"].items():
+        assert np.array_equal(v, golden["%s/init/%s" % (name, k)]), ("initial weights", k)
+    # the same slates in the same batches in the same order, every epoch
+    ref_sums, ref_sizes = golden[name + "/batch_label_sums"], golden[name + "/batch_sizes"]
+    for e in range(E):
+        assert [b[1] for b in got["batches"][e]] == ref_sizes[e].tolist(), ("batch sizes", e)
+        assert [b[0] for b in got["batches"][e]] == ref_sums[e].tolist(), ("batch composition", e)
+    drift = {"job": name, "epochs": E, "steps": int(sum(len(b) for b in got["batches"])), "fcstep": bool(got["run"]["fcstep"]),
+             "variable_length": bool(got["run"]["compact"])}
+    rel = lambda a, b: abs(a - b) / (1.0 + abs(b))  # noqa: E731
+    drift["train_loss"] = [rel(got["epochs"][e]["train_loss"], float(golden[name + "/train_loss"][e])) for e in range(E)]
+    drift["val_loss"] = [rel(got["epochs"][e]["val_loss"], float(golden[name + "/val_loss"][e])) for e in range(E)]
+    drift["train_metrics"] = [[abs(got["hist"][e][0][m] - float(golden[name + "/train_metrics"][e][j])) for j, m in enumerate(names)] for e in range(E)]
+    drift["val_metrics"] = [[abs(got["hist"][e][1][m] - float(golden[name + "/val_metrics"][e][j])) for j, m in enumerate(names)] for e in range(E)]
+    wmax, wrms = [], []
+    for e in range(E):
+        d = np.concatenate([(got["epochs"][e]["weights"][k].astype(np.float64) - golden["%s/weights_epoch%d/%s" % (name, e, k)]).ravel()
+                            for k in got["init"]])
+        wmax.append(float(np.abs(d).max()))
+        wrms.append(float(np.sqrt((d ** 2).mean())))
+    drift["weights_max_abs"], drift["weights_rms"] = wmax, wrms
+    drift["reference"] = {"train_loss": golden[name + "/train_loss"].tolist(), "val_loss": golden[name + "/val_loss"].tolist(),
+                          "val_metrics": golden[name + "/val_metrics"].tolist(), "metric_names": names}
+    drift["engine"] = {"train_loss": [ep["train_loss"] for ep in got["epochs"]], "val_loss": [ep["val_loss"] for ep in got["epochs"]],
+                       "val_metrics": [[got["hist"][e][1][m] for m in names] for e in range(E)]}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "trajectory_drift_%s.json" % name), "w") as fh:
+        json.dump(drift, fh, indent=1)
+    assert drift["train_loss"][0] <= BOUNDS["train_loss_epoch0"], drift["train_loss"]
+    assert max(drift["train_loss"]) <= BOUNDS["train_loss"] and max(drift["val_loss"]) <= BOUNDS["val_loss"], (drift["train_loss"], drift["val_loss"])
+    assert max(max(r) for r in drift["train_metrics"]) <= BOUNDS["metric"], drift["train_metrics"]
+    assert max(max(r) for r in drift["val_metrics"]) <= BOUNDS["metric"], drift["val_metrics"]
+    assert max(wmax) <= BOUNDS["weights_max"] and max(wrms) <= BOUNDS["weights_rms"], (wmax, wrms)
+    # the returned dict (-> experiment_result.json, main.py:104) carries the last epoch's numbers
+    for j, m in enumerate(names):
+        assert abs(float(got["result"]["val_metrics"][m]) - float(golden[name + "/val_metrics"][-1][j])) <= BOUNDS["metric"]
+        assert abs(float(got["result"]["train_metrics"][m]) - float(golden[name + "/train_metrics"][-1][j])) <= BOUNDS["metric"]
+
+
+def test_default_train_metrics_mode_trains_the_same_trajectory(golden, tmp_path):
+    """the default (train metrics from the training forward, the reference's extra passes burnt instead of run) visits the same
+    batches and ends on the same weights as the reference-mode run, bit for bit"""
+    a = _run(golden, "ragged_attn_approx", tmp_path, "reference")
+    b = _run(golden, "ragged_attn_approx", tmp_path, None)
+    assert a["batches"] == b["batches"]
+    for ea, eb in zip(a["epochs"], b["epochs"]):
+        assert ea["train_loss"] == eb["train_loss"] and ea["val_loss"] == eb["val_loss"]
+        assert all(np.array_equal(ea["weights"][k], eb["weights"][k]) for k in ea["weights"])
