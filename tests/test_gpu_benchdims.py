@@ -49,11 +49,11 @@ def _batch(rng, B, L, F, ragged):
     return x, y
 
 
-def _model_any(cfg, params):
-    """the engine model of an oracle cfg (encoder optional, FC activation None / ReLU)"""
+def _model_any(cfg, params, dropout=0.0):
+    """the engine model of an oracle cfg (encoder optional, FC activation None / ReLU); ``dropout``: every nn.Dropout of the model"""
     from allrank_amd.model import make_model
-    tr = dict(N=cfg["N"], d_ff=cfg["d_ff"], h=cfg["h"], positional_encoding=None, dropout=0.0) if cfg.get("N", 0) else None
-    fc = dict(sizes=list(cfg["fc_sizes"]), input_norm=False, activation=cfg.get("fc_activation"), dropout=0.0)
+    tr = dict(N=cfg["N"], d_ff=cfg["d_ff"], h=cfg["h"], positional_encoding=None, dropout=dropout) if cfg.get("N", 0) else None
+    fc = dict(sizes=list(cfg["fc_sizes"]), input_norm=False, activation=cfg.get("fc_activation"), dropout=dropout)
     model = make_model(fc, tr, dict(d_output=1, output_activation=None), cfg["n_features"])
     model.load_state_dict({k: torch.tensor(v) for k, v in params.items()}, strict=True)
     return model.to(DEV)
@@ -95,7 +95,7 @@ def _ndcg5_row(sc_engine, so, y, mask, score_err):
                 slates_full_valid_order_identical=full_same)
 
 
-def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=None, loss_args=None):
+def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=None, loss_args=None, dropout=0.0):
     """Per step: (a) the fp64 oracle's forward/backward AT THE ENGINE'S CURRENT WEIGHTS vs the engine's loss, scores and
     gradients -- identical weights on both sides at every step, so the 1e-5 loss bar applies to every step, not only the
     first; the oracle differentiates through the ENGINE's ReLU pattern (the saved activations of this very step;
@@ -105,14 +105,19 @@ def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=
     0.1 % of a step would show; (c) NDCG@5 and the sort of the engine's scores vs the oracle's (``_ndcg5_row``).
     (Comparing two free-running trajectories instead is meaningless beyond the first step:
     Adam's first update is lr * sign(g), so the ~1 % of the 6.4 M entries whose gradient is below its own round-off move
-    by +-lr with a random sign in ANY implementation and the scores drift apart by O(0.1) within three steps.)"""
+    by +-lr with a random sign in ANY implementation and the scores drift apart by O(0.1) within three steps.)
+    ``dropout`` > 0 (round 6): every nn.Dropout site of the model trains at that probability; the engine's masks are pure functions
+    of (site seed, step word, element index), restated in oracle/dropout_oracle.py (pinned to the kernels bit for bit in
+    tests/test_gpu_parity.py), so the oracle is handed exactly the masks each step used."""
     from allrank_amd.engine import FusedTrainer
+    from oracle import dropout_oracle as D
     params32 = M.init_params(cfg, seed=seed)
-    model = _model_any(cfg, params32)
+    model = _model_any(cfg, params32, dropout)
     rng = np.random.default_rng(seed + 1)
     x, y = _batch(rng, B, L, cfg["n_features"], ragged)
     mask = y == -1
-    ft = FusedTrainer(model, loss_name, dict(loss_args or {}), B, L, lr=LR, use_graph=True, gemm=gemm)
+    ft = FusedTrainer(model, loss_name, dict(loss_args or {}), B, L, lr=LR, use_graph=True, gemm=gemm, seed=77 + seed)
+    assert bool(ft._any_dropout) == bool(dropout > 0)
     if getattr(ft, "fcstep", False):          # the slate-resident FC + ListNet step keeps no activations unless asked to
         ft.keep_fc_out = ft.keep_loss_grad = True
     if set_perm is not None:
@@ -131,7 +136,10 @@ def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=
         sc = sc_t.cpu().numpy().astype(np.float64)
         g_eng = {k: named[k].grad.detach().cpu().numpy().astype(np.float64) for k in keys}
         w_after = {k: named[k].detach().cpu().numpy().astype(np.float64) for k in keys}
-        so, cache = M.forward(w_before, cfg, x64, mask)
+        masks = D.engine_masks(ft, int(ft.drop_step.item())) if dropout > 0 else None     # (the step word this step ran with)
+        so, cache = M.forward(w_before, cfg, x64, mask, masks)
+        ff_keep = [m_["ff"] > 0 for m_ in masks["layers"]] if masks is not None else None   # (a dropped unit is 0 on both sides)
+        del masks
         out = oracle_loss(so, y)
         lo, gs = float(out[0]), out[1]
         # the engine's ReLU branch pattern of THIS step (saved activations: feed-forward r, FC stack outputs)
@@ -139,9 +147,9 @@ def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=
         pats = [(ft.saved_activation(li, "r") > 0).view(B, L, -1).cpu().numpy() for li in range(len(ft.layers))]
         fc_pats = [(t > 0).view(B, L, -1).cpu().numpy() for t in ft.fc_out] if ft.fc_act == 1 else None
         flips, units, zmax = 0, 0, 0.0
-        for zref, pat in ([(lc["z"], p_) for lc, p_ in zip(cache["layers"], pats)] +
-                          ([(fz[1], p_) for fz, p_ in zip(cache["fc"], fc_pats)] if fc_pats is not None else [])):
-            diff = pat != (zref > 0)
+        for zref, pat, keep in ([(lc["z"], p_, None if ff_keep is None else ff_keep[i_]) for i_, (lc, p_) in enumerate(zip(cache["layers"], pats))] +
+                                ([(fz[1], p_, None) for fz, p_ in zip(cache["fc"], fc_pats)] if fc_pats is not None else [])):
+            diff = pat != ((zref > 0) if keep is None else ((zref > 0) & keep))
             flips, units = flips + int(diff.sum()), units + int(diff.size)
             if diff.any():
                 zmax = max(zmax, float(np.abs(zref[diff]).max()))
@@ -324,6 +332,19 @@ def test_fused_step_at_config2_dimensions_matches_fp64_oracle(name, cfg, B):
                 ragged=[(1, 200), (3, 17), (50, 1), (200, 100)], seed=25)
     _log("cfg2_%s_split_bf16" % name, rows)
     _check(rows, "cfg2/" + name)
+
+
+def test_fused_step_with_dropout_at_config3_dimensions_matches_fp64_oracle():
+    """every shipped config trains with dropout 0.1-0.4 (reproducibility/configs/*/*.json) and bench.py reports
+    ``value_dropout_0.1`` -- the config-3 model at 96 x 240 (large-tile kernels) with ALL FIVE dropout sites at p = 0.1 (after the FC
+    layer, on the attention probabilities, after the feed-forward ReLU, on both residual branches; model.py:43, transformer.py:105,155,
+    227) against the fp64 oracle under the engine's own masks: the same bars as the dropout-off rows (loss 1e-5, scores 2e-5 of
+    their scale, every gradient, the Adam replica, NDCG@5); three steps = two eager, then capture + replay, each with fresh masks."""
+    B, L = 96, 240
+    rows = _run(CFG3, B, L, "split_bf16", "approxNDCGLoss", lambda s, t: O.approxndcg(s, t, dtype=np.float64), steps=3,
+                ragged=[(1, 200), (3, 17), (50, 1)], seed=37, dropout=0.1)
+    _log("cfg3_dropout0.1_split_bf16", rows)
+    _check(rows, "cfg3/dropout0.1")
 
 
 def test_fused_step_at_64_slates_graph_path_matches_fp64_oracle():

@@ -31,7 +31,9 @@ DEV = "cuda:0"
 
 # relative to 1 + |reference value|; weights: absolute, per Adam step of lr 1e-3 an entry may move by ~lr in either direction only
 # where its gradient is below round-off, so the bound on the LARGEST deviation is a small multiple of lr, the rms bound much tighter
-BOUNDS = {"train_loss_epoch0": 1e-5, "train_loss": 2e-4, "val_loss": 2e-4, "metric": 5e-3, "weights_max": 3e-3, "weights_rms": 5e-5}
+# measured on the MI355X (profiles/r06_trajectory_drift.md), worst job: train loss 2.2e-6, val loss 8.3e-6, metrics 2.5e-4 (one slate of
+# 100 changing one swap), weights 1.2e-3 max / 3e-5 rms after 16 steps
+BOUNDS = {"train_loss_epoch0": 1e-5, "train_loss": 5e-5, "val_loss": 5e-5, "metric": 1e-3, "weights_max": 4e-3, "weights_rms": 1e-4}
 
 
 @pytest.fixture(scope="module")
@@ -128,13 +130,30 @@ def test_fit_trajectory_equals_the_reference_run(golden, name, tmp_path):
     drift["val_loss"] = [rel(got["epochs"][e]["val_loss"], float(golden[name + "/val_loss"][e])) for e in range(E)]
     drift["train_metrics"] = [[abs(got["hist"][e][0][m] - float(golden[name + "/train_metrics"][e][j])) for j, m in enumerate(names)] for e in range(E)]
     drift["val_metrics"] = [[abs(got["hist"][e][1][m] - float(golden[name + "/val_metrics"][e][j])) for j, m in enumerate(names)] for e in range(E)]
-    wmax, wrms = [], []
+    # Parameters the loss does not depend on (exactly zero gradient; in floating point round-off noise, which Adam normalises to steps
+    # of ~lr in a random direction -- such entries random-walk in BOTH runs and say nothing about parity; measured: up to 6e-3 on them
+    # while every other tensor agrees to 1e-3 ... 1e-7):
+    #   * a constant added to every score of a slate changes neither listNet's softmax nor ApproxNDCG's score differences: the output
+    #     bias; the final LayerNorm's bias b_2 (a constant through the linear head); in a model that is linear from the FC bias to the
+    #     score (no encoder, no activation) the FC bias too;
+    #   * a constant added to every KEY of a slate shifts all of a query's attention logits equally (softmax-invariant,
+    #     transformer.py:148-153): the key projection's bias of every layer.
+    free = ["output_layer.w_1.bias"]
+    if got["cfg"]["model"]["transformer"] is None:
+        if got["cfg"]["model"]["fc_model"]["activation"] is None:
+            free += ["input_layer.layers.%d.bias" % i for i in range(len(got["cfg"]["model"]["fc_model"]["sizes"]))]
+    else:
+        free += ["encoder.norm.b_2"] + ["encoder.layers.%d.self_attn.linears.1.bias" % i for i in range(got["cfg"]["model"]["transformer"]["N"])]
+    wmax, wrms, per_tensor = [], [], {}
     for e in range(E):
-        d = np.concatenate([(got["epochs"][e]["weights"][k].astype(np.float64) - golden["%s/weights_epoch%d/%s" % (name, e, k)]).ravel()
-                            for k in got["init"]])
+        ds = {k: (got["epochs"][e]["weights"][k].astype(np.float64) - golden["%s/weights_epoch%d/%s" % (name, e, k)]).ravel() for k in got["init"]}
+        d = np.concatenate([v for k, v in ds.items() if k not in free])
         wmax.append(float(np.abs(d).max()))
         wrms.append(float(np.sqrt((d ** 2).mean())))
-    drift["weights_max_abs"], drift["weights_rms"] = wmax, wrms
+        if e == E - 1:
+            per_tensor = {k: [float(np.abs(v).max()), float(np.sqrt((v ** 2).mean()))] for k, v in ds.items()}
+    drift["weights_max_abs"], drift["weights_rms"], drift["loss_independent_parameters"] = wmax, wrms, free
+    drift["last_epoch_per_tensor_max_rms"] = per_tensor
     drift["reference"] = {"train_loss": golden[name + "/train_loss"].tolist(), "val_loss": golden[name + "/val_loss"].tolist(),
                           "val_metrics": golden[name + "/val_metrics"].tolist(), "metric_names": names}
     drift["engine"] = {"train_loss": [ep["train_loss"] for ep in got["epochs"]], "val_loss": [ep["val_loss"] for ep in got["epochs"]],
