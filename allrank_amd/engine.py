@@ -86,8 +86,7 @@ class FusedTrainer(object):
     def __init__(self, model, loss_name, loss_args, B, L, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, world_size=1, group=None,
                  optimizer="Adam", weight_decay=0.0, momentum=0.0, nesterov=False,
                  use_graph=True, gemm="split_bf16", dropout=True, seed=None, gradient_clipping_norm=None, compact=False,
-                 weight_images=True, fc_step=True, group_wgrad=True, relu_bits=True, pad_input=True, overlap_wgrad=False,
-                 act_images=False, force_dist=False):
+                 weight_images=True, fc_step=True, group_wgrad=True, relu_bits=True, pad_input=True, force_dist=False):
         """gemm: "split_bf16" -- libltrx fp32-accurate GEMMs on the bf16 MFMA (3 products), "split_bf16_strict" (6
         products), "hipblaslt" (torch.mm/addmm, exact-fp32 library GEMMs), or "bf16" -- the THROUGHPUT mode: one bf16
         product per contraction in the dense projections AND in attention (fp32 storage, accumulation, LayerNorm, softmax,
@@ -116,23 +115,12 @@ class FusedTrainer(object):
         element (ltrx_gemm_nt acts 4 / 5) instead of being re-read from the saved fp32 activation; same results bit for bit.
         pad_input=True: the static input buffer keeps the features in rows padded to 256 floats so that the first FC layer (F = 136 is
         no multiple of the GEMM's 32-column step) runs the large-tile forward and weight-gradient kernels; False = dense rows (A/B).
-        act_images=True (round 5, opt-in): the activations that only ever feed GEMMs -- the LayerNorm outputs in front of the q/k/v and
-        feed-forward projections and the post-ReLU feed-forward activation -- are written by their producers (LayerNorm forward, the
-        FFN-1 GEMM's epilogue) as pre-split bf16 hi / lo operand IMAGES (same bytes, same buffers, no fp32 copy) and staged by the
-        forward GEMMs (operand A) and the grouped weight-gradient GEMM (operand B) with plain copies: no split left in those loops.
-        Applies per step where every consumer runs a large-tile kernel and the one-bit ReLU mask is active (``images_active``);
-        bit-identical results.  MEASURED (profiles/r05_act_images_ab.md): the consumers execute 6-28 % fewer VALU instructions and
-        take the same number of cycles -- the three-product GEMMs are bound by the matrix pipe at the chip's power limit, not by
-        VALU issue -- while the producers pay for the split: -1 % on the step.  Hence off by default.
-        overlap_wgrad=True: fork / join inside the step -- the grouped weight-gradient launch of encoder layer i and its reducing launch
-        run on a SECOND stream (a parallel branch of the captured hipGraph) beside the backward chain of layer i-1 (LayerNorm backward,
-        input-gradient GEMMs, attention backward), which does not depend on them (loss.backward() at train_utils.py:23 imposes no
-        order between a layer's dW and the next layer's dX).  The operands a deferred launch still reads (d_r, dqkv, the residual-
-        stream gradients, dropout-branch gradients, LayerNorm partials) are double-buffered by layer parity; the main stream joins the
-        branch of layer i+1 right before the LayerNorm backward that closes layer i (the first kernel that reuses its buffers), which
-        is also where a sharded run releases that layer's gradient bucket.  Same arithmetic, same launches: bit-identical results
-        (without dropout; with both sublayer dropouts on, the four weight gradients form one group instead of two).  Measured A/B:
-        profiles/r05_wgrad_overlap_ab.md."""
+        (Round 6: the two opt-in NEGATIVE RESULTS of round 5 -- ``overlap_wgrad`` (fork / join of the weight-gradient launches on a
+        second stream: 1-2 % slower, profiles/r05_wgrad_overlap_ab.md) and ``act_images`` (activations as pre-split operand images:
+        VALU -6 ... -28 % in the consumers, cycles unchanged, step -1 %, profiles/r05_act_images_ab.md) -- no longer live in this class;
+        tools/lab/patches/r06_engine_overlap_wgrad_act_images.patch re-adds them; the image-form kernel entry points they drove (ltrx_gemm_nt_img,
+        ltrx_gemm_tn_group_img, ltrx_layernorm_fwd_image) stay in the library with their kernel-level bit-identity test.)
+        force_dist=True: see ``self.sharded`` below."""
         import torch.nn as nn
         from . import _lib as LB
         from .losses import FusedLoss
@@ -144,13 +132,6 @@ class FusedTrainer(object):
         self.gemm = gemm
         self.weight_images = bool(weight_images)
         self.group_wgrad = bool(group_wgrad) and gemm != "split_bf16_strict"     # (the strict arithmetic has no large-tile kernel)
-        self.act_images = bool(act_images)
-        self.images_active = False                            # this step's activations travel as operand images (_images_ok)
-        self._img_cache = {}
-        self.overlap_wgrad = bool(overlap_wgrad)              # (resolved below once the model family is known)
-        self._side = None                                     # the second stream of the fork / join (overlap_wgrad)
-        self._cur_set = 0
-        self._side_busy = False
         self._wg_pending = []
         self.wgrad_group_log = []             # (problems, grouped kernel ran?) of the most recent _wgrad_flush calls
         self._wg_probe = (ctypes.c_ubyte * 65536)()
@@ -385,27 +366,15 @@ class FusedTrainer(object):
             self.xf = torch.zeros((M, d), **f32)
             self.mean_f = torch.zeros(M, **f32)
             self.rstd_f = torch.zeros(M, **f32)
-            self.overlap_wgrad = bool(self.overlap_wgrad and self.group_wgrad and gemm != "hipblaslt")
-            nset = 2 if self.overlap_wgrad else 1
-            # per layer parity (overlap_wgrad: two sets): what a layer's deferred weight-gradient launch still reads while the
-            # next layer's backward chain runs
-            self.d_r_set = [torch.zeros((M, self.dff), **f32) for _ in range(nset)]
-            self.dqkv_set = [torch.zeros((M, 3 * d), **f32) for _ in range(nset)]
-            self.d_r, self.dqkv = self.d_r_set[0], self.dqkv_set[0]
-            if self.overlap_wgrad:
-                self.c_mid = [torch.zeros((M, d), **f32) for _ in range(2)]      # d loss / d x1 of a layer (LN1 backward output)
-                self.c_out = [torch.zeros((M, d), **f32) for _ in range(2)]      # d loss / d (layer input) (LN0 backward output)
-                self.d_br_set = [[torch.zeros((M, d), **f32) for _ in range(2)] for _ in range(2)]     # [set][ffn / attention branch]
+            self.d_r = torch.zeros((M, self.dff), **f32)
+            self.dqkv = torch.zeros((M, 3 * d), **f32)
             self.d_o = torch.zeros((M, d), **f32)
             self.tmp_d = torch.zeros((M, d), **f32)
             self.d_br = torch.zeros((M, d), **f32)            # gradient of a dropped residual branch (ds * keep)
             self.ws_ln = torch.empty(max(self.lib.ltrx_layernorm_bwd_workspace_bytes(M, d), 64), dtype=torch.uint8, device=dev)
             # deferred parameter-gradient partials of up to three LayerNorm backwards per encoder layer (_reduce_flush)
             self.ws_ln_g = [self.ws_ln] + [torch.empty_like(self.ws_ln) for _ in range(2)]
-            self._ws_ln_sets = [self.ws_ln_g] + ([[torch.empty_like(self.ws_ln) for _ in range(3)]] if self.overlap_wgrad else [])
             self.ws_mha = torch.empty(max(self.lib.ltrx_mha_bwd_workspace_bytes(B, L, self.h, self.d // self.h, self._mha_mode), 64), dtype=torch.uint8, device=dev)
-        if not self.N:
-            self.overlap_wgrad = False
         no = self.n_out
         self.scores_raw = torch.zeros((B, L) if no == 1 else (B, L, no), **f32)      # what the loss sees (model.forward)
         self.scores = self.scores_raw if no == 1 else torch.zeros((B, L), **f32)      # model.score (sum over the output units)
@@ -542,13 +511,11 @@ class FusedTrainer(object):
         x = ((x ^ (x >> 15)) * 0x846CA68B) & 0xFFFFFFFF
         return x ^ (x >> 16)
 
-    def _ln_fwd(self, x, res, a, b, xsum, y, mean, rstd, p=0.0, seed=0, image=False):
-        """y = LN(x + drop_p(res)); xsum = x + drop_p(res).  ``image``: y is written as a pre-split operand image (act_images)"""
+    def _ln_fwd(self, x, res, a, b, xsum, y, mean, rstd, p=0.0, seed=0):
+        """y = LN(x + drop_p(res)); xsum = x + drop_p(res)"""
         P = self.LB.ptr
-        fn = self.lib.ltrx_layernorm_fwd_image if image else self.lib.ltrx_layernorm_fwd
-        self.LB.check(fn(P(x), P(res), P(a), P(b), self.rows, self.d, float(self.ln_eps), P(xsum), P(y),
-                         P(mean), P(rstd), float(p), seed, P(self.drop_step), self._st()),
-                      "layernorm_fwd_image" if image else "layernorm_fwd")
+        self.LB.check(self.lib.ltrx_layernorm_fwd(P(x), P(res), P(a), P(b), self.rows, self.d, float(self.ln_eps), P(xsum), P(y),
+                                                  P(mean), P(rstd), float(p), seed, P(self.drop_step), self._st()), "layernorm_fwd")
 
     def _drop_apply(self, src, dst, p, seed):
         """dst = src * keep-mask/(1-p) of the site (the backward of a dropped branch)"""
@@ -556,37 +523,18 @@ class FusedTrainer(object):
         self.LB.check(self.lib.ltrx_dropout_apply(P(src), P(dst), self.rows * src.shape[1], float(p), seed, P(self.drop_step), self._st()),
                       "dropout_apply")
 
-    def _branch_grad(self, ds, p, seed, buf=None):
+    def _branch_grad(self, ds, p, seed):
         if p == 0.0:
             return ds
-        buf = self.d_br if buf is None else buf
-        self._drop_apply(ds, buf, p, seed)
-        return buf
-
-    # ---- fork / join of the second stream (overlap_wgrad) ------------------------------------------------------------
-    def _side_stream(self):
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-        return self._side
-
-    def _fork(self):
-        """the side stream waits for everything issued so far on the main (current) stream"""
-        self._side_stream().wait_stream(torch.cuda.current_stream(self.dev))
-        self._side_busy = True
-
-    def _join(self):
-        """the main (current) stream waits for everything issued so far on the side stream (nothing to wait for when the side stream
-        got no work since the last join -- in particular never an event from outside a stream capture inside one)"""
-        if self._side_busy:
-            torch.cuda.current_stream(self.dev).wait_stream(self._side_stream())
-            self._side_busy = False
+        self._drop_apply(ds, self.d_br, p, seed)
+        return self.d_br
 
     def _ln_bwd(self, dy, xsum, a, mean, rstd, dres, dx, da, db):
         P = self.LB.ptr
         if self.group_wgrad and self.gemm != "hipblaslt" and self._ln_slot < len(self.ws_ln_g):
             # dx now; the (da, db) partials join the layer's one reducing launch (_reduce_flush)
             import ctypes
-            buf = self._ws_ln_sets[self._cur_set][self._ln_slot]
+            buf = self.ws_ln_g[self._ln_slot]
             self._ln_slot += 1
             rows_out = ctypes.c_int(0)
             self.LB.check(self.lib.ltrx_layernorm_bwd_partial(P(dy), P(xsum), P(a), P(mean), P(rstd), P(dres), self.rows, self.d,
@@ -608,52 +556,9 @@ class FusedTrainer(object):
         """dr *= (r > 0) / (1 - p): backward of dropout(relu(z)) given the stored post-dropout activation r"""
         self.LB.check(self.lib.ltrx_relu_bwd(self.LB.ptr(dr), self.LB.ptr(r), self.rows * dr.shape[1], 1.0 / (1.0 - p), self._st()), "relu_bwd")
 
-    def _images_ok(self):
-        """may THIS step (row count self.rows) hand its GEMM-only activations over as operand images?  Every consumer must run a
-        kernel that stages images -- the large-tile forward GEMMs (ltrx_gemm_nt_image_ok) and the grouped weight-gradient GEMM -- and
-        nobody may need their fp32 values: the ReLU backward reads the one-bit mask (``_relu_bits``), LayerNorm's row kernel writes
-        the image (d_model 256 ... 1024)."""
-        key = (self.rows, self.ws_tn.numel() if hasattr(self, "ws_tn") else 0)
-        hit = self._img_cache.get(key)
-        if hit is not None:
-            return hit
-        ok = bool(self.act_images and self.N and self.weight_images and self.group_wgrad and self.gemm in ("split_bf16", "bf16"))
-        if ok:
-            d, dff, rows, lib = self.d, self.dff, self.rows, self.lib
-            ok = d % 256 == 0 and d <= 1024 and all(self._relu_bits(st) is not None for st in self.layers)
-            ok = ok and all(lib.ltrx_gemm_nt_image_ok(rows, n_, k_) for n_, k_ in ((3 * d, d), (dff, d), (d, dff)))
-            if ok:
-                w2, w1, wo, wq = (d, dff), (dff, d), (d, d), (3 * d, d)
-                comps = [[w2, w1, wo, wq]]
-                if not self.overlap_wgrad and any(st["p_s0"] and st["p_s1"] for st in self.layers):
-                    comps = [[w2, w1], [wo, wq]]
-                for comp in comps:
-                    npa = (ctypes.c_int * len(comp))(*[c[0] for c in comp])
-                    kpa = (ctypes.c_int * len(comp))(*[c[1] for c in comp])
-                    ok = ok and (lib.ltrx_debug_tn_group_map(len(comp), rows, npa, kpa, self._wg_probe, self._wg_probe) > 0
-                                 and lib.ltrx_gemm_tn_group_workspace_bytes(len(comp), rows, npa, kpa) <= self.ws_tn.numel())
-        self._img_cache[key] = bool(ok)
-        return bool(ok)
-
-    @staticmethod
-    def decode_image(t):
-        """fp32 values (hi + lo: the value to 2^-17 relative, sign and zero exact) of a buffer that holds an operand image"""
-        g = t.contiguous().view(torch.int32).view(-1, 4)
-
-        def lo16(x_):
-            return (x_ << 16).view(torch.float32)
-
-        def hi16(x_):
-            return (x_ & -65536).view(torch.float32)
-        vals = torch.stack([lo16(g[:, 0]) + lo16(g[:, 2]), hi16(g[:, 0]) + hi16(g[:, 2]),
-                            lo16(g[:, 1]) + lo16(g[:, 3]), hi16(g[:, 1]) + hi16(g[:, 3])], 1)
-        return vals.view(t.shape)
-
     def saved_activation(self, layer, key):
-        """the saved activation ``key`` ("r", "xn0", "xn1", ...) of encoder layer ``layer`` of the LAST step as fp32 values -- decoded
-        when the step handed it over as an operand image (tests, diagnostics)"""
-        t = self.layers[layer][key]
-        return self.decode_image(t) if (self.images_active and key in ("r", "xn0", "xn1")) else t
+        """the saved activation ``key`` ("r", "xn0", "xn1", ...) of encoder layer ``layer`` of the LAST step (tests, diagnostics)"""
+        return self.layers[layer][key]
 
     def _refresh_transposes(self):
         if self.n_out > 1:                                        # W_out^T [d, d_output] zero-padded to a multiple of 4 columns
@@ -741,7 +646,7 @@ class FusedTrainer(object):
         need = self.lib.ltrx_gemm_nt_relu_bits_bytes(self.rows, self.dff, self.d)
         return buf if 0 < need <= buf.numel() else None
 
-    def _lin_fwd(self, x, w, b, out, act=0, p=0.0, seed=0, res=None, bits=None, a_img=False, c_img=False):
+    def _lin_fwd(self, x, w, b, out, act=0, p=0.0, seed=0, res=None, bits=None):
         """out = drop_p(act(x w^T + b)) [+ res]   (nn.Linear forward, act 1 = ReLU; dropout in the epilogue; ``res`` = the
         residual stream of the SublayerConnection this projection closes, transformer.py:98-106: added in the epilogue, so the
         sum is written once by the GEMM instead of being re-read and re-written by the LayerNorm that follows)"""
@@ -756,16 +661,14 @@ class FusedTrainer(object):
                 out[:n].add_(res[:n])
             return
         P = self.LB.ptr
-        # operand images of ACTIVATIONS (act_images): x holds an image (a_img) / out is to be written as one (c_img)
-        fl = (1 if a_img else 0) | (2 if c_img else 0)
         if bits is not None and act == 1:                         # ReLU + its one-bit mask for the backward (act 4)
-            self.LB.check(self.lib.ltrx_gemm_nt_img(P(x), x.stride(0), P(w), w.stride(0), self._img(w), P(out), out.stride(0), self.rows,
-                                                    w.shape[0], x.shape[1], P(b), 4, P(bits), 0, float(p), seed, P(self.drop_step), self._prec, 0,
-                                                    fl, self._st()), "gemm_nt(fwd, relu bits)")
+            self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), self._img(w), P(out), out.stride(0), self.rows,
+                                                w.shape[0], x.shape[1], P(b), 4, P(bits), 0, float(p), seed, P(self.drop_step), self._prec, 0,
+                                                self._st()), "gemm_nt(fwd, relu bits)")
             return
-        self.LB.check(self.lib.ltrx_gemm_nt_img(P(x), x.stride(0), P(w), w.stride(0), self._img(w), P(out), out.stride(0), self.rows, w.shape[0],
-                                                x.shape[1], P(b), 3 if res is not None else act, P(res), res.stride(0) if res is not None else 0,
-                                                float(p), seed, P(self.drop_step), self._prec, 0, fl, self._st()), "gemm_nt(fwd)")
+        self.LB.check(self.lib.ltrx_gemm_nt(P(x), x.stride(0), P(w), w.stride(0), self._img(w), P(out), out.stride(0), self.rows, w.shape[0],
+                                            x.shape[1], P(b), 3 if res is not None else act, P(res), res.stride(0) if res is not None else 0,
+                                            float(p), seed, P(self.drop_step), self._prec, 0, self._st()), "gemm_nt(fwd)")
 
     def _lin_dgrad(self, dy, w, wT, out, relu_of=None, p=0.0, seed=0, bits=None):
         """out = dy w   (input gradient of nn.Linear); wT = w^T contiguous.  With ``relu_of`` (the saved post-ReLU,
@@ -789,7 +692,7 @@ class FusedTrainer(object):
                                             relu_of.stride(0) if relu_of is not None else 0, float(p), seed, P(self.drop_step),
                                             self._prec, 0, self._st()), "gemm_nt(dgrad)")
 
-    def _lin_wgrad(self, dy, x, gw, gb, defer=False, x_img=False):
+    def _lin_wgrad(self, dy, x, gw, gb, defer=False):
         """gw = dy^T x, gb = column sums of dy   (weight and bias gradients of nn.Linear).  ``defer``: an encoder-layer projection
         -- queued for the layer's one grouped launch (_wgrad_flush); dy and x must stay untouched until then."""
         if self.gemm == "hipblaslt":
@@ -797,10 +700,8 @@ class FusedTrainer(object):
             self._colsum(dy, gb)
             return
         if defer and self.group_wgrad:
-            self._wg_pending.append((dy, x, gw, gb, bool(x_img)))
+            self._wg_pending.append((dy, x, gw, gb))
             return
-        if x_img:
-            raise RuntimeError("FusedTrainer: an activation image reached a weight gradient outside the grouped launch")
         P = self.LB.ptr
         # (tile 9: x is the padded input buffer -- its rows are readable up to the 256-column tile, see include/ltrx.h)
         padded = self._x_pad and x.data_ptr() == self.x_in_buf.data_ptr() and x.stride(0) == self.x_in_buf.stride(0)
@@ -837,12 +738,11 @@ class FusedTrainer(object):
                 and self.lib.ltrx_gemm_tn_group_workspace_bytes(n, self.rows, NP, KP) <= self.ws_tn.numel())
         self.wgrad_group_log.append((n, bool(took)))
         del self.wgrad_group_log[:-16]
-        bimg = ci(*[1 if t[4] else 0 for t in q])                 # operand B (the layer input) of a problem is an activation image
         if self.probe_wgrad is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        self.LB.check(self.lib.ltrx_gemm_tn_group_img(n, A, lda, Bm, ldb, C, bo, self.rows, NP, KP, self._prec, self.LB.ptr(self.ws_tn),
-                                                      self.ws_tn.numel(), *outs, bimg, self._st()), "gemm_tn_group(wgrad)")
+        self.LB.check(self.lib.ltrx_gemm_tn_group(n, A, lda, Bm, ldb, C, bo, self.rows, NP, KP, self._prec, self.LB.ptr(self.ws_tn),
+                                                  self.ws_tn.numel(), *outs, self._st()), "gemm_tn_group(wgrad)")
         if self.probe_wgrad is not None:
             ev1.record()
             self.probe_wgrad.append((ev0, ev1, n, bool(took)))
@@ -901,13 +801,12 @@ class FusedTrainer(object):
                                               P(self.x_pe), self._st()), "posenc_fwd")
             h = self.x_pe
         x = h                                                     # residual stream
-        img = self.images_active = self._images_ok()
         for i, st in enumerate(self.layers):
             lay = st["mod"]
             n0, n1 = lay.sublayer[0].norm, lay.sublayer[1].norm
-            self._ln_fwd(x, None, W(n0.a_2), W(n0.b_2), None, st["xn0"], st["mean0"], st["rstd0"], image=img)
+            self._ln_fwd(x, None, W(n0.a_2), W(n0.b_2), None, st["xn0"], st["mean0"], st["rstd0"])
             st["xin"] = x
-            self._lin_fwd(st["xn0"], st["wqkv"], st["bqkv"], st["qkv"], a_img=img)
+            self._lin_fwd(st["xn0"], st["wqkv"], st["bqkv"], st["qkv"])
             qkv = st["qkv"]
             self.LB.check(lib.ltrx_mha_fwd(P(qkv), qkv.data_ptr() + 4 * d, qkv.data_ptr() + 8 * d, P(kpm), B, L, self.h,
                                            d // self.h, 3 * d, P(st["o"]), d, P(st["lse"]), dp(st["p_att"]), st["s_att"],
@@ -915,19 +814,19 @@ class FusedTrainer(object):
             lo = lay.self_attn.linears[3]
             # x1 = x + dropout(attention branch): the residual sum is the out-projection's epilogue (act 3)
             self._lin_fwd(st["o"], W(lo.weight), W(lo.bias), st["x1"], 0, dp(st["p_s0"]), st["s_s0"], res=x)
-            self._ln_fwd(st["x1"], None, W(n1.a_2), W(n1.b_2), None, st["xn1"], st["mean1"], st["rstd1"], image=img)
+            self._ln_fwd(st["x1"], None, W(n1.a_2), W(n1.b_2), None, st["xn1"], st["mean1"], st["rstd1"])
             ff = lay.feed_forward
             if self.probe is not None and train:                  # bench.py: HIP events around the roofline kernel, in the step
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
             self._lin_fwd(st["xn1"], W(ff.w_1.weight), W(ff.w_1.bias), st["r"], 1, dp(st["p_ff"]), st["s_ff"],
-                          bits=self._relu_bits(st) if train else None, a_img=img, c_img=img)
+                          bits=self._relu_bits(st) if train else None)
             if self.probe is not None and train:
                 ev1.record()
                 self.probe.append((ev0, ev1))
             # x(next layer) = x1 + dropout(feed-forward branch), again in the epilogue of the projection that closes the sublayer
             nxt = self.layers[i + 1]["xsum0"] if i + 1 < len(self.layers) else self.xsum_f
-            self._lin_fwd(st["r"], W(ff.w_2.weight), W(ff.w_2.bias), nxt, 0, dp(st["p_s1"]), st["s_s1"], res=st["x1"], a_img=img)
+            self._lin_fwd(st["r"], W(ff.w_2.weight), W(ff.w_2.bias), nxt, 0, dp(st["p_s1"]), st["s_s1"], res=st["x1"])
             x = nxt
         out = self.model.output_layer
         if self.N:
@@ -962,7 +861,6 @@ class FusedTrainer(object):
         out = self.model.output_layer
         no = self.n_out
         self._wg_pending.clear()                                  # (a step that raised half-way must not leave work queued)
-        self._side_busy = False
         self._red_pending.clear()
         self._ln_slot = 0
         feat, sc_rows = self._forward(True)
@@ -983,11 +881,8 @@ class FusedTrainer(object):
             self.dz_pad[:M, :no].copy_(dsc.reshape(-1, no)[:M])
             self._lin_wgrad(self.dz_pad[:, :no], feat, G(out.w_1.weight), G(out.w_1.bias))
             self._lin_dgrad(self.dz_pad, W(out.w_1.weight), self.woutT_pad, ga)
-        ov = self.overlap_wgrad
-        img = self.images_active
         if self.N:
             nf = self.enc.norm
-            self._cur_set = (self.N - 1) % 2 if ov else 0           # (the final norm's partials join the last layer's reducing launch)
             self._ln_bwd(ga, self.xsum_f, W(nf.a_2), self.mean_f, self.rstd_f, None, gb, G(nf.a_2), G(nf.b_2))
             ds = gb                                               # d loss / d (x1_last + ffn_last)
             other = ga
@@ -996,29 +891,24 @@ class FusedTrainer(object):
                 lay = st["mod"]
                 n0, n1 = lay.sublayer[0].norm, lay.sublayer[1].norm
                 ff = lay.feed_forward
-                sset = i % 2 if ov else 0
-                self._cur_set = sset
-                d_r, dq = self.d_r_set[sset], self.dqkv_set[sset]
-                # where the two LayerNorm backwards of the layer write: ping-pong over (ga, gb), or -- overlap_wgrad -- the layer
-                # parity's own pair (the deferred weight-gradient launch of THIS layer still reads ds and `mid` while the next
-                # layer's chain runs)
-                mid, outb = (self.c_mid[sset], self.c_out[sset]) if ov else (other, ds)
+                d_r, dq = self.d_r, self.dqkv
+                mid, outb = other, ds                              # where the two LayerNorm backwards of the layer write: ping-pong over (ga, gb)
                 # FFN branch
-                db = self._branch_grad(ds, st["p_s1"], st["s_s1"], self.d_br_set[sset][0] if ov else None)
+                db = self._branch_grad(ds, st["p_s1"], st["s_s1"])
                 # (the four weight gradients of the layer are queued and run as one grouped launch before the first kernel that
                 #  overwrites one of their operands: the LN0 backward below, or the second use of the dropout buffer d_br)
-                self._lin_wgrad(db, st["r"], G(ff.w_2.weight), G(ff.w_2.bias), defer=True, x_img=img)
+                self._lin_wgrad(db, st["r"], G(ff.w_2.weight), G(ff.w_2.bias), defer=True)
                 self._lin_dgrad(db, W(ff.w_2.weight), self._wT.get(id(ff.w_2.weight)), d_r, relu_of=st["r"], p=st["p_ff"],
                                 bits=self._relu_bits(st))
-                self._lin_wgrad(d_r, st["xn1"], G(ff.w_1.weight), G(ff.w_1.bias), defer=True, x_img=img)
+                self._lin_wgrad(d_r, st["xn1"], G(ff.w_1.weight), G(ff.w_1.bias), defer=True)
                 self._lin_dgrad(d_r, W(ff.w_1.weight), self._wT.get(id(ff.w_1.weight)), self.tmp_d)
                 self._ln_bwd(self.tmp_d, st["x1"], W(n1.a_2), st["mean1"], st["rstd1"], ds, mid, G(n1.a_2), G(n1.b_2))
                 ds = mid                                           # ds = d loss / d x1
                 # attention branch
                 lo = lay.self_attn.linears[3]
-                if st["p_s0"] and st["p_s1"] and not ov:           # d_br still holds the FFN branch's dY
+                if st["p_s0"] and st["p_s1"]:                      # d_br still holds the FFN branch's dY
                     self._wgrad_flush()
-                db = self._branch_grad(ds, st["p_s0"], st["s_s0"], self.d_br_set[sset][1] if ov else None)
+                db = self._branch_grad(ds, st["p_s0"], st["s_s0"])
                 self._lin_wgrad(db, st["o"], G(lo.weight), G(lo.bias), defer=True)
                 self._lin_dgrad(db, W(lo.weight), self._wT.get(id(lo.weight)), self.d_o)
                 qkv = st["qkv"]
@@ -1029,29 +919,13 @@ class FusedTrainer(object):
                               "mha_bwd")
                 if self.compact and M > self.n_valid:              # alignment rows belong to no slate: no gradient
                     dq[self.n_valid:M].zero_()
-                self._lin_wgrad(dq, st["xn0"], st["gwqkv"], st["gbqkv"], defer=True, x_img=img)
+                self._lin_wgrad(dq, st["xn0"], st["gwqkv"], st["gbqkv"], defer=True)
                 self._lin_dgrad(dq, st["wqkv"], st.get("wqkvT"), self.tmp_d)
-                if ov:
-                    # join the branch of layer i+1 (its weight gradients and reductions are complete: its bucket may go, and its
-                    # buffers -- this layer's `outb` among them -- may be reused), then fork this layer's grouped launch: it runs on
-                    # the side stream beside the LN0 backward below and the whole chain of layer i-1
-                    self._join()
-                    if i + 1 < self.N:
-                        self._bucket_done(self.N - 1 - (i + 1))
-                    self._fork()
-                    with torch.cuda.stream(self._side):
-                        self._wgrad_flush(defer_reduce=True)
-                else:
-                    self._wgrad_flush(defer_reduce=True)
+                self._wgrad_flush(defer_reduce=True)
                 self._ln_bwd(self.tmp_d, st["xin"], W(n0.a_2), st["mean0"], st["rstd0"], ds, outb, G(n0.a_2), G(n0.b_2))
                 ds, other = outb, mid                              # ds = d loss / d (layer input)
-                if ov:
-                    self._fork()                                   # (the reducing launch also sums the LN0 partials just written)
-                    with torch.cuda.stream(self._side):
-                        self._reduce_flush()
-                else:
-                    self._reduce_flush()                           # the layer's parameter gradients are final from here
-                    self._bucket_done(self.N - 1 - i)
+                self._reduce_flush()                               # the layer's parameter gradients are final from here
+                self._bucket_done(self.N - 1 - i)
         else:
             ds, other = ga, gb
         if self.pos is not None:                                  # backward of x = sqrt(d) fc_out + pe[rank]
@@ -1071,13 +945,7 @@ class FusedTrainer(object):
                 elif self.p_fc:
                     self._drop_apply(ds, ds, self.p_fc, self._site(1000 + i))
             inp = (self.x_norm if self.in_norm is not None else self.x_in) if i == 0 else self.fc_out[i - 1]
-            if ov and self.N:
-                # (the FC weight gradients use the slab workspace of the deferred launch of layer 0: same stream, behind it)
-                self._fork()
-                with torch.cuda.stream(self._side):
-                    self._lin_wgrad(ds, inp, G(lyr.weight), G(lyr.bias))
-            else:
-                self._lin_wgrad(ds, inp, G(lyr.weight), G(lyr.bias))
+            self._lin_wgrad(ds, inp, G(lyr.weight), G(lyr.bias))
             if i == 0 and self.in_norm is not None:
                 # nn.LayerNorm parameter gradients: dw = sum dy * xhat, db = sum dy with dy = ds W_0 (the input itself needs no
                 # gradient; ltrx_layernorm_bwd's da / db formulas only use the saved mean and rstd, its dx output is scratch)
@@ -1094,9 +962,6 @@ class FusedTrainer(object):
                 if self.fc_act >= 3:
                     self.LB.check(lib.ltrx_out_act_bwd(P(ds), P(self.fc_out[i - 1]), M * ds.shape[1], self.fc_act - 2, P(ds), self._st()),
                                   "fc_act_bwd")
-        if ov and self.N:
-            self._join()                                          # every gradient is final: the rest of the buckets, then the optimizer
-            self._bucket_done(self.N - 1)
         self._bucket_done(len(self._buckets) - 1)
         return loss
 

@@ -143,7 +143,6 @@ def _run(cfg, B, L, gemm, loss_name, oracle_loss, steps, ragged, seed, set_perm=
         out = oracle_loss(so, y)
         lo, gs = float(out[0]), out[1]
         # the engine's ReLU branch pattern of THIS step (saved activations: feed-forward r, FC stack outputs)
-        # (saved_activation: the post-ReLU activation travels as a bf16 hi / lo operand image when act_images applies -- decoded here)
         pats = [(ft.saved_activation(li, "r") > 0).view(B, L, -1).cpu().numpy() for li in range(len(ft.layers))]
         fc_pats = [(t > 0).view(B, L, -1).cpu().numpy() for t in ft.fc_out] if ft.fc_act == 1 else None
         flips, units, zmax = 0, 0, 0.0
