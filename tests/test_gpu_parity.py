@@ -1724,6 +1724,13 @@ def test_relu_bits_default_falls_back_when_d_model_is_no_multiple_of_32():
     assert res[True] == res[False] and all(np.isfinite(res[True]))
 
 
+def _image_of(t):
+    from allrank_amd import _lib as LB
+    img = torch.empty_like(t)
+    LB.check(LB.lib().ltrx_split_image(LB.ptr(t), LB.ptr(img), t.numel(), None), "split_image")
+    return img
+
+
 def test_activation_operand_images_equal_the_fp32_hand_over_bit_for_bit():
     """round 5: an activation written as a pre-split bf16 hi / lo image by its producer and staged by its consumers with plain copies.
     Kernel level: ltrx_layernorm_fwd_image == split_image(ltrx_layernorm_fwd); ltrx_gemm_nt_img with LTRX_GEMM_A_IS_IMAGE == the fp32
