@@ -26,9 +26,6 @@
 // conventions to ltrx_mha.hip, so forward / backward kernels of the two paths are interchangeable.  Variable-length
 // (cu_seqlens) batches: slate b is rows cu[b] .. cu[b+1]-1; waves beyond the slate's length exit after the staging barrier.
 #include "ltrx_device.h"
-#include <string.h>
-#include <stdlib.h>
-#include <utility>
 
 using namespace ltrx;
 
@@ -173,12 +170,6 @@ __device__ unsigned long long g_mha_stamps[8][40][8];       // (or of the dK/dV 
 #endif
 #ifndef LTRX_MHA_TOUCH
 #define LTRX_MHA_TOUCH 1
-#endif
-#ifndef LTRX_W64_NO_MFMA          // lab builds: the pipelined iteration of the 64-query forward without its MFMAs / without its softmax
-#define LTRX_W64_NO_MFMA 0       // arithmetic (timing only, results are garbage): do the two overlap inside one wave?
-#endif
-#ifndef LTRX_W64_NO_VALU
-#define LTRX_W64_NO_VALU 0
 #endif
 #ifndef LTRX_MHA_SETPRIO
 #define LTRX_MHA_SETPRIO 0
@@ -356,12 +347,6 @@ __device__ __forceinline__ float touch_line(const float* __restrict__ base, int 
   }
   return t;
 }
-struct Touch3 {
-  float t[3];
-};
-__device__ __forceinline__ void touch_join3(const Touch3& x) {
-  asm volatile("s_waitcnt vmcnt(0)" ::"v"(x.t[0]), "v"(x.t[1]), "v"(x.t[2]) : "memory");
-}
 __device__ __forceinline__ void touch_join(const Touch& x) {
   asm volatile("s_waitcnt vmcnt(0)" ::"v"(x.t[0]), "v"(x.t[1]) : "memory");
 }
@@ -490,400 +475,6 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
   if (half == 0 && qrow < len) lse[((size_t)sl.b * h + sl.head) * sl.Lmax + qrow] = (lt > 0.f) ? (m + log2f(lt)) * kLn2 : 0.f;
   STAMP(34, 0);
   if (LTRX_MHA_TOUCH) touch_join(tch);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// forward, round 6: FOUR waves per (slate, head) -- one per SIMD -- each owning 64 queries as two 32-query
-// blocks A / B.  What the cycle stamps of the eight-wave kernel above said (profiles/NOTES.md, round 5): its two waves per SIMD are
-// each ONE dependent chain (fragment reads -> 12 MFMAs -> softmax -> split -> 12 MFMAs), so the matrix pipe idles while a wave does
-// its softmax and the VALU idles while it multiplies; two such chains side by side overlap only by accident of their phase (the
-// tile period was ~5450 cycles for 1536 cycles of matrix work per SIMD).  Here the overlap is built into ONE instruction stream:
-//   * the K fragments of a tile (8 ds_read_b128) and the V fragments (16 transposed reads) are read once and used for both blocks:
-//     half the LDS fragment traffic per product;
-//   * software pipeline across tiles: while the VALU runs the softmax of block A on tile kt, the matrix pipe runs S_A of tile
-//     kt + 1; P_A V beside the softmax of block B; S_B of tile kt + 1 and P_B V beside the split / staging arithmetic of the tile
-//     after next.  Every group of 12 MFMAs has independent VALU work in the same basic block for the scheduler to interleave;
-//   * one wave per SIMD may use the whole register file (512 registers: Q fragments of 64 queries 64, two O accumulators 64, two
-//     S tiles + their successors 64, K / V fragments 64, the staged tile 16);
-//   * staging stays streamed (a tile's loads are issued two tiles ahead; the split and LDS store of tile kt + 2 sit at the end of
-//     iteration kt, one barrier per tile), so memory traffic still overlaps compute and the prologue stays short.
-// Same LDS image layout, same MFMA operand layouts, same softmax conventions (log2 domain, natural-log LSE, dropout from (seed,
-// query row, key)) as the kernel above.  S uses two accumulators per block (the eight-wave kernel sums four): the results of the two
-// forward kernels agree to rounding, not bit for bit.
-// ------------------------------------------------------------------------------------------------------------------
-__device__ const uint8_t g_w64_zero_byte = 0;
-struct TileRegs2 {
-  f32x4 a[2], b[2];
-};
-// 256 threads stage one 32-row tile of TWO tensors (threads 0-127: A, 128-255: B): thread = chunk (idx & 7) of rows (idx >> 3), + 16.
-// Branch-free (clamped offset + select by value), so that the staging can share a basic block with the MFMAs it hides behind.
-__device__ __forceinline__ void tile_gload2(TileRegs2& r, const float* __restrict__ base, int tile, int nrows, int dk, int rs) {
-  const int idx = threadIdx.x & 127, c = (idx & 7) * 8;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = tile * 32 + (idx >> 3) + 16 * j;
-    const bool ok0 = row < nrows && c < dk, ok1 = row < nrows && c + 4 < dk;
-    const int o0 = ok0 ? row * rs + c : 0, o1 = ok1 ? row * rs + c + 4 : 0;       // (row 0 exists: len >= 1; a slate's rows x rs < 2^31)
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(base + o0);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(base + o1);
-    r.a[j] = ok0 ? v0 : f32x4{0.f, 0.f, 0.f, 0.f};
-    r.b[j] = ok1 ? v1 : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-}
-template <bool PL>
-__device__ __forceinline__ void tile_sstore2(unsigned char* img, int tile, const TileRegs2& r) {
-  const int idx = threadIdx.x & 127, chunk = idx & 7;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = (tile & 7) * 32 + (idx >> 3) + 16 * j;
-    const float x[8] = {r.a[j][0], r.a[j][1], r.a[j][2], r.a[j][3], r.b[j][0], r.b[j][1], r.b[j][2], r.b[j][3]};
-    bf16x8 h, l;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      h[e] = (__bf16)x[e];
-      l[e] = (__bf16)(x[e] - (float)h[e]);
-    }
-    const int o = img_off(row, chunk);
-    *reinterpret_cast<bf16x8*>(img + o) = h;
-    if (!PL) *reinterpret_cast<bf16x8*>(img + PLANE + o) = l;
-  }
-}
-// the row-wise fragments of one tile (rows_x_fixed's reads), kept so that two query blocks can use them
-struct RowFrags {
-  bf16x8 h[4], l[4];
-};
-template <bool PL>
-__device__ __forceinline__ void read_rows(const unsigned char* img, int tile_row0, RowFrags& x) {
-  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int o = img_off(tile_row0 + l31, 2 * ks + half);
-    x.h[ks] = *reinterpret_cast<const bf16x8*>(img + o);
-    if (!PL) x.l[ks] = *reinterpret_cast<const bf16x8*>(img + PLANE + o);
-  }
-}
-// P (fp32, D layout) -> the bf16 hi / lo B operands of P V (register 8 u + e <-> k index e of step u)
-struct PFrags {
-  bf16x8 h[2], l[2];
-};
-// an opaque use: the values are COMPUTED before this point (the compiler otherwise sinks arithmetic whose results are only needed after
-// a later branch below that branch, away from the MFMAs it is meant to run beside)
-template <bool PL>
-__device__ __forceinline__ void pin_p(PFrags& f) {
-  if (PL)
-    asm volatile("" : "+v"(f.h[0]), "+v"(f.h[1]));
-  else
-    asm volatile("" : "+v"(f.h[0]), "+v"(f.h[1]), "+v"(f.l[0]), "+v"(f.l[1]));
-}
-// one 32-query block of a wave
-struct W64Blk {
-  f32x16 s;            // S of the current tile (raw), then P
-  PFrags p;            // P of the previous tile, split: the operands of its P V
-  f32x16 o[2];         // O^T accumulators (columns 0-31 / 32-63)
-  float m, l;          // running maximum (log2 domain, joined across the lane halves), running sum of this lane half
-  float mt, mref, alpha, ps;
-  uint32_t drow;
-};
-// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}) -- every index below is a
-// constant in the front end already (register arrays indexed by a loop variable that only becomes constant after unrolling went to scratch)
-template <class F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-// MFMA number IDX of O += P V of two blocks against one tile's transposed fragments (four independent accumulators, used in turn)
-template <bool PL, int IDX>
-__device__ __forceinline__ void w64_pv_mfma(const ColFrags& f, W64Blk& A, W64Blk& B) {
-  constexpr int u = PL ? IDX / 4 : IDX / 12, term = PL ? 2 : (IDX % 12) / 4, ct = (IDX % 4) / 2;
-  if constexpr (IDX & 1) {
-    if constexpr (term == 0) B.o[ct] = LTRX_MFMA(f.l[u][ct], B.p.h[u], B.o[ct]);
-    if constexpr (term == 1) B.o[ct] = LTRX_MFMA(f.h[u][ct], B.p.l[u], B.o[ct]);
-    if constexpr (term == 2) B.o[ct] = LTRX_MFMA(f.h[u][ct], B.p.h[u], B.o[ct]);
-  } else {
-    if constexpr (term == 0) A.o[ct] = LTRX_MFMA(f.l[u][ct], A.p.h[u], A.o[ct]);
-    if constexpr (term == 1) A.o[ct] = LTRX_MFMA(f.h[u][ct], A.p.l[u], A.o[ct]);
-    if constexpr (term == 2) A.o[ct] = LTRX_MFMA(f.h[u][ct], A.p.h[u], A.o[ct]);
-  }
-}
-// MFMA number IDX of S (next tile) of two blocks against one tile's row fragments (one accumulator per block, used in turn)
-template <bool PL, int IDX>
-__device__ __forceinline__ void w64_s_mfma(const RowFrags& x, const bf16x8 (&ah)[4], const bf16x8 (&al)[4], const bf16x8 (&bh)[4],
-                                           const bf16x8 (&bl)[4], f32x16& na, f32x16& nb) {
-  constexpr int term = PL ? 2 : IDX / 8, ks = PL ? IDX / 2 : (IDX % 8) / 2;
-  if constexpr (IDX & 1) {
-    if constexpr (term == 0) nb = LTRX_MFMA(x.l[ks], bh[ks], nb);
-    if constexpr (term == 1) nb = LTRX_MFMA(x.h[ks], bl[ks], nb);
-    if constexpr (term == 2) nb = LTRX_MFMA(x.h[ks], bh[ks], nb);
-  } else {
-    if constexpr (term == 0) na = LTRX_MFMA(x.l[ks], ah[ks], na);
-    if constexpr (term == 1) na = LTRX_MFMA(x.h[ks], al[ks], na);
-    if constexpr (term == 2) na = LTRX_MFMA(x.h[ks], ah[ks], na);
-  }
-}
-// max over the two lane halves (lane i <-> lane i ^ 32) on the VALU: v_permlane32_swap of two copies leaves {lo, lo} and {hi, hi}
-// (__shfl_xor compiles to ds_bpermute: an LDS round trip the in-order wave waits for)
-__device__ __forceinline__ float max_across_halves(float x) {
-  const unsigned u = __float_as_uint(x);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-// the reference maximum of a query only moves when a tile's maximum exceeds it by more than this many powers of two; until then P
-// is taken relative to the stale reference (P <= 2^8: no overflow anywhere in fp32, same relative precision of the bf16 hi / lo
-// split) and the O accumulators need no rescaling -- they stay in accumulation registers.  Mathematically the same softmax: the
-// final O / l and m + log2(l) do not depend on which reference was used.
-constexpr float kW64Tau = 8.0f;
-// slice `c` of the online softmax of one block's [32 keys][32 queries] tile b.s (lane = query, registers = 16 of the 32 keys; the
-// other lane half holds the other 16): 0, 1 scale + mask bias; 2 tile maximum, reference maximum, alpha; 3 .. 18 one element each:
-// P = exp2(S - m) (+ dropout), the sum, and -- with every second element -- the bf16 hi / lo split of the pair into pn
-// (every slice ends in an opaque use of its results -- asm volatile with "+v" operands: such statements and the scheduling barriers
-//  keep their order, so the slice's arithmetic is emitted where it is written, between its two MFMAs; without the pins the optimizer
-//  gathers the sixteen exp / sum / split steps of a block behind the last MFMA, next to their first real use)
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-template <bool DROP, bool PL, int c>
-__device__ __forceinline__ void w64_softmax_slice(W64Blk& b, const f32x4 (&kb)[4], float sl2, int half, const DropCfg& drop,
-                                                  int key0, PFrags& pn) {
-  if constexpr (c < 2) {
-    static_for<8>([&](auto i) {
-      constexpr int r = 8 * c + decltype(i)::value;
-      b.s[r] = b.s[r] * sl2 + kb[r >> 2][r & 3];
-    });
-    asm volatile("" : "+v"(b.s[8 * c + 0]), "+v"(b.s[8 * c + 1]), "+v"(b.s[8 * c + 2]), "+v"(b.s[8 * c + 3]), "+v"(b.s[8 * c + 4]),
-                 "+v"(b.s[8 * c + 5]), "+v"(b.s[8 * c + 6]), "+v"(b.s[8 * c + 7]));
-  } else if constexpr (c == 2) {
-    float mt = b.s[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, b.s[r]);
-    mt = max_across_halves(mt);
-    const bool grow = mt > b.m + kW64Tau;                   // (first tile: m = -inf; a fully masked tile: mt = -inf -> no)
-    const float mn = grow ? mt : b.m;
-    b.mref = (mn == -INFINITY) ? 0.f : mn;
-    b.alpha = grow ? fast_exp2(b.m - b.mref) : 1.0f;
-    b.m = mn;
-    b.ps = 0.f;
-    asm volatile("" : "+v"(b.mref), "+v"(b.alpha), "+v"(b.m));
-  } else {
-    constexpr int r = c - 3;
-    float x = fast_exp2(b.s[r] - b.mref);
-    b.ps += x;
-    if (DROP) x *= drop_scale_rk(drop, b.drow, key0 + rowmap(r, half));
-    b.s[r] = x;
-    if constexpr (r & 1) {
-      const float y0 = b.s[r - 1], y1 = b.s[r];
-      bf16x2 hh = {(__bf16)y0, (__bf16)y1};
-      bf16x2 ll = {(__bf16)(y0 - (float)hh[0]), (__bf16)(y1 - (float)hh[1])};
-      if (PL)
-        asm volatile("" : "+v"(hh), "+v"(b.ps));
-      else
-        asm volatile("" : "+v"(hh), "+v"(ll), "+v"(b.ps));
-      constexpr int u = r >> 3, e = (r & 7) - 1;
-      pn.h[u][e] = hh[0];
-      pn.h[u][e + 1] = hh[1];
-      if (!PL) {
-        pn.l[u][e] = ll[0];
-        pn.l[u][e + 1] = ll[1];
-      }
-    } else {
-      asm volatile("" : "+v"(b.s[r]), "+v"(b.ps));
-    }
-  }
-}
-__device__ __forceinline__ void scale2(f32x16 (&o)[2], float a) {
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[ct][r] *= a;
-}
-
-template <bool DROP, bool PL>
-__global__ void __launch_bounds__(256) ltrx_mha_fwd_w64_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                               const float* __restrict__ v, const uint8_t* __restrict__ kpm, int L,
-                                                               int h, int dk, int rs, float* __restrict__ o, int ors,
-                                                               float* __restrict__ lse, float scale, DropCfg drop,
-                                                               const uint32_t* __restrict__ drop_step, const int* __restrict__ cu,
-                                                               const int* __restrict__ order) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* kimg = smem;
-  unsigned char* vimg = smem + 2 * PLANE;
-  float* kbias = reinterpret_cast<float*>(smem + 4 * PLANE);
-  if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
-  const Slate sl = which_slate(L, h, cu, order);
-  const int lane = threadIdx.x & 63, half = lane >> 5, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int len = sl.len;
-  if ((int)(blockIdx.y * RMAX) >= len) return;        // whole workgroup beyond this slate (uniform: before any load or barrier)
-  const float* qb = q + sl.row0 * rs + (size_t)sl.head * dk;
-  const float* src = (threadIdx.x < 128 ? k : v) + sl.row0 * rs + (size_t)sl.head * dk;     // this thread's streamed tensor
-  unsigned char* dst = threadIdx.x < 128 ? kimg : vimg;
-  const int nkt = (len + 31) / 32;
-  STAMP(32, 0);
-  TileRegs2 tr, tr1;
-  tile_gload2(tr, src, 0, len, dk, rs);
-  tile_gload2(tr1, src, 1, len, dk, rs);
-  // threads 0-31: padding-mask byte of key 32 t + threadIdx.x of the tiles being staged (they travel with their tile)
-  // (all 256 threads carry the mask byte of key 32 t + (threadIdx.x & 31) and write the same kbias entry: no divergent region, no
-  //  branch inside the pipelined iteration; without a mask the loads read one zero byte)
-  const int kx = threadIdx.x & 31;
-  const bool has_kpm = kpm != nullptr;
-  const uint8_t* kp = has_kpm ? kpm + sl.row0 : &g_w64_zero_byte;
-#define LTRX_W64_KM(key_) kp[(has_kpm && (key_) < len) ? (key_) : 0]
-  const uint8_t km0 = LTRX_W64_KM(kx), km1 = LTRX_W64_KM(32 + kx);
-  const int q0 = blockIdx.y * RMAX + wave * 64;
-  const bool active = q0 < len;                 // (inactive waves still stage and take every barrier)
-  bf16x8 qhA[4], qlA[4], qhB[4], qlB[4];
-  {   // scratch: 8 KB of ring slots 4-7 of plane `wave` (first written by tile 4: three barriers from here)
-    f32x4* scratch = reinterpret_cast<f32x4*>(smem + (size_t)wave * PLANE + PLANE / 2);
-    FixedRegs fa, fb;
-    fixed_gload(fa, qb, q0, len, dk, rs);
-    fixed_gload(fb, qb, q0 + 32, len, dk, rs);
-    fixed_finish(qhA, qlA, fa, scratch);
-    fixed_finish(qhB, qlB, fb, scratch);
-  }
-  tile_sstore2<PL>(dst, 0, tr);
-  tile_sstore2<PL>(dst, 1, tr1);
-  kbias[kx] = (kx >= len || km0) ? -INFINITY : 0.f;
-  kbias[32 + kx] = (32 + kx >= len || km1) ? -INFINITY : 0.f;
-  tile_gload2(tr, src, 2, len, dk, rs);
-  uint8_t km_n = LTRX_W64_KM(64 + kx);
-  lds_only_barrier();
-  const float sl2 = scale * kLog2e;
-  if (!active) {
-    for (int kt = 0; kt + 1 < nkt; ++kt) {
-      tile_sstore2<PL>(dst, kt + 2, tr);
-      kbias[((kt + 2) & 7) * 32 + kx] = ((kt + 2) * 32 + kx >= len || km_n) ? -INFINITY : 0.f;
-      tile_gload2(tr, src, kt + 3, len, dk, rs);
-      km_n = LTRX_W64_KM((kt + 3) * 32 + kx);
-      lds_only_barrier();
-    }
-    return;
-  }
-  W64Blk A, B;
-  zero2(A.o);
-  zero2(B.o);
-  A.m = B.m = -INFINITY;
-  A.l = B.l = 0.f;
-  A.mt = B.mt = A.mref = B.mref = A.alpha = B.alpha = A.ps = B.ps = 0.f;
-  A.drow = DROP ? drop_row_seed(drop, sl.bh, sl.Lmax, q0 + (lane & 31)) : 0u;
-  B.drow = DROP ? drop_row_seed(drop, sl.bh, sl.Lmax, q0 + 32 + (lane & 31)) : 0u;
-  ColFrags vf;                                     // V fragments of tile t - 1 (read at the end of iteration t - 1)
-  // One iteration t of the pipeline.  The matrix pipe's work: O += P V of tile t - 1 (24 MFMAs, both blocks), then S of tile t + 1
-  // (24 MFMAs).  The VALU's work: the softmax of tile t (S -> P, running max / sum), the split of P into bf16 hi / lo, the split and
-  // LDS store of tile t + 2.  The two are interleaved BY HAND: after every MFMA one slice of the VALU work (about the 8 issue slots
-  // the matrix pipe is busy with that MFMA), then a scheduling barrier -- left to itself hipcc issues the MFMAs in one burst and the
-  // softmax behind them (and a sched_group_barrier pipeline of 48 x {1 MFMA, 6 VALU} was only partially honoured).
-  // At the end the O accumulators (now tiles 0 .. t - 1, referred to the maximum before tile t) are rescaled by alpha(t) -- only when
-  // some query's maximum moved (wave-uniform branch; after the first tiles it rarely does), so that they can live in accumulation
-  // registers that only the matrix pipe touches.
-#define LTRX_W64_ITER(T_, HAS_S, HAS_PV, STAGE)                                                                                  \
-  do {                                                                                                                          \
-    const int t_ = (T_);                                                                                                        \
-    const int slot_ = (t_ & 7) * 32, nslot_ = ((t_ + 1) & 7) * 32;                                                              \
-    constexpr int NPV_ = PL ? 8 : 24, NOPS_ = 2 * NPV_, CPO_ = 48 / NOPS_;                                                      \
-    f32x4 kb_[4];                                                                                                               \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) kb_[g] = *reinterpret_cast<const f32x4*>(kbias + slot_ + 8 * g + 4 * half);   \
-    RowFrags kf_;                                                                                                               \
-    PFrags pnA_, pnB_;                                                                                                          \
-    f32x16 nA_, nB_;                                                                                                            \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) nA_[r] = nB_[r] = 0.f;                                                       \
-    STAMP(t_, 0);                                                                                                               \
-    static_for<NOPS_>([&](auto op_) {                                                                                           \
-      constexpr int op = decltype(op_)::value;                                                                                  \
-      if constexpr (op == NOPS_ / 6) STAMP(t_, 1);                                                                              \
-      if constexpr (op == NOPS_ / 2) STAMP(t_, 2);                                                                              \
-      if constexpr (op == 5 * NOPS_ / 6) STAMP(t_, 3);                                                                          \
-      if constexpr (op < NPV_) {                                                                                                \
-        if constexpr (HAS_PV && !LTRX_W64_NO_MFMA) w64_pv_mfma<PL, op>(vf, A, B);                                               \
-      } else {                                                                                                                  \
-        if constexpr (HAS_S && !LTRX_W64_NO_MFMA) w64_s_mfma<PL, op - NPV_>(kf_, qhA, qlA, qhB, qlB, nA_, nB_);                 \
-      }                                                                                                                         \
-      static_for<CPO_>([&](auto cc_) {                                                                                          \
-        constexpr int c = op * CPO_ + decltype(cc_)::value;                                                                     \
-        if constexpr (LTRX_W64_NO_VALU) {                                                                                       \
-        } else if constexpr (c < 2) w64_softmax_slice<DROP, PL, c>(A, kb_, sl2, half, drop, t_ * 32, pnA_);                     \
-        else if constexpr (c < 4) w64_softmax_slice<DROP, PL, c - 2>(B, kb_, sl2, half, drop, t_ * 32, pnB_);                   \
-        else if constexpr (c == 4) w64_softmax_slice<DROP, PL, 2>(A, kb_, sl2, half, drop, t_ * 32, pnA_);                      \
-        else if constexpr (c == 5) w64_softmax_slice<DROP, PL, 2>(B, kb_, sl2, half, drop, t_ * 32, pnB_);                      \
-        else if constexpr (c < 22) w64_softmax_slice<DROP, PL, c - 3>(A, kb_, sl2, half, drop, t_ * 32, pnA_);                  \
-        else if constexpr (c < 38) w64_softmax_slice<DROP, PL, c - 19>(B, kb_, sl2, half, drop, t_ * 32, pnB_);                 \
-        if constexpr (HAS_S && c >= 16 && c < 20) {       /* the K fragments of tile t + 1, ahead of its first MFMA */          \
-          const int o_ = img_off(nslot_ + (lane & 31), 2 * (c - 16) + half);                                                    \
-          kf_.h[c - 16] = *reinterpret_cast<const bf16x8*>(kimg + o_);                                                          \
-          if (!PL) kf_.l[c - 16] = *reinterpret_cast<const bf16x8*>(kimg + PLANE + o_);                                         \
-        }                                                                                                                       \
-        if constexpr (STAGE && c == 38) tile_sstore2<PL>(dst, t_ + 2, tr);                                                      \
-        if constexpr (STAGE && c == 40) {                                                                                       \
-          kbias[((t_ + 2) & 7) * 32 + kx] = ((t_ + 2) * 32 + kx >= len || km_n) ? -INFINITY : 0.f;                              \
-          tile_gload2(tr, src, t_ + 3, len, dk, rs);                                                                            \
-          km_n = LTRX_W64_KM((t_ + 3) * 32 + kx);                                                                               \
-        }                                                                                                                       \
-        if constexpr (c == 43) read_cols<PL>(vimg, slot_, vf);   /* V of tile t for the next iteration (this one's P V are issued) */ \
-      });                                                                                                                       \
-      __builtin_amdgcn_sched_barrier(0);                                                                                        \
-    });                                                                                                                         \
-    STAMP(t_, 4);                                                                                                               \
-    A.l = A.l * A.alpha + A.ps;                                                                                                 \
-    B.l = B.l * B.alpha + B.ps;                                                                                                 \
-    pin_p<PL>(pnA_);                                                                                                            \
-    pin_p<PL>(pnB_);                                                                                                            \
-    A.p = pnA_;                                                                                                                 \
-    B.p = pnB_;                                                                                                                 \
-    if (HAS_PV && __builtin_amdgcn_ballot_w64(A.alpha != 1.0f || B.alpha != 1.0f) != 0) {                                       \
-      scale2(A.o, A.alpha);                                                                                                     \
-      scale2(B.o, B.alpha);                                                                                                     \
-    }                                                                                                                           \
-    if (HAS_S) {                                                                                                                \
-      A.s = nA_;                                                                                                                \
-      B.s = nB_;                                                                                                                \
-    }                                                                                                                           \
-    STAMP(t_, 5);                                                                                                               \
-    if (STAGE) lds_only_barrier();                                                                                              \
-    STAMP(t_, 6);                                                                                                               \
-  } while (0)
-  STAMP(32, 1);
-  {
-    RowFrags kf;
-    read_rows<PL>(kimg, 0, kf);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) A.s[r] = B.s[r] = 0.f;
-    static_for<(PL ? 8 : 24)>([&](auto op) { w64_s_mfma<PL, decltype(op)::value>(kf, qhA, qlA, qhB, qlB, A.s, B.s); });
-  }
-  if (nkt > 1) {
-    LTRX_W64_ITER(0, true, false, true);          // (O is still zero: nothing to rescale)
-    for (int kt = 1; kt + 1 < nkt; ++kt) LTRX_W64_ITER(kt, true, true, true);
-    LTRX_W64_ITER(nkt - 1, false, true, false);
-  } else {
-    LTRX_W64_ITER(0, false, false, false);
-  }
-#undef LTRX_W64_ITER
-#undef LTRX_W64_KM
-  Touch3 tch = {{0.f, 0.f, 0.f}};
-  if (LTRX_MHA_TOUCH && blockIdx.y == 0) {     // (after the last wait on a streamed tile: nothing waits for these)
-    Slate nx;
-    if (next_slate(L, h, cu, order, nx)) {
-      const size_t ofs = nx.row0 * rs + (size_t)nx.head * dk;
-      tch.t[0] = touch_line(q + ofs, threadIdx.x, nx.len, dk, rs);
-      tch.t[1] = touch_line(q + ofs, threadIdx.x + 256, nx.len, dk, rs);
-      tch.t[2] = touch_line(threadIdx.x < 128 ? k + ofs : v + ofs, threadIdx.x & 127, min(nx.len, 64), dk, rs);
-    }
-  }
-  STAMP(33, 0);
-  static_for<(PL ? 8 : 24)>([&](auto op) { w64_pv_mfma<PL, decltype(op)::value>(vf, A, B); });      // O += P V of the last tile
-  f32x4* es = end_scratch(smem, nkt - 1, wave);
-  float* ob = o + sl.row0 * ors + (size_t)sl.head * dk;
-  const int l31 = lane & 31;
-  {
-    const float lt = A.l + __shfl_xor(A.l, 32, 64);
-    store_rows(ob, q0, len, dk, ors, A.o, (lt > 0.f) ? 1.0f / lt : 0.f, es);
-    if (half == 0 && q0 + l31 < len) lse[((size_t)sl.b * h + sl.head) * sl.Lmax + q0 + l31] = (lt > 0.f) ? (A.m + log2f(lt)) * kLn2 : 0.f;
-  }
-  {
-    const float lt = B.l + __shfl_xor(B.l, 32, 64);
-    store_rows(ob, q0 + 32, len, dk, ors, B.o, (lt > 0.f) ? 1.0f / lt : 0.f, es);
-    if (half == 0 && q0 + 32 + l31 < len) lse[((size_t)sl.b * h + sl.head) * sl.Lmax + q0 + 32 + l31] = (lt > 0.f) ? (B.m + log2f(lt)) * kLn2 : 0.f;
-  }
-  STAMP(34, 0);
-  if (LTRX_MHA_TOUCH) touch_join3(tch);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1155,29 +746,6 @@ int ltrx_mha_fwd_res_launch(const float* q, const float* k, const float* v, cons
   const DropCfg drop = ltrx_make_drop(p_drop, seed);
   const float scale = 1.0f / sqrtf((float)dk);
   const dim3 grid(B * h, (L + RMAX - 1) / RMAX);
-  // LTRX_MHA_FWD=w32 selects the eight-wave kernel (32 queries per wave) for A/B runs; default: four waves x 64 queries (round 6)
-  static const bool w32 = []() { const char* e = getenv("LTRX_MHA_FWD"); return e && !strcmp(e, "w32"); }();
-  if (!w32) {
-    static std::atomic<uint64_t> attr64_done{0};
-    const int arc64 = ltrx_once_per_device(attr64_done, []() {
-      if (res_attr(ltrx_mha_fwd_w64_kernel<false, false>, RES_SMEM) != LTRX_OK || res_attr(ltrx_mha_fwd_w64_kernel<true, false>, RES_SMEM) != LTRX_OK ||
-          res_attr(ltrx_mha_fwd_w64_kernel<false, true>, RES_SMEM) != LTRX_OK || res_attr(ltrx_mha_fwd_w64_kernel<true, true>, RES_SMEM) != LTRX_OK)
-        return LTRX_EHIP;
-      return LTRX_OK;
-    });
-    if (arc64 != LTRX_OK) return arc64;
-#define LTRX_FWD64(D_, P_)                                                                                                        \
-  hipLaunchKernelGGL((ltrx_mha_fwd_w64_kernel<D_, P_>), grid, dim3(256), RES_SMEM, s, q, k, v, kpm, L, h, dk, rs, o, ors, lse, scale, \
-                     drop, seed_step, cu, order)
-    if (drop.thresh != 0u) {
-      if (plain) LTRX_FWD64(true, true); else LTRX_FWD64(true, false);
-    } else {
-      if (plain) LTRX_FWD64(false, true); else LTRX_FWD64(false, false);
-    }
-#undef LTRX_FWD64
-    LTRX_LAUNCH_CHECK();
-    return LTRX_OK;
-  }
 #define LTRX_FWD(D_, P_)                                                                                                          \
   hipLaunchKernelGGL((ltrx_mha_fwd_res_kernel<D_, P_>), grid, dim3(512), RES_SMEM, s, q, k, v, kpm, L, h, dk, rs, o, ors, lse, scale, \
                      drop, seed_step, cu, order)
