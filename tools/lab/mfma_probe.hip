@@ -9,7 +9,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 template <int NCH, int NVALU, bool DO_MFMA>
-__global__ void __launch_bounds__(512) probe(float* out, unsigned long long* cyc, int iters, float seed) {
+__global__ void __launch_bounds__(1024) probe(float* out, unsigned long long* cyc, int iters, float seed) {
   f32x16 acc[NCH];
   for (int c = 0; c < NCH; ++c)
     for (int r = 0; r < 16; ++r) acc[c][r] = seed * (c + r);
@@ -40,7 +40,10 @@ __global__ void __launch_bounds__(512) probe(float* out, unsigned long long* cyc
     for (int r = 0; r < 16; ++r) s += acc[c][r];
   for (int i = 0; i < 8; ++i) s += v[i];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-  if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+  if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) {
+    cyc[2 * (threadIdx.x >> 6)] = t0;
+    cyc[2 * (threadIdx.x >> 6) + 1] = t1;
+  }
 }
 
 template <int NCH, int NVALU, bool DO_MFMA>
@@ -50,20 +53,27 @@ static void run(const char* name, int threads, int blocks, float* out, unsigned 
   hipDeviceSynchronize();
   hipLaunchKernelGGL((probe<NCH, NVALU, DO_MFMA>), dim3(blocks), dim3(threads), 0, 0, out, cyc, iters, 1.0f);
   hipDeviceSynchronize();
-  unsigned long long c = 0;
-  hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-  const int per_it = (8 / NCH) * NCH;      // MFMA slots per iteration
-  printf("%-44s threads %3d blocks %4d: %7.1f cycles per slot (MFMA%s + %d VALU)\n", name, threads, blocks, (double)c / iters / per_it, DO_MFMA ? "" : " off", NVALU);
+  unsigned long long c[16];
+  hipMemcpy(c, cyc, sizeof(c), hipMemcpyDeviceToHost);
+  const int per_it = (8 / NCH) * NCH, nw = threads / 64;      // MFMA slots per iteration
+  unsigned long long lo = c[0], hi = c[1];
+  for (int w = 0; w < nw; ++w) {
+    if (c[2 * w] < lo) lo = c[2 * w];
+    if (c[2 * w + 1] > hi) hi = c[2 * w + 1];
+  }
+  // wave 0 alone (the oldest wave wins the issue arbitration) and the whole workgroup (first start to last end)
+  printf("%-30s threads %3d blocks %4d: wave 0 %6.1f, workgroup %6.1f cycles per slot and wave (MFMA%s + %d VALU); per SIMD: %6.1f per slot\n", name, threads, blocks,
+         (double)(c[1] - c[0]) / iters / per_it, (double)(hi - lo) / iters / per_it, DO_MFMA ? "" : " off", NVALU, (double)(hi - lo) / iters / per_it / (nw / 4));
 }
 
 int main() {
   float* out;
   unsigned long long* cyc;
   hipMalloc(&out, 4096 * 512 * 4);
-  hipMalloc(&cyc, 8);
+  hipMalloc(&cyc, 16 * 8);
   for (int cfg = 0; cfg < 3; ++cfg) {
-    const int threads = cfg == 1 ? 512 : 256, blocks = cfg == 2 ? 256 : 1;
-    printf("--- %d waves per SIMD, %d workgroup(s)\n", threads / 256, blocks);
+    const int threads = cfg == 1 ? 512 : (cfg == 2 ? 1024 : 256), blocks = 1;
+    printf("--- %d wave(s) per SIMD\n", threads / 256);
     run<1, 0, true>("1 chain", threads, blocks, out, cyc);
     run<2, 0, true>("2 chains", threads, blocks, out, cyc);
     run<4, 0, true>("4 chains", threads, blocks, out, cyc);
