@@ -29,6 +29,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# dmabuf IPC (RCCL peer buffers across the ranks of a node) -- whoever launched this rank (torchrun, the driver, _self_spawn):
+# set before the HIP runtime comes up; already exported on the GPU boxes, a no-op there
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
