@@ -40,7 +40,7 @@ namespace {
 constexpr int RMAX = 256;                 // rows (items of a slate) held in LDS
 constexpr int DK = 64;                    // padded head dimension
 constexpr int PLANE = RMAX * DK * 2;      // bytes of one bf16 plane
-constexpr size_t RES_STATS = 4 * (size_t)PLANE + 3 * RMAX * sizeof(float);   // LDS bytes of the four planes + per-row statistics
+constexpr size_t RES_STATS = 4 * (size_t)PLANE + 3 * RMAX * sizeof(float);   // LDS bytes of the four planes + per-row statistics (the forward: mask bias [RMAX] + 8 tile flags)
 constexpr int XROW = 64;                  // the dS workspace's row stride is a multiple of this (64 floats = 256 bytes)
 constexpr size_t dq_smem(int nw) { return 2 * (size_t)PLANE + (size_t)nw * 32 * 32 * sizeof(float); }     // dQ kernel: 80 KB with 4 waves (two workgroups per CU)
 constexpr float kLog2e = 1.4426950408889634f;
@@ -121,7 +121,7 @@ __device__ __forceinline__ void fixed_gload(FixedRegs& f, const float* __restric
     f.x[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 }
-__device__ __forceinline__ void fixed_finish(bf16x8 (&fh)[4], bf16x8 (&fl)[4], const FixedRegs& f, f32x4* scratch) {
+__device__ __forceinline__ void fixed_finish(bf16x8 (&fh)[4], bf16x8 (&fl)[4], const FixedRegs& f, f32x4* scratch, float pre = 1.0f) {
   const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5, c16 = lane & 15;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -132,7 +132,7 @@ __device__ __forceinline__ void fixed_finish(bf16x8 (&fh)[4], bf16x8 (&fl)[4], c
   for (int ks = 0; ks < 4; ++ks) {
     const f32x4 a = scratch[l31 * 16 + ((4 * ks + 2 * half) ^ (l31 & 15))];
     const f32x4 b = scratch[l31 * 16 + ((4 * ks + 2 * half + 1) ^ (l31 & 15))];
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const float v[8] = {a.x * pre, a.y * pre, a.z * pre, a.w * pre, b.x * pre, b.y * pre, b.z * pre, b.w * pre};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       fh[ks][e] = (__bf16)v[e];
@@ -366,6 +366,125 @@ __device__ __forceinline__ bool next_slate(int L, int h, const int* __restrict__
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
+// Round 6: the forward's tile loop with FEWER INSTRUCTIONS.  profiles/r06_attention_forward_experiments.md: matrix and vector
+// instructions of a SIMD share their time and the kernel's parts add up, so the only lever is the instruction count of a tile
+// (round 5: 24 MFMA + 214 VALU + 17 exp + 29 LDS instructions per wave in the compute half).  What went:
+//   * LDS addresses: the per-lane byte offsets of the 4 K-fragment reads, the 8 transposed V reads and the mask-bias read do not depend
+//     on the tile -- computed once (13 registers), one v_add per address and tile instead of the swizzle arithmetic (~47 -> 13);
+//   * S in ONE accumulator (a dependent MFMA chain costs nothing: r06_mfma_issue_probe.txt) instead of four partial sums added up
+//     on the VALU (24 v_pk_add);
+//   * the softmax scale folded into Q before its split (prologue), the mask bias only on tiles that contain a masked or
+//     out-of-range key (a per-tile flag written by the staging threads): 16 fma + 4 LDS reads on the other tiles;
+//   * lazy rescaling: a query's reference maximum only moves when a tile exceeds it by 2^8 (P <= 256: no overflow anywhere in fp32,
+//     the bf16 hi / lo split keeps its relative precision; O / l and m + log2 l do not depend on the reference), so the 32
+//     accumulator multiplies by alpha run on the first tile and then almost never (wave-uniform branch);
+//   * the cross-half maximum with v_permlane32_swap instead of ds_bpermute (an LDS round trip);
+//   * packed fp32 arithmetic (v_pk_add_f32) for S - m, the row sum and the lo part of the P split.
+// The result differs from round 5's kernel in rounding only (summation order of S, reference of the softmax).
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float kLazyTau = 8.0f;
+__device__ __forceinline__ float max_across_halves(float x) {     // lane i <-> lane i ^ 32: {lo, lo} and {hi, hi} after the swap
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float sum_across_halves(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+struct FwdOffsets {
+  int k[4];       // K fragments: byte offset of chunk 2 ks + half of row l31 inside a 32-row tile of the K hi plane (lo plane: + PLANE)
+  int v[2][2][2]; // V transposed reads [u][ct][0 / 1]: byte offsets inside a 32-row tile, relative to the V hi plane
+  int kb;         // mask bias: byte offset of this lane half's first float inside a tile's 32 floats
+};
+__device__ __forceinline__ FwdOffsets fwd_offsets() {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5, i16 = lane & 15, g16 = (lane >> 4) & 1;
+  const int rsub = i16 >> 2, c8 = (i16 & 3) >> 1, b8 = (i16 & 1) * 8;
+  FwdOffsets f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) f.k[ks] = img_off(l31, 2 * ks + half);
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int r0 = 16 * u + 4 * half + rsub, chunk = (2 * ct + g16) * 2 + c8;
+      f.v[u][ct][0] = img_off(r0, chunk) + b8;
+      f.v[u][ct][1] = img_off(r0 + 8, chunk) + b8;
+    }
+  f.kb = 16 * half;
+  return f;
+}
+// S^T[key = rowmap(r, half)][query = l31] of one tile in one accumulator; `tile` = LDS byte address of the tile's first row in the K hi plane
+template <bool PL>
+__device__ __forceinline__ f32x16 fwd_s_tile(const unsigned char* tile, const FwdOffsets& fo, const bf16x8 (&fh)[4], const bf16x8 (&fl)[4]) {
+  bf16x8 xh[4], xl[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    xh[ks] = *reinterpret_cast<const bf16x8*>(tile + fo.k[ks]);
+    if (!PL) xl[ks] = *reinterpret_cast<const bf16x8*>(tile + fo.k[ks] + PLANE);
+  }
+  f32x16 a;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+  if (!PL) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a = LTRX_MFMA(xl[ks], fh[ks], a);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a = LTRX_MFMA(xh[ks], fl[ks], a);
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) a = LTRX_MFMA(xh[ks], fh[ks], a);
+  return a;
+}
+// O^T += V^T P^T of one tile; `tile` = LDS byte address of the tile's first row in the V hi plane
+template <bool PL>
+__device__ __forceinline__ void fwd_pv_tile(const unsigned char* tile, const FwdOffsets& fo, const f32x16& p, f32x16 (&out)[2]) {
+  ColFrags f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + fo.v[u][ct][0]));
+      const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + fo.v[u][ct][1]));
+      f.h[u][ct] = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      if (!PL) {
+        const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + fo.v[u][ct][0] + PLANE));
+        const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + fo.v[u][ct][1] + PLANE));
+        f.l[u][ct] = bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+      }
+    }
+  bf16x8 ph[2], pl[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const f32x2 x = {p[8 * u + e], p[8 * u + e + 1]};
+      const __bf16 h0 = (__bf16)x[0], h1 = (__bf16)x[1];
+      ph[u][e] = h0;
+      ph[u][e + 1] = h1;
+      if (!PL) {
+        const f32x2 hf = {(float)h0, (float)h1};
+        const f32x2 d = x - hf;
+        pl[u][e] = (__bf16)d[0];
+        pl[u][e + 1] = (__bf16)d[1];
+      }
+    }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (!PL) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) out[ct] = LTRX_MFMA(f.l[u][ct], ph[u], out[ct]);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) out[ct] = LTRX_MFMA(f.h[u][ct], pl[u], out[ct]);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) out[ct] = LTRX_MFMA(f.h[u][ct], ph[u], out[ct]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // forward: wave w owns queries 32 w .. 32 w + 31 of the slate
 // ------------------------------------------------------------------------------------------------------------------
 template <bool DROP, bool PL>
@@ -379,6 +498,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
   unsigned char* kimg = smem;
   unsigned char* vimg = smem + 2 * PLANE;
   float* kbias = reinterpret_cast<float*>(smem + 4 * PLANE);
+  int* kflag = reinterpret_cast<int*>(kbias + RMAX);           // per ring slot: does the tile hold a masked / out-of-range key?
   Touch tch = {{0.f, 0.f}};
   if (DROP && drop_step) drop.seed ^= drop_step[0] * 0x9E3779B9u;
   const Slate sl = which_slate(L, h, cu, order);
@@ -399,18 +519,25 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
   {   // (scratch: this wave's 8 KB of ring slots 4-7 of the image planes, first written by tile 4 -- four barriers from here)
     FixedRegs fq;
     fixed_gload(fq, qb, q0, len, dk, rs);
-    fixed_finish(qh, ql, fq, reinterpret_cast<f32x4*>(smem + (size_t)(wave >> 1) * PLANE + PLANE / 2 + (size_t)(wave & 1) * 8192));
+    // (Q is scaled by scale * log2 e before its split: S comes out of the MFMAs in the softmax's log2 domain)
+    fixed_finish(qh, ql, fq, reinterpret_cast<f32x4*>(smem + (size_t)(wave >> 1) * PLANE + PLANE / 2 + (size_t)(wave & 1) * 8192),
+                 scale * kLog2e);
   }
+  const FwdOffsets fo = fwd_offsets();
   f32x16 oacc[2];
   zero2(oacc);
   float m = -INFINITY, l = 0.f;
   const uint32_t drow = DROP ? drop_row_seed(drop, sl.bh, sl.Lmax, q0 + (lane & 31)) : 0u;
-  const float sl2 = scale * kLog2e;
   const int nkt = (len + 31) / 32;
   for (int kt = 0; kt < nkt; ++kt) {
     STAMP(kt, 0);
     tile_sstore<PL>(dst, kt, tr);
-    if (threadIdx.x < 32) kbias[(kt & 7) * 32 + threadIdx.x] = (kt * 32 + (int)threadIdx.x >= len || km_n) ? -INFINITY : 0.f;
+    if (threadIdx.x < 32) {
+      const bool off = kt * 32 + (int)threadIdx.x >= len || km_n;
+      kbias[(kt & 7) * 32 + threadIdx.x] = off ? -INFINITY : 0.f;
+      const bool any_off = __builtin_amdgcn_ballot_w64(off) != 0;
+      if (threadIdx.x == 0) kflag[kt & 7] = any_off ? 1 : 0;
+    }
     if (kt + 1 < nkt) {
       tile_gload(tr, src, kt + 1, len, dk, rs);       // in flight during this tile's MFMAs
       // the mask bytes of the next tile travel with it (loaded at the top of their own tile, the round trip sat between wave 0 and
@@ -430,45 +557,60 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
     STAMP(kt, 2);
     if (!active) continue;
     const int slot = (kt & 7) * 32;                            // ring slot (rows of the LDS images) of this tile
-    f32x16 s = rows_x_fixed<4, PL>(kimg, slot, qh, ql);            // S^T[key = rowmap(r, half)][query = l31]
+    const unsigned char* ktile = kimg + slot * (DK * 2);
+    f32x16 s = fwd_s_tile<PL>(ktile, fo, qh, ql);              // S^T[key = rowmap(r, half)][query = l31], log2 domain
     STAMP(kt, 3);
-    float mt = -INFINITY;
+    if (__builtin_amdgcn_readfirstlane(kflag[kt & 7])) {       // (wave-uniform) a masked or out-of-range key in this tile
+      const float* kb = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(kbias + slot) + fo.kb);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[r] = s[r] * sl2 + kbias[slot + rowmap(r, half)];
-      mt = fmaxf(mt, s[r]);
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(kb + 8 * g);       // keys 8 g + 4 half + 0..3 = rowmap(4 g + e, half)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[4 * g + e] += b4[e];
+      }
     }
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float mn = fmaxf(m, mt);
+    float mt = fmaxf(s[0], s[1]);
+#pragma unroll
+    for (int r = 2; r < 16; ++r) mt = fmaxf(mt, s[r]);
+    mt = max_across_halves(mt);
+    const bool grow = mt > m + kLazyTau;                       // (first tile: m = -inf; nothing but masked keys so far: mt = -inf -> no)
+    const float mn = grow ? mt : m;
     const float mref = (mn == -INFINITY) ? 0.f : mn;
-    const float alpha = fast_exp2(m - mref);
-    float ps = 0.f;
-    f32x16 p;
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {              // some query's reference moves: rescale what was accumulated under the old one
+      const float alpha = grow ? fast_exp2(m - mref) : 1.0f;
+      l *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      p[r] = fast_exp2(s[r] - mref);
-      ps += p[r];
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[ct][r] *= alpha;
     }
-    l = l * alpha + ps;
+    m = mn;
+    f32x16 p;
+    f32x2 ps2 = {0.f, 0.f};
+    const f32x2 mref2 = {mref, mref};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 t = f32x2{s[r], s[r + 1]} - mref2;
+      const f32x2 e2 = {fast_exp2(t[0]), fast_exp2(t[1])};
+      ps2 += e2;
+      p[r] = e2[0];
+      p[r + 1] = e2[1];
+    }
+    l += ps2[0] + ps2[1];
     if (DROP) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) p[r] *= drop_scale_rk(drop, drow, kt * 32 + rowmap(r, half));
     }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[ct][r] *= alpha;
     STAMP(kt, 4);
-    cols_x_p<PL>(vimg, slot, p, oacc);                                     // O^T[d][query] += V^T[d][key] P^T[key][query]
+    fwd_pv_tile<PL>(vimg + slot * (DK * 2), fo, p, oacc);      // O^T[d][query] += V^T[d][key] P^T[key][query]
     STAMP(kt, 5);
-    m = mn;
   }
   STAMP(33, 0);
   if (!active) {
     if (LTRX_MHA_TOUCH) touch_join(tch);
     return;
   }
-  const float lt = l + __shfl_xor(l, 32, 64);
+  const float lt = sum_across_halves(l);
   const float inv = (lt > 0.f) ? 1.0f / lt : 0.f;
   store_rows(o + sl.row0 * ors + (size_t)sl.head * dk, q0, len, dk, ors, oacc, inv, end_scratch(smem, nkt - 1, wave));
   const int qrow = q0 + (lane & 31);

@@ -996,7 +996,10 @@ def test_fused_step_with_dropout_matches_the_fp64_oracle_under_the_same_masks(d,
             ge = v.grad.detach().cpu().numpy().astype(np.float64)
             own = float(np.abs(g_or[k]).max())
             err = float(np.abs(ge - g_or[k]).max())
-            assert err <= 1e-3 * own + 1e-6 * gmax, (step, k, err, own)
+            # (the second term is the floor for tensors whose TRUE gradient is 0 -- the key-projection bias: softmax is invariant to a
+            #  per-query shift -- where the engine returns round-off of the attention backward: measured 1.1e-6 of the model's largest
+            #  gradient with round 6's forward (one S accumulator, lazy softmax reference), 0.6e-6 before)
+            assert err <= 1e-3 * own + 3e-6 * gmax, (step, k, err, own)
 
 
 def _dropout_model(p, fc_act, fc_drop, N=2):
