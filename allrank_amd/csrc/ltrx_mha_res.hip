@@ -394,15 +394,30 @@ __device__ __forceinline__ float sum_across_halves(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-struct FwdOffsets {
+// two fp32 values -> one register of two bf16 hi parts and one of two bf16 lo parts (x = hi + lo to 2^-17 relative): ONE conversion
+// per pair and part, the hi parts widened back with a shift / a mask, the subtraction packed -- 5 instructions per pair
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+template <bool PL>
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& l) {
+  const bf16x2 hp = {(__bf16)x0, (__bf16)x1};
+  h = __builtin_bit_cast(uint32_t, hp);
+  if (!PL) {
+    const f32x2 hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    const f32x2 d = f32x2{x0, x1} - hf;
+    const bf16x2 lp = {(__bf16)d[0], (__bf16)d[1]};
+    l = __builtin_bit_cast(uint32_t, lp);
+  }
+}
+struct TileOffsets {
   int k[4];       // K fragments: byte offset of chunk 2 ks + half of row l31 inside a 32-row tile of the K hi plane (lo plane: + PLANE)
   int v[2][2][2]; // V transposed reads [u][ct][0 / 1]: byte offsets inside a 32-row tile, relative to the V hi plane
   int kb;         // mask bias: byte offset of this lane half's first float inside a tile's 32 floats
 };
-__device__ __forceinline__ FwdOffsets fwd_offsets() {
+__device__ __forceinline__ TileOffsets tile_offsets() {     // (the same for every [32 rows][64] bf16 tile of every image plane)
   const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5, i16 = lane & 15, g16 = (lane >> 4) & 1;
   const int rsub = i16 >> 2, c8 = (i16 & 3) >> 1, b8 = (i16 & 1) * 8;
-  FwdOffsets f;
+  TileOffsets f;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) f.k[ks] = img_off(l31, 2 * ks + half);
 #pragma unroll
@@ -418,7 +433,7 @@ __device__ __forceinline__ FwdOffsets fwd_offsets() {
 }
 // S^T[key = rowmap(r, half)][query = l31] of one tile in one accumulator; `tile` = LDS byte address of the tile's first row in the K hi plane
 template <bool PL>
-__device__ __forceinline__ f32x16 fwd_s_tile(const unsigned char* tile, const FwdOffsets& fo, const bf16x8 (&fh)[4], const bf16x8 (&fl)[4]) {
+__device__ __forceinline__ f32x16 rows_mma(const unsigned char* tile, const TileOffsets& fo, const bf16x8 (&fh)[4], const bf16x8 (&fl)[4]) {
   bf16x8 xh[4], xl[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
@@ -440,7 +455,7 @@ __device__ __forceinline__ f32x16 fwd_s_tile(const unsigned char* tile, const Fw
 }
 // O^T += V^T P^T of one tile; `tile` = LDS byte address of the tile's first row in the V hi plane
 template <bool PL>
-__device__ __forceinline__ void fwd_pv_tile(const unsigned char* tile, const FwdOffsets& fo, const f32x16& p, f32x16 (&out)[2]) {
+__device__ __forceinline__ void cols_mma(const unsigned char* tile, const TileOffsets& fo, const f32x16& p, f32x16 (&out)[2]) {
   ColFrags f;
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -457,20 +472,18 @@ __device__ __forceinline__ void fwd_pv_tile(const unsigned char* tile, const Fwd
     }
   bf16x8 ph[2], pl[2];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < 2; ++u) {
+    u32x4 hw, lw = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-      const f32x2 x = {p[8 * u + e], p[8 * u + e + 1]};
-      const __bf16 h0 = (__bf16)x[0], h1 = (__bf16)x[1];
-      ph[u][e] = h0;
-      ph[u][e + 1] = h1;
-      if (!PL) {
-        const f32x2 hf = {(float)h0, (float)h1};
-        const f32x2 d = x - hf;
-        pl[u][e] = (__bf16)d[0];
-        pl[u][e + 1] = (__bf16)d[1];
-      }
+    for (int j = 0; j < 4; ++j) {
+      uint32_t hj, lj = 0u;
+      split_pair<PL>(p[8 * u + 2 * j], p[8 * u + 2 * j + 1], hj, lj);
+      hw[j] = hj;
+      lw[j] = lj;
     }
+    ph[u] = __builtin_bit_cast(bf16x8, hw);
+    pl[u] = __builtin_bit_cast(bf16x8, lw);
+  }
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     if (!PL) {
@@ -523,7 +536,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
     fixed_finish(qh, ql, fq, reinterpret_cast<f32x4*>(smem + (size_t)(wave >> 1) * PLANE + PLANE / 2 + (size_t)(wave & 1) * 8192),
                  scale * kLog2e);
   }
-  const FwdOffsets fo = fwd_offsets();
+  const TileOffsets fo = tile_offsets();
   f32x16 oacc[2];
   zero2(oacc);
   float m = -INFINITY, l = 0.f;
@@ -558,7 +571,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
     if (!active) continue;
     const int slot = (kt & 7) * 32;                            // ring slot (rows of the LDS images) of this tile
     const unsigned char* ktile = kimg + slot * (DK * 2);
-    f32x16 s = fwd_s_tile<PL>(ktile, fo, qh, ql);              // S^T[key = rowmap(r, half)][query = l31], log2 domain
+    f32x16 s = rows_mma<PL>(ktile, fo, qh, ql);              // S^T[key = rowmap(r, half)][query = l31], log2 domain
     STAMP(kt, 3);
     if (__builtin_amdgcn_readfirstlane(kflag[kt & 7])) {       // (wave-uniform) a masked or out-of-range key in this tile
       const float* kb = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(kbias + slot) + fo.kb);
@@ -602,7 +615,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
       for (int r = 0; r < 16; ++r) p[r] *= drop_scale_rk(drop, drow, kt * 32 + rowmap(r, half));
     }
     STAMP(kt, 4);
-    fwd_pv_tile<PL>(vimg + slot * (DK * 2), fo, p, oacc);      // O^T[d][query] += V^T[d][key] P^T[key][query]
+    cols_mma<PL>(vimg + slot * (DK * 2), fo, p, oacc);      // O^T[d][query] += V^T[d][key] P^T[key][query]
     STAMP(kt, 5);
   }
   STAMP(33, 0);
@@ -671,6 +684,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
   }
   f32x16 dqacc[2];
   zero2(dqacc);
+  const TileOffsets fo = tile_offsets();
   for (int c = 0; c < nchunk; ++c) {
     if (c > 0) lds_only_barrier();                     // every wave is done with the previous chunk of K
 #pragma unroll
@@ -701,7 +715,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
         ds[4 * g + 2] = x.z;
         ds[4 * g + 3] = x.w;
       }
-      cols_x_p<PL>(kimg, s * 32, ds, dqacc);              // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+      cols_mma<PL>(kimg + s * 32 * (DK * 2), fo, ds, dqacc);      // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
     }
   }
   if (!active) return;
@@ -768,12 +782,16 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
     const uint8_t km = kpm ? kpm[sl.row0 + (key < len ? key : 0)] : (uint8_t)0;
     // scratch: this wave's 8 KB of ring slots 4-7 of the image planes (first written by tile 4, four barriers from here)
     f32x4* scratch = reinterpret_cast<f32x4*>(smem + (size_t)(wave >> 1) * PLANE + PLANE / 2 + (size_t)(wave & 1) * 8192);
-    fixed_finish(kh, kl, fk, scratch);
-    fixed_finish(vh, vl, fv, scratch);
+    // (round 6: the two factors every element of a tile used to be multiplied by are folded into the fixed operands before their split --
+    //  K carries scale * log2 e, so S comes out of the MFMAs in the softmax's log2 domain; V carries scale, so dO V^T is scale * dP, and
+    //  the staging threads store scale * delta: dS = P (scale dP - scale delta))
+    fixed_finish(kh, kl, fk, scratch, scale * kLog2e);
+    fixed_finish(vh, vl, fv, scratch, scale);
     key_masked = (key >= len) || km != 0;
   }
   const float kbias = key_masked ? -INFINITY : 0.f;
-  const float sl2 = scale * kLog2e;
+  const f32x2 kb2 = {kbias, kbias};
+  const TileOffsets fo = tile_offsets();
   f32x16 dkacc[2], dvacc[2];
   zero2(dkacc);
   zero2(dvacc);
@@ -787,7 +805,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
     DSTAMP(qt, 0);
     if (!first) {                                                // (rows beyond the slate were loaded as zeros: delta 0)
       const float d = tile_delta(tr, to);
-      if ((threadIdx.x & 7) == 0) del_t[(qt & 7) * 32 + ((threadIdx.x & 255) >> 3)] = d;
+      if ((threadIdx.x & 7) == 0) del_t[(qt & 7) * 32 + ((threadIdx.x & 255) >> 3)] = d * scale;
     }
     tile_sstore<PL>(dst, qt, tr);
     if (threadIdx.x < 32) {                                      // per-query statistics of this tile (ring slot)
@@ -808,16 +826,38 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
     const int slot = (qt & 7) * 32;
     // (order chosen for register pressure: both 16-register products first, then the two accumulations; the fences keep the
     //  scheduler from hoisting the second accumulation's transposed reads above the first)
-    f32x16 p = rows_x_fixed<2, PL>(qimg, slot, kh, kl);               // S[query = rowmap(r, half)][key = l31]
-    f32x16 ds = rows_x_fixed<2, PL>(doimg, slot, vh, vl);            // dP[query][key] = dO V^T
+    const unsigned char* qtile = qimg + slot * (DK * 2);
+    const unsigned char* dotile = doimg + slot * (DK * 2);
+    f32x16 p = rows_mma<PL>(qtile, fo, kh, kl);                       // S[query = rowmap(r, half)][key = l31], log2 domain
+    f32x16 ds = rows_mma<PL>(dotile, fo, vh, vl);                     // scale * dP[query][key] = scale * dO V^T
     DSTAMP(qt, 3);
+    {
+      const float* lse_p = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(lse_t + slot) + fo.kb);
+      const float* del_p = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(del_t + slot) + fo.kb);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qr = slot + rowmap(r, half);
-      const float pr = fast_exp2(p[r] * sl2 + kbias - lse_t[qr]);
-      const float dm = DROP ? drop_scale_rk(drop, drow_t[qr], key) : 1.0f;
-      ds[r] = pr * (ds[r] * dm - del_t[qr]) * scale;             // dS
-      p[r] = pr * dm;                                            // P M
+      for (int g = 0; g < 4; ++g) {                                   // rows 8 g + 4 half + 0..3 = rowmap(4 g + e, half)
+        const f32x4 ls4 = *reinterpret_cast<const f32x4*>(lse_p + 8 * g);
+        const f32x4 dl4 = *reinterpret_cast<const f32x4*>(del_p + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          const int r = 4 * g + e;
+          const f32x2 t = (f32x2{p[r], p[r + 1]} - f32x2{ls4[e], ls4[e + 1]}) + kb2;
+          const f32x2 pr = {fast_exp2(t[0]), fast_exp2(t[1])};
+          f32x2 dm = {1.0f, 1.0f};
+          if (DROP) {
+            const int qr = slot + rowmap(r, half);
+            dm = f32x2{drop_scale_rk(drop, drow_t[qr], key), drop_scale_rk(drop, drow_t[qr + 1], key)};
+          }
+          const f32x2 dpv = {ds[r], ds[r + 1]};
+          const f32x2 x = (DROP ? dpv * dm : dpv) - f32x2{dl4[e], dl4[e + 1]};
+          const f32x2 dsv = pr * x;                                   // dS
+          const f32x2 pm = DROP ? pr * dm : pr;                       // P M
+          ds[r] = dsv[0];
+          ds[r + 1] = dsv[1];
+          p[r] = pm[0];
+          p[r + 1] = pm[1];
+        }
+      }
     }
     DSTAMP(qt, 4);
     {
@@ -839,10 +879,10 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
     }
     DSTAMP(qt, 5);
     __builtin_amdgcn_sched_barrier(0);
-    cols_x_p<PL>(doimg, slot, p, dvacc);                             // dV^T[d][key] += dO^T[d][query] (P M)[query][key]
+    cols_mma<PL>(dotile, fo, p, dvacc);                              // dV^T[d][key] += dO^T[d][query] (P M)[query][key]
     DSTAMP(qt, 6);
     __builtin_amdgcn_sched_barrier(0);
-    cols_x_p<PL>(qimg, slot, ds, dkacc);                             // dK^T[d][key] += Q^T[d][query] dS[query][key]
+    cols_mma<PL>(qtile, fo, ds, dkacc);                              // dK^T[d][key] += Q^T[d][query] dS[query][key]
     DSTAMP(qt, 7);
     __builtin_amdgcn_sched_barrier(0);
   }
