@@ -171,6 +171,9 @@ __device__ unsigned long long g_mha_stamps[8][40][8];       // (or of the dK/dV 
 #ifndef LTRX_MHA_TOUCH
 #define LTRX_MHA_TOUCH 1
 #endif
+#ifndef LTRX_MHA_PRIO_HALF        // static priority for the second-dispatched half of an eight-wave workgroup (the arbitration loser of every segment)
+#define LTRX_MHA_PRIO_HALF 0
+#endif
 #ifndef LTRX_MHA_SETPRIO
 #define LTRX_MHA_SETPRIO 0
 #endif
@@ -537,6 +540,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_fwd_res_kernel(const float* __re
                  scale * kLog2e);
   }
   const TileOffsets fo = tile_offsets();
+  if (LTRX_MHA_PRIO_HALF && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
   f32x16 oacc[2];
   zero2(oacc);
   float m = -INFINITY, l = 0.f;
@@ -796,6 +800,7 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
   zero2(dkacc);
   zero2(dvacc);
   const int nqt = (len + 31) / 32;
+  if (LTRX_MHA_PRIO_HALF && wave >= 4) __builtin_amdgcn_s_setprio(1);
   // dS tile addressing: a wave-uniform base (scalar registers) + ONE 32-bit per-lane offset, so that the 16 stores of a tile cost
   // no vector registers beyond the data (the kernel sits at the 256-register limit)
   float* const dsp = dsw + ((size_t)sl.b * h + sl.head) * LK * LK + (blockIdx.y * RMAX + wave * 32);
