@@ -22,6 +22,7 @@
 //     dS with the queries inside a lane, also writes it to an HBM workspace, and dQ = dS K -- which needs the keys inside a lane --
 //     is a second, memory-bound kernel that reads it back: the transposition happens in memory, deterministically (no atomics,
 //     no cross-wave reduction; everything in one kernel does not fit the LDS: Q, dO, K, V images alone are 256 KB).
+// (Round 6: the tile loops were put on an instruction diet -- see the block above the forward kernel.)
 // Softmax in the log2 domain, natural-log LSE saved, dropout on P regenerated from (seed, query row, key) -- identical
 // conventions to ltrx_mha.hip, so forward / backward kernels of the two paths are interchangeable.  Variable-length
 // (cu_seqlens) batches: slate b is rows cu[b] .. cu[b+1]-1; waves beyond the slate's length exit after the staging barrier.
@@ -174,105 +175,13 @@ __device__ unsigned long long g_mha_stamps[8][40][8];       // (or of the dK/dV 
 #ifndef LTRX_MHA_PRIO_HALF        // static priority for the second-dispatched half of an eight-wave workgroup (the arbitration loser of every segment)
 #define LTRX_MHA_PRIO_HALF 0
 #endif
-#ifndef LTRX_MHA_SETPRIO
-#define LTRX_MHA_SETPRIO 0
-#endif
 
-// acc[r] = sum_c IMG[tile_row0 + rowmap(r, half)][c] * FIXED[l31][c].  NACC accumulators (4: one per 16-deep k-step, term-major
-// order, consecutive MFMAs never write the same accumulator; 2: 32 fewer live registers for the kernels at the VGPR limit)
-template <int NACC, bool PL>
-__device__ __forceinline__ f32x16 rows_x_fixed(const unsigned char* img, int tile_row0, const bf16x8 (&fh)[4], const bf16x8 (&fl)[4]) {
-  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
-  f32x16 a[NACC];
-  bf16x8 xh[4], xl[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int o = img_off(tile_row0 + l31, 2 * ks + half);
-    xh[ks] = *reinterpret_cast<const bf16x8*>(img + o);
-    if (!PL) xl[ks] = *reinterpret_cast<const bf16x8*>(img + PLANE + o);
-  }
-#pragma unroll
-  for (int n = 0; n < NACC; ++n)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[n][r] = 0.f;
-  if (LTRX_MHA_SETPRIO) __builtin_amdgcn_s_setprio(1);
-  if (!PL) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) a[ks % NACC] = LTRX_MFMA(xl[ks], fh[ks], a[ks % NACC]);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) a[ks % NACC] = LTRX_MFMA(xh[ks], fl[ks], a[ks % NACC]);
-  }
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) a[ks % NACC] = LTRX_MFMA(xh[ks], fh[ks], a[ks % NACC]);
-  if (LTRX_MHA_SETPRIO) __builtin_amdgcn_s_setprio(0);
-  if (NACC == 4) return (a[0] + a[1]) + (a[2] + a[3]);
-  return a[0] + a[1 % NACC];
-}
-
-// out[ct][r'] += sum_row IMG[tile_row0 + row][32 ct + l31] * p[row]    (p in D layout: register r <-> tile row rowmap(r, half))
-// The A fragment (column 32 ct + l31, rows {16u + 4 half + 0..3, 16u + 8 + 4 half + 0..3}) comes from two transposed reads.
-// (read_cols / mma_cols are separate so that a kernel can place the 16 reads ahead of the arithmetic that produces p; measured on
-// MI355X, round 2: issuing them before the softmax / dS arithmetic, or fencing reads from MFMAs, changes nothing -- +-1 %,
-// gpurun_out/mha_ab.txt -- the second wave of each SIMD already covers that latency.)
+// Tile products.  Row-wise: acc[r] = sum_c IMG[tile_row0 + rowmap(r, half)][c] * FIXED[l31][c] (rows_mma below).  Column-wise:
+// out[ct][r'] += sum_row IMG[tile_row0 + row][32 ct + l31] * p[row]  (p in D layout: register r <-> tile row rowmap(r, half); cols_mma
+// below): the A fragment (column 32 ct + l31, rows {16u + 4 half + 0..3, 16u + 8 + 4 half + 0..3}) comes from two transposed reads.
 struct ColFrags {
   bf16x8 h[2][2], l[2][2];          // [u][ct]
 };
-template <bool PL>
-__device__ __forceinline__ void read_cols(const unsigned char* img, int tile_row0, ColFrags& f) {
-  const int lane = threadIdx.x & 63, half = lane >> 5, i16 = lane & 15, g16 = (lane >> 4) & 1;
-  // lane i16 of a 16-lane group supplies the address of row (i16 >> 2), columns 4 (i16 & 3) .. +3 of the [4][16] block
-  const int rsub = i16 >> 2, c8 = (i16 & 3) >> 1, b8 = (i16 & 1) * 8;
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int r0 = tile_row0 + 16 * u + 4 * half + rsub;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int chunk = (2 * ct + g16) * 2 + c8;
-      const int o0 = img_off(r0, chunk) + b8, o1 = img_off(r0 + 8, chunk) + b8;
-      const bf16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + o0));
-      const bf16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + o1));
-      f.h[u][ct] = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-      if (!PL) {
-        const bf16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + PLANE + o0));
-        const bf16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(img + PLANE + o1));
-        f.l[u][ct] = bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-      }
-    }
-  }
-}
-template <bool PL>
-__device__ __forceinline__ void mma_cols(const ColFrags& f, const f32x16& p, f32x16 (&out)[2]) {
-  bf16x8 ph[2], pl[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float x = p[8 * u + e];
-      const __bf16 h = (__bf16)x;
-      ph[u][e] = h;
-      pl[u][e] = (__bf16)(x - (float)h);
-    }
-  if (LTRX_MHA_SETPRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    if (!PL) {
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) out[ct] = LTRX_MFMA(f.l[u][ct], ph[u], out[ct]);
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) out[ct] = LTRX_MFMA(f.h[u][ct], pl[u], out[ct]);
-    }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) out[ct] = LTRX_MFMA(f.h[u][ct], ph[u], out[ct]);
-  }
-  if (LTRX_MHA_SETPRIO) __builtin_amdgcn_s_setprio(0);
-}
-template <bool PL>
-__device__ __forceinline__ void cols_x_p(const unsigned char* img, int tile_row0, const f32x16& p, f32x16 (&out)[2]) {
-  ColFrags f;
-  read_cols<PL>(img, tile_row0, f);
-  mma_cols<PL>(f, p, out);
-}
-
 // lane owns output row row0 + l31; register 4g + e of out[ct] is column 32 ct + 8 g + 4 half + e.  Written through a wave-private
 // 4-KB LDS scratch, one [32 rows][32 columns] half at a time, so that a store instruction covers 8 rows x 128 contiguous bytes
 // instead of 64 lanes x 16 bytes in 32 different rows (the texture-address unit pays per line: 64 instead of 512 line writes per
@@ -369,8 +278,8 @@ __device__ __forceinline__ bool next_slate(int L, int h, const int* __restrict__
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
-// Round 6: the forward's tile loop with FEWER INSTRUCTIONS.  profiles/r06_attention_forward_experiments.md: matrix and vector
-// instructions of a SIMD share their time and the kernel's parts add up, so the only lever is the instruction count of a tile
+// Round 6: the tile loops of all three kernels with FEWER INSTRUCTIONS (the list below is the forward's; the backward's is at its kernels).  profiles/r06_attention_forward_experiments.md: about two thirds of a
+// SIMD's vector-instruction time is ADDED to its matrix time and the kernel's parts add up, so the lever is the instruction count of a tile
 // (round 5: 24 MFMA + 214 VALU + 17 exp + 29 LDS instructions per wave in the compute half).  What went:
 //   * LDS addresses: the per-lane byte offsets of the 4 K-fragment reads, the 8 transposed V reads and the mask-bias read do not depend
 //     on the tile -- computed once (13 registers), one v_add per address and tile instead of the swizzle arithmetic (~47 -> 13);
