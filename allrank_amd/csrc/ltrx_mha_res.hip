@@ -779,6 +779,8 @@ __global__ void __launch_bounds__(512) ltrx_mha_bwd_dkdv_res_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r)         // (asm: hipcc otherwise keeps 16 loop-invariant 64-bit vector addresses = 32 registers)
         asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(dso), "v"(ds[r]), "s"(t + (size_t)((r & 3) + 8 * (r >> 2)) * LK));
+      // (round 6 probe: the same tile as four 16-byte stores per lane in a [key][query] layout -- 32-byte pieces in 32 rows -- made the
+      //  tile 9-13 k cycles instead of 7.1 k: sixteen 128-byte row segments per instruction pair beat four scattered wide stores)
     }
     __builtin_amdgcn_sched_barrier(0);
     // the next tile's loads go out AFTER the dS stores: the wait that precedes the next tile_sstore is vmcnt(0) and the memory
