@@ -319,6 +319,65 @@ def test_attention_forward_backward(B, L, h, dk, mode):
     assert np.all(g[:, :, d:][np.broadcast_to(mask[:, :, None], (B, L, 2 * d))] == 0)   # padded keys get exactly 0
 
 
+@pytest.mark.parametrize("step", [0.6, 5.0, 11.0, 40.0])
+def test_attention_lazy_softmax_reference_is_invariant_to_the_key_order(step):
+    """Round 6: the LDS-resident forward keeps a LAZY softmax reference (a query's reference maximum only moves when a 32-key tile exceeds
+    it by 2^8; until then P is taken relative to the stale reference and the O accumulators are not rescaled).  Random inputs almost never
+    move the reference after the first tile, so this test builds logits that CLIMB with the key index -- by `step` natural-log units per
+    32-key tile: 0.6 never moves the reference after tile 0 (P grows to ~2^6 against it), 5 moves it every second tile, 11 and 40 every
+    tile -- and compares with the SAME keys and values in REVERSED order: there the first tile holds the largest scores, the reference is
+    set once and never moves.  Attention is invariant to a joint permutation of keys and values, every (query, key) score is the same dot
+    product with the same three-product rounding in both runs, so the two outputs may differ by the summation order of the softmax only --
+    any error of the lazy-reference bookkeeping (a missed or doubled rescale, a wrong LSE) shows at O(1).  Gradients likewise (dk, dv
+    flipped back).  Logits this large are outside the accuracy bars of the fp32-class arithmetic itself (|s| 2^-17 per score), which is
+    why the comparison is between two orders of one arithmetic and not with the fp64 oracle; the oracle only bounds the output loosely."""
+    from allrank_amd import ops
+    B, L, h, dk = 2, 240, 2, 64
+    d = h * dk
+    rng = np.random.default_rng(int(step * 10) + 3)
+    qkv = (0.05 * rng.standard_normal((B, L, 3 * d))).astype(np.float32)
+    ramp = (np.arange(L) // 32).astype(np.float32) * step
+    for hh in range(h):
+        qkv[:, :, hh * dk] = 2.0                                                     # q . k / sqrt(dk) = ramp(key) + noise
+        qkv[:, :, d + hh * dk] = ramp * np.sqrt(dk) / 2.0
+    qkv[1, 100:140, 0] = -2.0                                                        # these queries see the ramp falling
+    qkv[:, :, 2 * d:] = rng.standard_normal((B, L, d)).astype(np.float32)
+    mask = np.zeros((B, L), dtype=bool)
+    mask[1, 230:] = True
+    go = rng.standard_normal((B, L, d)).astype(np.float32)
+    res = {}
+    for name, flip in (("climbing", False), ("reversed", True)):
+        x, mk = qkv.copy(), mask.copy()
+        if flip:                                   # keys and values (and their padding mask) in reversed order, queries as they were
+            x[:, :, d:] = qkv[:, ::-1, d:]
+            mk = mask[:, ::-1].copy()
+        t = _t(x, True)
+        with ops.arithmetic(attention=1):
+            o = ops.attention(t[:, :, :d], t[:, :, d:2 * d], t[:, :, 2 * d:], _t(mk), h)
+        (o * _t(go)).sum().backward()
+        g = t.grad.cpu().numpy().astype(np.float64)
+        if flip:
+            g[:, :, d:] = g[:, ::-1, d:].copy()    # dk, dv back in the original key order
+        res[name] = (o.detach().cpu().numpy().astype(np.float64), g)
+        assert np.isfinite(res[name][0]).all() and np.isfinite(res[name][1]).all(), name
+    (o1, g1), (o2, g2) = res["climbing"], res["reversed"]
+    vmax = float(np.abs(qkv[:, :, 2 * d:]).max())
+    err = dict(o=float(np.abs(o1 - o2).max()) / vmax)
+    kmax = float(np.abs(qkv[:, :, d:2 * d]).max())
+    for nm, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        # (scale: the largest gradient entry of the three tensors; dq = sum_k dS k is a sum of terms |k| times larger than that -- k is
+        #  dominated by the ramp feature, up to 1120 -- whose fp32 accumulation ORDER differs between the two runs: its bar carries |k|max)
+        err[nm] = float(np.abs(g1[:, :, sl] - g2[:, :, sl]).max()) / float(np.abs(g1).max()) / (max(kmax, 1.0) if nm == "dq" else 1.0)
+    # loose sanity bound against the fp64 oracle (the arithmetic's own error at these logits, not the reference logic)
+    heads = lambda x: x.reshape(B, L, h, dk).transpose(0, 2, 1, 3).astype(np.float64)      # noqa: E731
+    oo, _p = M.attention_fwd(heads(qkv[:, :, :d]), heads(qkv[:, :, d:2 * d]), heads(qkv[:, :, 2 * d:]), mask)
+    err["o_vs_fp64"] = float(np.abs(o1 - oo.transpose(0, 2, 1, 3).reshape(B, L, d)).max()) / vmax
+    _log("attention_key_order_%g" % step, err)
+    # measured on the MI355X: o <= 2.8e-6, dk <= 2.6e-6, dv <= 1.7e-6, dq <= 1.04e-6 (per unit of |k|max), o vs fp64 <= 1.4e-5
+    assert err["o"] < 1e-5 and err["dq"] < 3e-6 and err["dk"] < 1e-5 and err["dv"] < 1e-5, err
+    assert err["o_vs_fp64"] < 1e-4, err
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_attention_fully_masked_slate_is_zero_and_finite(mode):
     """A slate whose keys are all padding (dataset.py pads whole slates when a batch is short): output and all three input
