@@ -747,7 +747,7 @@ def main():
                             backward=_ar(kb, 4.0 * B * L * 8 * d_ + 4.0 * B * h_ * L,
                                          dict(ds_handover_bytes=ds_b, hbm_gbps_with_ds_handover=round((4.0 * B * L * 8 * d_ + ds_b) / kb["sec"] / 1e9, 1),
                                               kernels="ltrx_mha_bwd_dkdv_res_kernel + ltrx_mha_bwd_dq_res_kernel")),
-                            notes="profiles/r04_pmc_step_bytes_256.md (PMC traffic of both backward kernels), profiles/NOTES.md (chunked / 24-bit dS hand-over: measured slower)")
+                            notes="profiles/r06_attention_forward_experiments.md (round 6: the tile period is the SUM of its MFMA, vector, LDS and staging parts; 64-query forward and phase shift slower; instruction diet: forward 182 -> 162 us, dK/dV 343 -> 325 us), profiles/r04_pmc_step_bytes_256.md (PMC traffic of both backward kernels), profiles/NOTES.md (chunked / 24-bit dS hand-over: measured slower)")
         loss_roof = None
         if w["loss"].startswith("neuralNDCG"):
             # the Sinkhorn kernels are VALU bound (no contraction): algorithmic flops = n^2 x (4 per forward step + 6 per backward step)
