@@ -742,7 +742,7 @@ def main():
                 r_.update(extra or {})
                 return r_
             ds_b = 2.0 * 4.0 * B * h_ * LK * LK
-            att_roof = dict(bound="mfma (VALU-side: softmax and the split of P / dS beside the matrix pipe)", launches_per_step=w["N"],
+            att_roof = dict(bound="mfma (issue-side: the softmax / split arithmetic and the LDS fragment reads ADD to the matrix time, they do not hide behind it)", launches_per_step=w["N"],
                             forward=_ar(kf, 4.0 * B * L * 4 * d_ + 4.0 * B * h_ * L),
                             backward=_ar(kb, 4.0 * B * L * 8 * d_ + 4.0 * B * h_ * L,
                                          dict(ds_handover_bytes=ds_b, hbm_gbps_with_ds_handover=round((4.0 * B * L * 8 * d_ + ds_b) / kb["sec"] / 1e9, 1),
